@@ -1,0 +1,195 @@
+"""Deterministic synthetic workload generators for the SVOL hot path.
+
+Everything here is numpy ``RandomState`` based (stable across numpy/torch
+versions and across machines) so that the golden fixtures under
+``tests/golden/`` — which were produced by feeding exactly these tensors to the
+reference implementation — can be regenerated bit-for-bit on the GPU box
+without shipping weights.
+
+Workload definition follows SURVEY.md §8(d) / BASELINE.md §3: features ~ N(0,1)
+at the head boundary ``SVANet.forward(src_sketch[B,1,Din], src_sketch_mask[B,1],
+src_video[B,T*P,Din], src_video_mask[B,T*P])`` (reference svanet.py:65), targets
+per frame m ~ U{0,1,2} boxes with at least one box in frame 0
+(svol_dataset.py:272 guarantees >=1 box per video), cx,cy ~ U(.25,.75),
+w,h ~ U(.05,.35), cxcywh.
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+D_FF = 2048  # hard-coded in the reference (cross_modal_transformer.py:196-202)
+
+
+def head_args(**over) -> SimpleNamespace:
+    """Namespace with every field the head + criterion read."""
+    a = dict(
+        hidden_dim=256, nheads=8, num_layers=6, num_queries=100,
+        num_queries_per_frame=10, num_frames=32,
+        input_vid_dim=512, input_skch_dim=512, input_dropout=0.4,
+        n_input_proj=2, aux_loss=True, use_sketch_pos=True, vis_mode=None,
+        sketch_position_embedding='sine', video_position_embedding='sine',
+        matcher='video_matcher', set_cost_bbox=5, set_cost_giou=1,
+        set_cost_class=2, eos_coef=0.1, bbox_type='cxcywh',
+        sketch_head='svanet',
+    )
+    a.update(over)
+    return SimpleNamespace(**a)
+
+
+# named workload configurations (BASELINE.json "configs")
+def cfg1_args(matcher='video_matcher'):
+    n = 10 if matcher == 'video_matcher' else 40
+    return head_args(hidden_dim=64, nheads=8, num_layers=1, num_queries=n,
+                     num_queries_per_frame=10, num_frames=4, matcher=matcher)
+
+
+def cfg2_args(matcher='video_matcher'):
+    n = 100 if matcher == 'video_matcher' else 320
+    return head_args(hidden_dim=256, nheads=8, num_layers=6, num_queries=n,
+                     num_queries_per_frame=10, num_frames=32, matcher=matcher)
+
+
+CFG_SHAPES = {
+    'cfg1': dict(B=1, T=4, P=49),
+    'cfg2': dict(B=8, T=32, P=196),
+    'cfg5': dict(B=1, T=128, P=256),
+}
+
+
+def head_param_shapes(args) -> "OrderedDict[str, tuple]":
+    """Parameter names/shapes of the SVANet head, in the reference's
+    ``state_dict()`` order (probed from the reference; pinned by
+    tests/golden/*.npz ``keys``)."""
+    d, nl = args.hidden_dim, args.num_layers
+    out = OrderedDict()
+    attn = ['sketch_video_cross_attn', 'content_self_attn', 'token_self_attn',
+            'content_token_cross_attn']
+    for i in range(nl):
+        p = f'transformer.layers.{i}.'
+
+        def mha(name):
+            out[p + name + '.in_proj_weight'] = (3 * d, d)
+            out[p + name + '.in_proj_bias'] = (3 * d,)
+            out[p + name + '.out_proj.weight'] = (d, d)
+            out[p + name + '.out_proj.bias'] = (d,)
+
+        def norm(k):
+            out[p + f'norm{k}.weight'] = (d,)
+            out[p + f'norm{k}.bias'] = (d,)
+
+        def mlp(k):
+            out[p + f'mlp{k}.fc1.weight'] = (D_FF, d)
+            out[p + f'mlp{k}.fc1.bias'] = (D_FF,)
+            out[p + f'mlp{k}.fc2.weight'] = (d, D_FF)
+            out[p + f'mlp{k}.fc2.bias'] = (d,)
+
+        mha(attn[0]); norm(1)
+        mha(attn[1]); norm(2)
+        mlp(1); norm(3)
+        mha(attn[2]); norm(4)
+        mha(attn[3]); norm(5)
+        mlp(2); norm(6)
+    for j, (o, i_) in enumerate([(d, d), (d, d), (4, d)]):
+        out[f'bbox_embed.layers.{j}.weight'] = (o, i_)
+        out[f'bbox_embed.layers.{j}.bias'] = (o,)
+    out['class_embed.weight'] = (2, d); out['class_embed.bias'] = (2,)
+    out['class_head.weight'] = (2, d); out['class_head.bias'] = (2,)
+    out['query_embed.weight'] = (args.num_queries, d)
+    for name, din in (('input_video_proj', args.input_vid_dim),
+                      ('input_sketch_proj', args.input_skch_dim)):
+        for j in range(args.n_input_proj):
+            i_ = din if j == 0 else d
+            out[f'{name}.{j}.LayerNorm.weight'] = (i_,)
+            out[f'{name}.{j}.LayerNorm.bias'] = (i_,)
+            out[f'{name}.{j}.net.1.weight'] = (d, i_)
+            out[f'{name}.{j}.net.1.bias'] = (d,)
+    return out
+
+
+def _rs(key: str, seed: int) -> np.random.RandomState:
+    return np.random.RandomState((zlib.crc32(key.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+
+
+def synth_state_dict(args, seed: int = 1) -> "OrderedDict[str, torch.Tensor]":
+    """Deterministic non-trivial fp32 weights for every head parameter.
+
+    Matrices: Xavier-uniform range (what the reference re-initialises its
+    transformer with, cross_modal_transformer.py:22-25); biases U(-.1,.1);
+    LayerNorm weight 1+U(-.1,.1) so that every gradient path is exercised.
+    """
+    sd = OrderedDict()
+    for k, shp in head_param_shapes(args).items():
+        r = _rs(k, seed)
+        if k == 'query_embed.weight':
+            v = r.standard_normal(shp)
+        elif len(shp) == 2:
+            a = float(np.sqrt(6.0 / (shp[0] + shp[1])))
+            v = r.uniform(-a, a, size=shp)
+        elif ('norm' in k or 'LayerNorm' in k) and k.endswith('weight'):
+            v = 1.0 + r.uniform(-0.1, 0.1, size=shp)
+        else:
+            v = r.uniform(-0.1, 0.1, size=shp)
+        sd[k] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+    return sd
+
+
+def synth_inputs(args, B: int, T: int, P: int, seed: int = 1, pad_frames: int = 0):
+    """Head-boundary inputs. ``pad_frames``: number of trailing frames marked
+    padding (mask 0) in every odd batch element (exercises key_padding_mask)."""
+    r = _rs('inputs', seed)
+    L = T * P
+    src_video = r.standard_normal((B, L, args.input_vid_dim)).astype(np.float32)
+    src_sketch = r.standard_normal((B, 1, args.input_skch_dim)).astype(np.float32)
+    vmask = np.ones((B, L), np.float32)
+    if pad_frames:
+        for b in range(B):
+            if b % 2 == 1:
+                vmask[b, (T - pad_frames) * P:] = 0.0
+    smask = np.ones((B, 1), np.float32)
+    return dict(src_sketch=torch.from_numpy(src_sketch),
+                src_sketch_mask=torch.from_numpy(smask),
+                src_video=torch.from_numpy(src_video),
+                src_video_mask=torch.from_numpy(vmask))
+
+
+def synth_targets(B: int, T: int, seed: int = 1, max_per_frame: int = 2):
+    """``targets`` list in the reference's schema (svol_dataset.py:18-44):
+    ``'bboxes': {frame_idx: [{'track_id', 'bbox': Tensor[4] cxcywh}]}``,
+    ``'num_boxes_per_frame': list[T]``."""
+    r = _rs('targets', seed)
+    targets = []
+    for b in range(B):
+        bboxes = OrderedDict()
+        nbf = []
+        for t in range(T):
+            m = int(r.randint(0, max_per_frame + 1))
+            if t == 0 and m == 0:
+                m = 1
+            frame = []
+            for j in range(m):
+                cxcy = r.uniform(0.25, 0.75, size=2)
+                wh = r.uniform(0.05, 0.35, size=2)
+                box = np.concatenate([cxcy, wh]).astype(np.float32)
+                frame.append({'track_id': j, 'bbox': torch.from_numpy(box)})
+            bboxes[t * 3] = frame  # frame ids are arbitrary sampled indices
+            nbf.append(m)
+        targets.append({'video': f'synthetic_{b:04d}', 'size': [480, 360],
+                        'sketch': f'sketch_{b:04d}', 'category': 'synthetic',
+                        'total_boxes': int(sum(nbf)),
+                        'num_boxes_per_frame': nbf, 'bboxes': bboxes})
+    return targets
+
+
+def synth_head_outputs(B: int, N: int, seed: int = 1):
+    """Random (pred_logits, pred_boxes) for matcher/criterion-only goldens."""
+    r = _rs('head_outputs', seed)
+    logits = r.standard_normal((B, N, 2)).astype(np.float32)
+    cxcy = r.uniform(0.1, 0.9, size=(B, N, 2))
+    wh = r.uniform(0.02, 0.5, size=(B, N, 2))
+    boxes = np.concatenate([cxcy, wh], -1).astype(np.float32)
+    return torch.from_numpy(logits), torch.from_numpy(boxes)

@@ -1,0 +1,54 @@
+"""Shared helpers for the test-suite (loading goldens, unpacking indices)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from svol_amd import synthetic as syn
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+    meta = json.loads(str(z['meta'])) if 'meta' in z.files else {}
+    return z, meta
+
+
+def head_case(name, dtype=torch.float32):
+    """Regenerate (args, state_dict, inputs, targets) of a golden head case."""
+    z, meta = load_golden('head_' + name)
+    args = syn.head_args(**meta['args'])
+    sd = syn.synth_state_dict(args, seed=1)
+    inp = syn.synth_inputs(args, meta['B'], meta['T'], meta['P'], seed=1, pad_frames=meta['pad_frames'])
+    tg = syn.synth_targets(meta['B'], meta['T'], seed=1)
+    if dtype != torch.float32:
+        sd = {k: v.to(dtype) for k, v in sd.items()}
+        inp = {k: v.to(dtype) for k, v in inp.items()}
+    return z, meta, args, sd, inp, tg
+
+
+def unpack_indices(z, prefix):
+    p, t, o = z[prefix + '/pred'], z[prefix + '/tgt'], z[prefix + '/offs']
+    return [(p[o[i]:o[i + 1]], t[o[i]:o[i + 1]]) for i in range(len(o) - 1)]
+
+
+def check_grad(z, key, g, rtol, atol):
+    """Compare a gradient against the golden record (full / stats+sample / None)."""
+    if f'gnone/{key}' in z.files:
+        assert g is None or float(g.abs().max()) == 0.0, f'{key}: expected grad None'
+        return
+    assert g is not None, f'{key}: grad missing'
+    g = g.detach().cpu().double().numpy()
+    if f'g/{key}' in z.files:
+        ref = z[f'g/{key}'].astype(np.float64)
+        np.testing.assert_allclose(g, ref, rtol=rtol, atol=atol, err_msg=key)
+    else:
+        flat = g.reshape(-1)
+        step = max(1, flat.size // 256)
+        ref_s = z[f'gsample/{key}'].astype(np.float64)
+        np.testing.assert_allclose(flat[::step][:256], ref_s, rtol=rtol, atol=atol, err_msg=key + ' (sample)')
+        st = z[f'gstat/{key}']
+        l2 = np.sqrt((flat ** 2).sum())
+        assert abs(l2 - st[2]) <= rtol * st[2] + atol * np.sqrt(flat.size), f'{key}: l2 {l2} vs {st[2]}'
