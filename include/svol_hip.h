@@ -1,0 +1,157 @@
+/*
+ * svol_hip.h — C-ABI of libsvol_hip.so, the MI355X (gfx950) kernel library behind
+ * the SVOL hot path (sketch<->video cross-modal DETR head + Hungarian/GIoU loss).
+ *
+ * The reference (sangminwoo/SVOL) is pure Python and has NO FFI: its boundary
+ * is lib/modeling/{model,svanet,loss,matcher}.py.  This header
+ * is the build's own inner boundary; every entry point cites the reference
+ * arithmetic it replaces (paths relative to the reference root).  The Python
+ * host (svol_amd/) binds it with ctypes.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no torch types; every pointer is DEVICE memory
+ *    owned by the caller (no ownership transfer, no allocation inside);
+ *  - `dtype` selects the activation/compute element type: SVOL_F32 (the
+ *    reference's precision) or SVOL_BF16 (fp32 accumulate, fp32 statistics);
+ *  - matrices are row-major with explicit leading dimensions (elements);
+ *  - every function enqueues on `stream` (a hipStream_t passed as void*) and
+ *    returns immediately: 0 on success, <0 = SVOL_E_* (never throws, never
+ *    syncs).  No hidden global mutable state: callable concurrently from the
+ *    forward thread and the autograd thread.
+ */
+#ifndef SVOL_HIP_H
+#define SVOL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVOL_F32 0
+#define SVOL_BF16 1
+
+#define SVOL_OK 0
+#define SVOL_E_INVALID (-1)     /* null pointer / bad size / misaligned          */
+#define SVOL_E_UNSUPPORTED (-2) /* shape outside what the kernels implement      */
+#define SVOL_E_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after launch  */
+
+/* epilogue / activation selectors */
+#define SVOL_ACT_NONE 0
+#define SVOL_ACT_RELU 1
+#define SVOL_ACT_GELU 2    /* exact erf GELU: cross_modal_transformer.py:189-190 */
+#define SVOL_ACT_SIGMOID 3 /* svanet.py:127 */
+
+int svol_abi_version(void);
+const char* svol_strerror(int code);
+
+/* ---- dtype plumbing ----------------------------------------------------- */
+/* dst[i] = (dtype_dst) src[i];  n elements. */
+int svol_cast(const void* src, int dtype_src, void* dst, int dtype_dst, int64_t n, void* stream);
+/* src fp32 [R,C] -> dst (dtype) [R,C] (may be null) and dstT (dtype) [C,R] (may be null).
+ * Used once per step per weight: nn.Linear weights are [out,in]; dX = dY*W needs W^T K-contiguous. */
+int svol_cast_transpose(const float* src, void* dst, void* dstT, int dtype, int64_t R, int64_t C, void* stream);
+
+/* ---- GEMMs (nn.Linear and its backward) --------------------------------- */
+/* C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]) + residual[M,N]
+ *   A2/n_split: output columns n >= n_split read their A operand from A2 instead of A
+ *               (fused q/k-with-pos vs v-without-pos projection, cross_modal_transformer.py:137-138);
+ *               pass A2=NULL, n_split=0 when unused.  n_split must be a multiple of 128.
+ *   bias fp32 or NULL; residual (dtype, ld = ldr) or NULL; pre_act_out (dtype, ld = ldc) or NULL
+ *   receives the pre-activation (saved for backward).  Replaces nn.Linear/F.relu/F.gelu:
+ *   svanet.py:174-181, cross_modal_transformer.py:163-179, svanet.py:144-156. */
+int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, const void* B, int64_t ldb,
+                 void* C, int64_t ldc, const float* bias, int act, void* pre_act_out, const void* residual,
+                 int64_t ldr, int64_t M, int64_t N, int64_t K, int dtype, void* stream);
+/* dW[N,K] (fp32, ld = ldc) (+)= A[Mc,N]^T * B[Mc,K]   (contraction over the Mc rows; weight gradient).
+ * The output is accumulated with fp32 atomics: the caller zeroes C first unless it wants accumulation. */
+int svol_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t Mc,
+                 int64_t N, int64_t K, int dtype, void* stream);
+/* out[N] (fp32) += sum_m X[m,n]   (bias gradient).  Caller zeroes `out`. */
+int svol_colsum(const void* X, int64_t ldx, float* out, int64_t M, int64_t N, int dtype, void* stream);
+/* dpre[i] = dy[i] * act'(aux[i]); aux = post-activation for RELU/SIGMOID, pre-activation for GELU. */
+int svol_act_bwd(const void* dy, const void* aux, void* dpre, int act, int64_t n, int dtype, void* stream);
+
+/* ---- LayerNorm (+ dropout, + positional add) ---------------------------- */
+/* y = dropout(LN(x) ; p, seed);  ypos = y + pos (optional; pos has `pos_rows` rows and is indexed
+ * row % pos_rows so a [N,d] query embedding broadcasts over the batch).  mean/rstd fp32 [M] saved.
+ * nn.LayerNorm + nn.Dropout of svanet.py:168-178; post-norms cross_modal_transformer.py:127-158. */
+int svol_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, void* ypos, const void* pos,
+                       int64_t pos_rows, float* mean, float* rstd, int64_t M, int64_t D, float dropout_p,
+                       uint64_t seed, int dtype, void* stream);
+/* dx = LN'(dy [+ dy2]) ; dgamma/dbeta (fp32) accumulated with atomics (caller zeroes). */
+int svol_layernorm_bwd(const void* dy, const void* dy2, const void* x, const float* gamma, const float* mean,
+                       const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t M, int64_t D,
+                       float dropout_p, uint64_t seed, int dtype, void* stream);
+
+/* ---- sine positional encoding (position_encoding.py:51-71) -------------- */
+/* mask [B,L] float (1 = valid) -> pos [B,L,D] (dtype). */
+int svol_posenc_sine(const float* mask, void* pos, int64_t B, int64_t L, int64_t D, int dtype, void* stream);
+
+/* ---- multi-head attention core (flash style, never materialises Lq x Lk) -
+ * q/k/v/o are [B*L, ld] row-major, head h occupies columns [h*dh, (h+1)*dh).  softmax(q k^T * scale
+ * + kbias) v; kbias [B,Lk] fp32 additive (0 / -inf = key_padding_mask, cross_modal_transformer.py:154)
+ * or NULL.  lse2 [B,H,Lq] fp32 = log2-domain log-sum-exp saved for backward.  dh <= 32, dh % 8 == 0.
+ * Replaces the core of nn.MultiheadAttention (cross_modal_transformer.py:139,147,154). */
+int svol_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
+                  int64_t ldo, float* lse2, const float* kbias, int64_t B, int64_t H, int64_t Lq, int64_t Lk,
+                  int64_t dh, float scale, int dtype, void* stream);
+/* delta[B,H,Lq] = rowsum(dO * O) ; then dq / dk / dv (same layouts as q/k/v). */
+int svol_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
+                  int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta, const float* kbias,
+                  void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int64_t B, int64_t H,
+                  int64_t Lq, int64_t Lk, int64_t dh, float scale, int dtype, void* stream);
+
+/* ---- sketch->video gate (cross_modal_transformer.py:122-127) ------------
+ * Only the head-averaged attention weights of the 1-query MHA are used by the reference, so the
+ * K projection collapses to one d-vector per (batch, head): u[b,h,:] = scale * W_k,h^T q_{b,h}
+ * (the k-bias term is constant over keys and cancels in the softmax).
+ *   scores[b,h,l] = (x[b,l,:] + pos[b,l,:]) . u[b,h,:]
+ *   a[b,l]        = mean_h softmax_l(scores[b,h,:])
+ *   y             = LN1(x * (1 + a)) ;  ypos = y + pos
+ * ws: fp32 workspace of B*H*(L+2) floats (scores, then per-(b,h) max and sum). */
+int svol_gate_fwd(const void* x, const void* pos, const float* u, const float* gamma, const float* beta, void* y,
+                  void* ypos, float* a, float* mean, float* rstd, float* ws, int64_t B, int64_t L, int64_t D,
+                  int64_t H, int dtype, void* stream);
+/* dy (+ dy2) -> dx, du (fp32, caller zeroes), dgamma/dbeta (fp32 atomics, caller zeroes).
+ * ws: the forward's workspace (scores/max/sum); ws2: B*L + B*H fp32 scratch. */
+int svol_gate_bwd(const void* dy, const void* dy2, const void* x, const void* pos, const float* u,
+                  const float* gamma, const float* a, const float* mean, const float* rstd, const float* ws,
+                  float* ws2, void* dx, float* du, float* dgamma, float* dbeta, int64_t B, int64_t L, int64_t D,
+                  int64_t H, int dtype, void* stream);
+
+/* ---- set matching + criterion (matcher.py:38-159, loss.py:39-157) -------
+ * A "problem" is one LSAP block the reference solves with scipy: one video for
+ * HungarianMatcher (matcher.py:158), one (video, frame) for PerFrameMatcher (matcher.py:92-96),
+ * replicated for every decoder layer (loss.py:148-155).  Problem p covers prediction rows
+ * [pred_off[p], pred_off[p]+pred_cnt[p]) of logits[R,2]/boxes[R,4] (fp32, R = layers*B*N) and target
+ * boxes [tgt_off[p], tgt_off[p]+tgt_cnt[p]) of tgt_boxes[sumM,4] (fp32 cxcywh).
+ *   cost = w_bbox * L1 + w_giou * (-GIoU) + w_class * (-softmax(logits)[0])   (matcher.py:76-85)
+ * written to cost[cost_off[p] + i*tgt_cnt[p] + j]. */
+int svol_match_cost(const float* logits, const float* boxes, const float* tgt_boxes, const int32_t* pred_off,
+                    const int32_t* pred_cnt, const int32_t* tgt_off, const int32_t* tgt_cnt,
+                    const int64_t* cost_off, float* cost, int32_t n_problems, float w_bbox, float w_giou,
+                    float w_class, void* stream);
+/* Batched rectangular LSAP, bit-exact restatement of scipy.optimize.linear_sum_assignment
+ * (Crouse 2016 shortest augmenting path, fp64 duals, tall blocks solved transposed, reverse column
+ * scan, tie rule "lower, or equal and unassigned").  match[r] = matched target index (global row of
+ * tgt_boxes) for prediction row r, or -1.  status[p] = 0 ok, 1 invalid entries (NaN/-inf), 2 infeasible.
+ * max_dim = max over problems of max(pred_cnt, tgt_cnt) (sizes the per-problem LDS). */
+int svol_lsap_batched(const float* cost, const int64_t* cost_off, const int32_t* pred_off, const int32_t* pred_cnt,
+                      const int32_t* tgt_off, const int32_t* tgt_cnt, int32_t* match, int32_t* status,
+                      int32_t n_problems, int32_t max_dim, void* stream);
+/* Per decoder layer (rows_per_layer = B*N prediction rows each):
+ *   losses[layer*4 + {0,1,2,3}] = loss_label (weighted CE, plain mean over B*N; loss.py:54-55),
+ *                                 loss_bbox (L1 mean over matched*4; loss.py:93-94),
+ *                                 loss_giou (mean(1-GIoU) over matched; loss.py:96-102),
+ *                                 class_error (100 - top1 acc on matched; loss.py:59)
+ * and the unit gradients g_label[R,2] = d loss_label/d logits, g_bbox[R,4] = d loss_bbox/d boxes,
+ * g_giou[R,4] = d loss_giou/d boxes (the backward pass scales them by the upstream loss weights). */
+int svol_set_loss(const float* logits, const float* boxes, const float* tgt_boxes, const int32_t* match,
+                  float* losses, float* g_label, float* g_bbox, float* g_giou, int32_t n_layers,
+                  int32_t rows_per_layer, float eos_coef, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVOL_HIP_H */

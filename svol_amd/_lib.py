@@ -1,0 +1,74 @@
+"""ctypes binding of libsvol_hip.so (include/svol_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails the
+product raises.  (The CPU oracle under ``oracle/`` is test infrastructure and is
+never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsvol_hip.so')
+
+_p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_i32 = ctypes.c_int32
+_int = ctypes.c_int
+_f32 = ctypes.c_float
+_u64 = ctypes.c_uint64
+
+# name -> argtypes, exactly the declarations of include/svol_hip.h
+SIGNATURES = {
+    'svol_cast': [_p, _int, _p, _int, _i64, _p],
+    'svol_cast_transpose': [_p, _p, _p, _int, _i64, _i64, _p],
+    'svol_gemm_nt': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _int, _p, _p, _i64, _i64, _i64, _i64, _int, _p],
+    'svol_gemm_tn': [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _int, _p],
+    'svol_colsum': [_p, _i64, _p, _i64, _i64, _int, _p],
+    'svol_act_bwd': [_p, _p, _p, _int, _i64, _int, _p],
+    'svol_layernorm_fwd': [_p, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _f32, _u64, _int, _p],
+    'svol_layernorm_bwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f32, _u64, _int, _p],
+    'svol_posenc_sine': [_p, _p, _i64, _i64, _i64, _int, _p],
+    'svol_attn_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _int, _p],
+    'svol_attn_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64,
+                      _i64, _i64, _i64, _i64, _i64, _f32, _int, _p],
+    'svol_gate_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p],
+    'svol_gate_bwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p],
+    'svol_match_cost': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _f32, _f32, _f32, _p],
+    'svol_lsap_batched': [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p],
+    'svol_set_loss': [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _f32, _p],
+}
+
+_LIB = None
+
+
+class SvolHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raise loudly when absent."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise SvolHipError(
+                f'{LIB_PATH} not found: the SVOL hot path has no CPU fallback. '
+                'Build it with `python -m svol_amd.build` (hipcc, gfx950).')
+        L = ctypes.CDLL(LIB_PATH)
+        L.svol_abi_version.restype = _int
+        L.svol_abi_version.argtypes = []
+        L.svol_strerror.restype = ctypes.c_char_p
+        L.svol_strerror.argtypes = [_int]
+        for name, at in SIGNATURES.items():
+            f = getattr(L, name)  # AttributeError if the symbol is not exported
+            f.restype = _int
+            f.argtypes = at
+        _LIB = L
+    return _LIB
+
+
+def check(rc: int, name: str):
+    if rc != 0:
+        msg = lib().svol_strerror(rc).decode()
+        raise SvolHipError(f'{name} failed: {msg} (code {rc})')

@@ -1,0 +1,67 @@
+"""Build libsvol_hip.so (the C-ABI kernel library, include/svol_hip.h) in-tree with hipcc for gfx950.
+
+    python -m svol_amd.build            # incremental
+    python -m svol_amd.build --force
+
+No CPU fallback exists: if this library is missing the product raises at first use.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OUT = os.path.join(HERE, 'libsvol_hip.so')
+SOURCES = ['gemm.hip', 'norm.hip', 'attention.hip', 'gate.hip', 'criterion.hip']
+ARCH = 'gfx950'
+COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+PER_FILE = {'criterion.hip': ['-ffp-contract=off']}  # bit-exact cost / LSAP arithmetic
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return 'hipcc'
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hdrs = [os.path.join(CSRC, 'common.h'), os.path.join(os.path.dirname(HERE), 'include', 'svol_hip.h')]
+    objdir = os.path.join(CSRC, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = _hipcc()
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src.replace('.hip', '.o'))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            jobs.append([hipcc] + COMMON + PER_FILE.get(src, []) + ['-c', s, '-o', o])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    if force or jobs or _stale(OUT, objs):
+        run([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', OUT] + objs)
+    return OUT
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print(OUT)

@@ -1,0 +1,76 @@
+// Shared device/host helpers for libsvol_hip (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/svol_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define SVOL_CHECK_LAUNCH()                                   \
+    do {                                                      \
+        if (hipGetLastError() != hipSuccess) return SVOL_E_LAUNCH; \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- scalar conversions ---------------------------------------------------
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+// ---- 4-element vector access (8 B for bf16, 16 B for f32) ------------------
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    f32x4 v;
+    __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const f32x4*>(p); }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<f32x4*>(p) = v; }
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <> struct Vec4<bf16_t> {
+    bf16x4 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x4*>(p); }
+    __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<bf16x4*>(p) = v; }
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16_t)x; }
+};
+
+// ---- wave-level reductions (64 lanes) --------------------------------------
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
+    return x;
+}
+
+// ---- counter-based RNG for dropout (stateless: same mask in fwd and bwd) ----
+__device__ __forceinline__ uint32_t hash_u64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return (uint32_t)x;
+}
+// keep-mask scale for element idx: 0 (dropped) or 1/(1-p)
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
+    uint32_t r = hash_u64(seed * 0x9E3779B97F4A7C15ULL + idx);
+    float u = (float)(r >> 8) * (1.0f / 16777216.0f);
+    return u < p ? 0.0f : inv_keep;
+}
+
+// exact (erf) GELU and derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}

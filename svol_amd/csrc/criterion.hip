@@ -1,0 +1,340 @@
+// Set matching + criterion on device (reference lib/modeling/matcher.py, lib/modeling/loss.py,
+// lib/utils/box_utils.py and scipy.optimize.linear_sum_assignment).
+//
+// The reference builds the FULL [B*N, sumM] cost matrix, copies it to the host (.cpu() sync,
+// matcher.py:86/156), and calls scipy once per block in a Python loop, once per decoder layer.
+// Here only the diagonal blocks the reference actually uses are computed, and every block of every
+// layer is solved in one launch (one wavefront per block) with no host round trip.
+//
+// Compiled with -ffp-contract=off: the cost arithmetic mirrors torch's separate fp32 ops (no FMA
+// fusion) and the solver mirrors scipy's fp64 arithmetic, so assignments are bit-exact.
+#include "common.h"
+
+namespace {
+
+struct Box { float x0, y0, x1, y1; };
+__device__ __forceinline__ Box to_xyxy(const float* b) {  // box_utils.py:9-13
+    return Box{b[0] - 0.5f * b[2], b[1] - 0.5f * b[3], b[0] + 0.5f * b[2], b[1] + 0.5f * b[3]};
+}
+__device__ __forceinline__ float giou_pair(const Box& a, const Box& b) {  // box_utils.py:24-61
+    const float area1 = (a.x1 - a.x0) * (a.y1 - a.y0);
+    const float area2 = (b.x1 - b.x0) * (b.y1 - b.y0);
+    const float iw = fmaxf(fminf(a.x1, b.x1) - fmaxf(a.x0, b.x0), 0.f);
+    const float ih = fmaxf(fminf(a.y1, b.y1) - fmaxf(a.y0, b.y0), 0.f);
+    const float inter = iw * ih;
+    const float uni = area1 + area2 - inter;
+    const float iou = inter / uni;
+    const float ew = fmaxf(fmaxf(a.x1, b.x1) - fminf(a.x0, b.x0), 0.f);
+    const float eh = fmaxf(fmaxf(a.y1, b.y1) - fminf(a.y0, b.y0), 0.f);
+    const float area = ew * eh;
+    return iou - (area - uni) / area;
+}
+
+__global__ __launch_bounds__(256) void match_cost_kernel(const float* __restrict__ logits, const float* __restrict__ boxes,
+                                                         const float* __restrict__ tgt, const int32_t* __restrict__ pred_off,
+                                                         const int32_t* __restrict__ pred_cnt,
+                                                         const int32_t* __restrict__ tgt_off,
+                                                         const int32_t* __restrict__ tgt_cnt,
+                                                         const int64_t* __restrict__ cost_off, float* __restrict__ cost,
+                                                         float w_bbox, float w_giou, float w_class) {
+    const int p = blockIdx.x;
+    const int np = pred_cnt[p], nt = tgt_cnt[p];
+    const int po = pred_off[p], to = tgt_off[p];
+    float* C = cost + cost_off[p];
+    for (int e = threadIdx.x; e < np * nt; e += blockDim.x) {
+        const int i = e / nt, j = e - i * nt;
+        const float* lg = logits + (int64_t)(po + i) * 2;
+        const float* pb = boxes + (int64_t)(po + i) * 4;
+        const float* tb = tgt + (int64_t)(to + j) * 4;
+        // softmax(-1)[0]  (matcher.py:59)
+        const float mx = fmaxf(lg[0], lg[1]);
+        const float e0 = expf(lg[0] - mx), e1 = expf(lg[1] - mx);
+        const float p0 = e0 / (e0 + e1);
+        // torch.cdist(p=1) (matcher.py:79)
+        const float l1 = ((fabsf(pb[0] - tb[0]) + fabsf(pb[1] - tb[1])) + fabsf(pb[2] - tb[2])) + fabsf(pb[3] - tb[3]);
+        const float g = giou_pair(to_xyxy(pb), to_xyxy(tb));
+        C[e] = (w_bbox * l1 + w_giou * (-g)) + w_class * (-p0);  // matcher.py:85
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Batched LSAP: one wave64 per problem.  Restates scipy's rectangular_lsap (Crouse 2016).
+__device__ __forceinline__ double wave_min_d(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmin(x, __shfl_xor(x, o, 64));
+    return x;
+}
+__device__ __forceinline__ int wave_min_i(int x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = min(x, __shfl_xor(x, o, 64));
+    return x;
+}
+__device__ __forceinline__ int wave_max_i(int x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = max(x, __shfl_xor(x, o, 64));
+    return x;
+}
+
+__global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost, const int64_t* __restrict__ cost_off,
+                                                  const int32_t* __restrict__ pred_off, const int32_t* __restrict__ pred_cnt,
+                                                  const int32_t* __restrict__ tgt_off, const int32_t* __restrict__ tgt_cnt,
+                                                  int32_t* __restrict__ match, int32_t* __restrict__ status, int max_dim) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    double* u = reinterpret_cast<double*>(lds);
+    double* v = u + max_dim;
+    double* spc = v + max_dim;
+    int* path = reinterpret_cast<int*>(spc + max_dim);
+    int* col4row = path + max_dim;
+    int* row4col = col4row + max_dim;
+    int* remaining = row4col + max_dim;
+    unsigned char* SR = reinterpret_cast<unsigned char*>(remaining + max_dim);
+    unsigned char* SC = SR + max_dim;
+
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int np = pred_cnt[p], nt = tgt_cnt[p];
+    const int po = pred_off[p], to = tgt_off[p];
+    const float* C = cost + cost_off[p];
+    for (int i = lane; i < np; i += 64) match[po + i] = -1;
+    if (lane == 0) status[p] = 0;
+    if (np == 0 || nt == 0) return;
+    const bool tr = nt < np;  // tall matrix -> solve the transpose (scipy)
+    const int nr = tr ? nt : np, nc = tr ? np : nt;
+    auto cst = [&](int i, int j) -> double { return (double)(tr ? C[(int64_t)j * nt + i] : C[(int64_t)i * nt + j]); };
+
+    // NaN / -inf -> "matrix contains invalid numeric entries"
+    int bad = 0;
+    for (int e = lane; e < np * nt; e += 64) {
+        const float c = C[e];
+        if (c != c || c == -INFINITY) bad = 1;
+    }
+    if (__any(bad)) {
+        if (lane == 0) status[p] = 1;
+        return;
+    }
+    for (int i = lane; i < nr; i += 64) { u[i] = 0.0; col4row[i] = -1; }
+    for (int j = lane; j < nc; j += 64) { v[j] = 0.0; path[j] = -1; row4col[j] = -1; }
+    __syncthreads();
+
+    for (int cur = 0; cur < nr; ++cur) {
+        for (int it = lane; it < nc; it += 64) { remaining[it] = nc - it - 1; SC[it] = 0; spc[it] = INFINITY; }
+        for (int i = lane; i < nr; i += 64) SR[i] = 0;
+        __syncthreads();
+        int num_remaining = nc;
+        double min_val = 0.0;
+        int i = cur, sink = -1;
+        while (sink == -1) {
+            if (lane == 0) SR[i] = 1;
+            const double ui = u[i];
+            double lmin = INFINITY;
+            int first_it = 0x7fffffff, last_una = -1;
+            for (int it = lane; it < num_remaining; it += 64) {
+                const int j = remaining[it];
+                const double r = min_val + cst(i, j) - ui - v[j];
+                double s = spc[j];
+                if (r < s) { path[j] = i; spc[j] = r; s = r; }
+                const bool una = row4col[j] == -1;
+                if (s < lmin) { lmin = s; first_it = it; last_una = una ? it : -1; }
+                else if (s == lmin) {
+                    if (first_it == 0x7fffffff) first_it = it;  // s == lmin == +inf on the first visit
+                    if (una) last_una = it;
+                }
+            }
+            const double gmin = wave_min_d(lmin);
+            const int best_una = wave_max_i(lmin == gmin ? last_una : -1);
+            const int best_first = wave_min_i(lmin == gmin ? first_it : 0x7fffffff);
+            const int index = best_una >= 0 ? best_una : best_first;
+            min_val = gmin;
+            if (min_val == INFINITY) {  // infeasible
+                if (lane == 0) status[p] = 2;
+                return;
+            }
+            __syncthreads();
+            const int j = remaining[index];
+            const int r4c = row4col[j];
+            if (r4c == -1) sink = j; else i = r4c;
+            __syncthreads();
+            if (lane == 0) { SC[j] = 1; remaining[index] = remaining[num_remaining - 1]; }
+            --num_remaining;
+            __syncthreads();
+        }
+        // dual update
+        if (lane == 0) u[cur] += min_val;
+        for (int ii = lane; ii < nr; ii += 64)
+            if (SR[ii] && ii != cur) u[ii] += min_val - spc[col4row[ii]];
+        for (int j = lane; j < nc; j += 64)
+            if (SC[j]) v[j] -= min_val - spc[j];
+        __syncthreads();
+        // augment
+        if (lane == 0) {
+            int j = sink;
+            for (;;) {
+                const int ii = path[j];
+                row4col[j] = ii;
+                const int t = col4row[ii];
+                col4row[ii] = j;
+                j = t;
+                if (ii == cur) break;
+            }
+        }
+        __syncthreads();
+    }
+    if (tr) {
+        for (int ii = lane; ii < nr; ii += 64) match[po + col4row[ii]] = to + ii;
+    } else {
+        for (int ii = lane; ii < nr; ii += 64) match[po + ii] = to + col4row[ii];
+    }
+}
+
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_d(double x, double* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    __syncthreads();
+    if (lane == 0) red[wave] = x;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// d(giou)/d(pred cxcywh), pred = b[0..3], target t[0..3]
+__device__ void giou_grad(const float* b, const float* t, float& giou, float (&gb)[4]) {
+    const float x0 = b[0] - 0.5f * b[2], y0 = b[1] - 0.5f * b[3], x1 = b[0] + 0.5f * b[2], y1 = b[1] + 0.5f * b[3];
+    const float tx0 = t[0] - 0.5f * t[2], ty0 = t[1] - 0.5f * t[3], tx1 = t[0] + 0.5f * t[2], ty1 = t[1] + 0.5f * t[3];
+    const float area1 = (x1 - x0) * (y1 - y0), area2 = (tx1 - tx0) * (ty1 - ty0);
+    const float dix = fminf(x1, tx1) - fmaxf(x0, tx0), diy = fminf(y1, ty1) - fmaxf(y0, ty0);
+    const float iw = fmaxf(dix, 0.f), ih = fmaxf(diy, 0.f);
+    const float inter = iw * ih;
+    const float uni = area1 + area2 - inter;
+    const float iou = inter / uni;
+    const float dex = fmaxf(x1, tx1) - fminf(x0, tx0), dey = fmaxf(y1, ty1) - fminf(y0, ty0);
+    const float ew = fmaxf(dex, 0.f), eh = fmaxf(dey, 0.f);
+    const float area = ew * eh;
+    giou = iou - (area - uni) / area;
+    // reverse mode, upstream d/dgiou = 1
+    const float G_union = -inter / (uni * uni) + 1.f / area;
+    const float G_inter = 1.f / uni - G_union;
+    const float G_area = -uni / (area * area);
+    const float G_area1 = G_union;
+    auto gsel = [](float a, float c, bool want_greater) -> float {  // share of the gradient going to `a`
+        if (a == c) return 0.5f;
+        return ((a > c) == want_greater) ? 1.f : 0.f;
+    };
+    const float G_iw = dix >= 0.f ? G_inter * ih : 0.f, G_ih = diy >= 0.f ? G_inter * iw : 0.f;
+    const float G_ew = dex >= 0.f ? G_area * eh : 0.f, G_eh = dey >= 0.f ? G_area * ew : 0.f;
+    float gx0 = -G_iw * gsel(x0, tx0, true) - G_ew * gsel(x0, tx0, false) - G_area1 * (y1 - y0);
+    float gx1 = G_iw * gsel(x1, tx1, false) + G_ew * gsel(x1, tx1, true) + G_area1 * (y1 - y0);
+    float gy0 = -G_ih * gsel(y0, ty0, true) - G_eh * gsel(y0, ty0, false) - G_area1 * (x1 - x0);
+    float gy1 = G_ih * gsel(y1, ty1, false) + G_eh * gsel(y1, ty1, true) + G_area1 * (x1 - x0);
+    gb[0] = gx0 + gx1;
+    gb[1] = gy0 + gy1;
+    gb[2] = 0.5f * (gx1 - gx0);
+    gb[3] = 0.5f * (gy1 - gy0);
+}
+
+__global__ __launch_bounds__(256) void set_loss_kernel(const float* __restrict__ logits, const float* __restrict__ boxes,
+                                                       const float* __restrict__ tgt, const int32_t* __restrict__ match,
+                                                       float* __restrict__ losses, float* __restrict__ g_label,
+                                                       float* __restrict__ g_bbox, float* __restrict__ g_giou, int rows,
+                                                       float eos) {
+    __shared__ double red[4];
+    const int layer = blockIdx.x;
+    const int64_t base = (int64_t)layer * rows;
+    double cnt = 0.0;
+    for (int r = threadIdx.x; r < rows; r += 256) cnt += match[base + r] >= 0 ? 1.0 : 0.0;
+    const double K = block_sum_d(cnt, red);
+    const float invK = K > 0 ? (float)(1.0 / K) : 0.f;
+    const float invR = 1.f / (float)rows;
+    double s_nll = 0.0, s_l1 = 0.0, s_g = 0.0, s_ok = 0.0;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        const int64_t row = base + r;
+        const int m = match[row];
+        const float l0 = logits[row * 2], l1 = logits[row * 2 + 1];
+        const float mx = fmaxf(l0, l1);
+        const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+        const float lse = mx + logf(e0 + e1);
+        const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+        const int cls = m >= 0 ? 0 : 1;  // foreground = 0, background = 1 (loss.py:32-33)
+        const float w = cls == 0 ? 1.f : eos;
+        s_nll += (double)(-w * ((cls == 0 ? l0 : l1) - lse));
+        g_label[row * 2] = w * (p0 - (cls == 0 ? 1.f : 0.f)) * invR;
+        g_label[row * 2 + 1] = w * (p1 - (cls == 1 ? 1.f : 0.f)) * invR;
+        float gb[4] = {0.f, 0.f, 0.f, 0.f}, gg[4] = {0.f, 0.f, 0.f, 0.f};
+        if (m >= 0) {
+            const float* b = boxes + row * 4;
+            const float* t = tgt + (int64_t)m * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float d = b[c] - t[c];
+                s_l1 += (double)fabsf(d);
+                gb[c] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * invK * 0.25f;
+            }
+            float gi, dgi[4];
+            giou_grad(b, t, gi, dgi);
+            s_g += (double)(1.f - gi);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gg[c] = -dgi[c] * invK;
+            s_ok += (l0 >= l1) ? 1.0 : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { g_bbox[row * 4 + c] = gb[c]; g_giou[row * 4 + c] = gg[c]; }
+    }
+    const double t_nll = block_sum_d(s_nll, red);
+    const double t_l1 = block_sum_d(s_l1, red);
+    const double t_g = block_sum_d(s_g, red);
+    const double t_ok = block_sum_d(s_ok, red);
+    if (threadIdx.x == 0) {
+        losses[layer * 4 + 0] = (float)(t_nll / (double)rows);
+        losses[layer * 4 + 1] = K > 0 ? (float)(t_l1 / (4.0 * K)) : 0.f;
+        losses[layer * 4 + 2] = K > 0 ? (float)(t_g / K) : 0.f;
+        losses[layer * 4 + 3] = K > 0 ? (float)(100.0 - t_ok * (100.0 / K)) : 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int svol_match_cost(const float* logits, const float* boxes, const float* tgt_boxes, const int32_t* pred_off,
+                    const int32_t* pred_cnt, const int32_t* tgt_off, const int32_t* tgt_cnt, const int64_t* cost_off,
+                    float* cost, int32_t n_problems, float w_bbox, float w_giou, float w_class, void* stream) {
+    if (!logits || !boxes || !tgt_boxes || !pred_off || !pred_cnt || !tgt_off || !tgt_cnt || !cost_off || !cost)
+        return SVOL_E_INVALID;
+    if (n_problems < 0) return SVOL_E_INVALID;
+    if (n_problems == 0) return SVOL_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(match_cost_kernel, dim3((unsigned)n_problems), dim3(256), 0, s, logits, boxes, tgt_boxes, pred_off,
+                       pred_cnt, tgt_off, tgt_cnt, cost_off, cost, w_bbox, w_giou, w_class);
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_lsap_batched(const float* cost, const int64_t* cost_off, const int32_t* pred_off, const int32_t* pred_cnt,
+                      const int32_t* tgt_off, const int32_t* tgt_cnt, int32_t* match, int32_t* status, int32_t n_problems,
+                      int32_t max_dim, void* stream) {
+    if (!cost || !cost_off || !pred_off || !pred_cnt || !tgt_off || !tgt_cnt || !match || !status) return SVOL_E_INVALID;
+    if (n_problems < 0 || max_dim < 0) return SVOL_E_INVALID;
+    if (n_problems == 0) return SVOL_OK;
+    if (max_dim > 2048) return SVOL_E_UNSUPPORTED;
+    int md = ((max_dim + 15) / 16) * 16;
+    if (md < 16) md = 16;
+    const size_t lds = (size_t)md * (3 * 8 + 4 * 4 + 2);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(lsap_kernel, dim3((unsigned)n_problems), dim3(64), lds, s, cost, cost_off, pred_off, pred_cnt, tgt_off,
+                       tgt_cnt, match, status, md);
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_set_loss(const float* logits, const float* boxes, const float* tgt_boxes, const int32_t* match, float* losses,
+                  float* g_label, float* g_bbox, float* g_giou, int32_t n_layers, int32_t rows_per_layer, float eos_coef,
+                  void* stream) {
+    if (!logits || !boxes || !tgt_boxes || !match || !losses || !g_label || !g_bbox || !g_giou) return SVOL_E_INVALID;
+    if (n_layers <= 0 || rows_per_layer <= 0) return SVOL_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(set_loss_kernel, dim3((unsigned)n_layers), dim3(256), 0, s, logits, boxes, tgt_boxes, match, losses,
+                       g_label, g_bbox, g_giou, (int)rows_per_layer, eos_coef);
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+}  // extern "C"

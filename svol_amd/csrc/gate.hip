@@ -1,0 +1,396 @@
+// Sketch -> video attention gate (reference cross_modal_transformer.py:122-127), HBM-bound row kernels.
+//
+// The reference runs a full nn.MultiheadAttention with ONE query (the sketch token) over the L video
+// tokens and keeps only the head-averaged attention weights att1[b,l]; mem = LN1(x + att1 * x).
+// With a single query the key projection collapses: score[b,h,l] = (x+pos)[b,l,:] . u[b,h,:] with
+// u[b,h,:] = d_h^-1/2 * W_k,h^T q[b,h,:] (the k-bias adds a per-(b,h) constant that cancels in the
+// softmax), so the [L,d]x[d,d] K projection, the V projection, P.V and out_proj of the reference are
+// never computed.  Forward = 3 passes over x (scores, per-(b,h) max/sum, apply+LN1); backward = 3.
+#include "common.h"
+
+namespace {
+
+constexpr int GP = 4;  // max passes: D <= 1024
+constexpr int GH = 8;  // max heads
+
+// scores[b,hh,l] = (x+pos)[b,l,:] . u[b,hh,:]      grid = (ceil(L / (4*rpw)), B), one wave per row
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void gate_scores_kernel(const T* __restrict__ x, const T* __restrict__ pos,
+                                                          const float* __restrict__ u, float* __restrict__ scores, int L,
+                                                          int D, int H, int rpw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int l0 = (blockIdx.x * 4 + wave) * rpw;
+    float ur[GH][NP][4];
+#pragma unroll
+    for (int hh = 0; hh < GH; ++hh)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int c = (lane + 64 * j) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ur[hh][j][e] = (hh < H && c < D) ? u[((int64_t)b * H + hh) * D + c + e] : 0.f;
+        }
+    for (int l = l0; l < l0 + rpw && l < L; ++l) {
+        const int64_t row = (int64_t)b * L + l;
+        float part[GH];
+#pragma unroll
+        for (int hh = 0; hh < GH; ++hh) part[hh] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            if (c < D) {
+                Vec4<T> xv, pv;
+                xv.load(x + row * D + c);
+                pv.load(pos + row * D + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = xv.get(e) + pv.get(e);
+#pragma unroll
+                    for (int hh = 0; hh < GH; ++hh) part[hh] += t * ur[hh][j][e];
+                }
+            }
+        }
+#pragma unroll
+        for (int hh = 0; hh < GH; ++hh) {
+            const float s = wave_sum(part[hh]);
+            if (lane == 0 && hh < H) scores[((int64_t)b * H + hh) * L + l] = s;
+        }
+    }
+}
+
+// per (b,hh): mx = max_l score, sm = sum_l exp(score - mx);  optionally also
+// c = sum_l p[l] * da[b,l] / H (backward).   grid = B*H blocks of 256
+__global__ __launch_bounds__(256) void gate_stats_kernel(const float* __restrict__ scores, float* __restrict__ mx_out,
+                                                         float* __restrict__ sm_out, int L) {
+    __shared__ float red[4];
+    const int bh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* s = scores + (int64_t)bh * L;
+    float m = -INFINITY;
+    for (int l = tid; l < L; l += 256) m = fmaxf(m, s[l]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float acc = 0.f;
+    for (int l = tid; l < L; l += 256) acc += __expf(s[l] - m);
+    acc = wave_sum(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        mx_out[bh] = m;
+        sm_out[bh] = red[0] + red[1] + red[2] + red[3];
+    }
+}
+
+__global__ __launch_bounds__(256) void gate_bwd_stats_kernel(const float* __restrict__ scores,
+                                                             const float* __restrict__ mx, const float* __restrict__ sm,
+                                                             const float* __restrict__ da, float* __restrict__ c_out,
+                                                             int L, int H) {
+    __shared__ float red[4];
+    const int bh = blockIdx.x, b = bh / H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* s = scores + (int64_t)bh * L;
+    const float m = mx[bh], inv = 1.f / sm[bh];
+    float acc = 0.f;
+    for (int l = tid; l < L; l += 256) acc += __expf(s[l] - m) * inv * da[(int64_t)b * L + l];
+    acc = wave_sum(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) c_out[bh] = (red[0] + red[1] + red[2] + red[3]) / (float)H;
+}
+
+// a[b,l] = mean_h softmax ; s1 = x*(1+a) ; y = LN(s1) ; ypos = y + pos        one wave per row
+template <typename T>
+__global__ __launch_bounds__(256) void gate_apply_kernel(const T* __restrict__ x, const T* __restrict__ pos,
+                                                         const float* __restrict__ scores, const float* __restrict__ mx,
+                                                         const float* __restrict__ sm, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, T* __restrict__ y,
+                                                         T* __restrict__ ypos, float* __restrict__ a_out,
+                                                         float* __restrict__ mean, float* __restrict__ rstd, int L, int D,
+                                                         int H, int64_t M) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int b = (int)(row / L), l = (int)(row % L);
+    float a = 0.f;
+    for (int hh = 0; hh < H; ++hh) {
+        const int bh = b * H + hh;
+        a += __expf(scores[(int64_t)bh * L + l] - mx[bh]) / sm[bh];
+    }
+    a /= (float)H;
+    float v[GP][4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < GP; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < D) {
+            Vec4<T> t;
+            t.load(x + row * D + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[j][e] = t.get(e) * (1.f + a); s += v[j][e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][e] = 0.f;
+        }
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < GP; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; a_out[row] = a; }
+#pragma unroll
+    for (int j = 0; j < GP; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < D) {
+            Vec4<T> o, op, pv;
+            pv.load(pos + row * D + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float r = (v[j][e] - mu) * rs * gamma[c + e] + beta[c + e];
+                o.set(e, r);
+                op.set(e, r + pv.get(e));
+            }
+            o.store(y + row * D + c);
+            if (ypos) op.store(ypos + row * D + c);
+        }
+    }
+}
+
+// backward pass 1: LN1 backward, dx_part = ds1*(1+a), da[row] = sum_d ds1*x ; dgamma/dbeta atomics
+template <typename T>
+__global__ __launch_bounds__(256) void gate_bwd_ln_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
+                                                          const T* __restrict__ x, const float* __restrict__ a_in,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, T* __restrict__ dx,
+                                                          float* __restrict__ da, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, int64_t M, int D, int rpw) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw;
+    float dg[GP][4], db[GP][4];
+#pragma unroll
+    for (int j = 0; j < GP; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dg[j][e] = 0.f; db[j][e] = 0.f; }
+    for (int64_t row = r0; row < r0 + rpw && row < M; ++row) {
+        const float mu = mean[row], rs = rstd[row], a = a_in[row];
+        float g[GP][4], xh[GP][4], xs[GP][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < GP; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            if (c < D) {
+                Vec4<T> p, p2, xv;
+                p.load(dy + row * D + c);
+                if (dy2) p2.load(dy2 + row * D + c);
+                xv.load(x + row * D + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = p.get(e) + (dy2 ? p2.get(e) : 0.f);
+                    xs[j][e] = xv.get(e);
+                    const float hv = (xs[j][e] * (1.f + a) - mu) * rs;
+                    xh[j][e] = hv;
+                    dg[j][e] += d * hv;
+                    db[j][e] += d;
+                    const float gg = d * gamma[c + e];
+                    g[j][e] = gg;
+                    s1 += gg;
+                    s2 += gg * hv;
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+        float dacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < GP; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            if (c < D) {
+                Vec4<T> o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ds = rs * (g[j][e] - s1 - xh[j][e] * s2);
+                    dacc += ds * xs[j][e];
+                    o.set(e, ds * (1.f + a));
+                }
+                o.store(dx + row * D + c);
+            }
+        }
+        dacc = wave_sum(dacc);
+        if (lane == 0) da[row] = dacc;
+    }
+#pragma unroll
+    for (int j = 0; j < GP; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(dgamma + c + e, dg[j][e]);
+                atomicAdd(dbeta + c + e, db[j][e]);
+            }
+        }
+    }
+}
+
+// backward pass 3: dscore[hh] = p_hh[l] * (da[l]/H - c[b,hh]) ; dx += sum_hh dscore*u ; du += dscore*(x+pos)
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ pos,
+                                                             const float* __restrict__ u, const float* __restrict__ scores,
+                                                             const float* __restrict__ mx, const float* __restrict__ sm,
+                                                             const float* __restrict__ da, const float* __restrict__ cc,
+                                                             T* __restrict__ dx, float* __restrict__ du, int L, int D,
+                                                             int H, int rpw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int l0 = (blockIdx.x * 4 + wave) * rpw;
+    float ur[GH][NP][4], dur[GH][NP][4];
+#pragma unroll
+    for (int hh = 0; hh < GH; ++hh)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int c = (lane + 64 * j) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ur[hh][j][e] = (hh < H && c < D) ? u[((int64_t)b * H + hh) * D + c + e] : 0.f;
+                dur[hh][j][e] = 0.f;
+            }
+        }
+    for (int l = l0; l < l0 + rpw && l < L; ++l) {
+        const int64_t row = (int64_t)b * L + l;
+        float ds[GH];
+        const float dal = da[row] / (float)H;
+#pragma unroll
+        for (int hh = 0; hh < GH; ++hh) {
+            if (hh < H) {
+                const int bh = b * H + hh;
+                const float pp = __expf(scores[(int64_t)bh * L + l] - mx[bh]) / sm[bh];
+                ds[hh] = pp * (dal - cc[bh]);
+            } else ds[hh] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            if (c < D) {
+                Vec4<T> xv, pv, dv;
+                xv.load(x + row * D + c);
+                pv.load(pos + row * D + c);
+                dv.load(dx + row * D + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = xv.get(e) + pv.get(e);
+                    float add = 0.f;
+#pragma unroll
+                    for (int hh = 0; hh < GH; ++hh) {
+                        add += ds[hh] * ur[hh][j][e];
+                        dur[hh][j][e] += ds[hh] * t;
+                    }
+                    dv.set(e, dv.get(e) + add);
+                }
+                dv.store(dx + row * D + c);
+            }
+        }
+    }
+#pragma unroll
+    for (int hh = 0; hh < GH; ++hh)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            if (hh < H && c < D) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(du + ((int64_t)b * H + hh) * D + c + e, dur[hh][j][e]);
+            }
+        }
+}
+
+int rows_per_wave(int64_t rows, int64_t target_waves) {
+    int64_t r = (rows + target_waves - 1) / target_waves;
+    return (int)(r < 1 ? 1 : r);
+}
+
+}  // namespace
+
+extern "C" {
+
+int svol_gate_fwd(const void* x, const void* pos, const float* u, const float* gamma, const float* beta, void* y,
+                  void* ypos, float* a, float* mean, float* rstd, float* ws, int64_t B, int64_t L, int64_t D, int64_t H,
+                  int dtype, void* stream) {
+    if (!x || !pos || !u || !gamma || !beta || !y || !a || !mean || !rstd || !ws) return SVOL_E_INVALID;
+    if (B <= 0 || L <= 0 || D <= 0 || H <= 0) return SVOL_E_INVALID;
+    if (D % 4 || D > GP * 256 || H > GH || B > 65535 || L > (1 << 24)) return SVOL_E_UNSUPPORTED;
+    if (dtype != SVOL_BF16 && dtype != SVOL_F32) return SVOL_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int np_ = D <= 256 ? 1 : (D <= 512 ? 2 : 4);
+    float* scores = ws;
+    float* mx = ws + B * H * L;
+    float* sm = mx + B * H;
+    const int rpw = rows_per_wave(L, 2048 / (B > 2048 ? 2048 : B) + 1);
+    dim3 g1((unsigned)((L + 4 * rpw - 1) / (4 * rpw)), (unsigned)B);
+    const int64_t M = B * L;
+    const unsigned g3 = (unsigned)((M + 3) / 4);
+    if (dtype == SVOL_BF16) {
+        if (np_ == 1) hipLaunchKernelGGL((gate_scores_kernel<bf16_t, 1>), g1, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)pos, u, scores, (int)L, (int)D, (int)H, rpw);
+        else if (np_ == 2) hipLaunchKernelGGL((gate_scores_kernel<bf16_t, 2>), g1, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)pos, u, scores, (int)L, (int)D, (int)H, rpw);
+        else hipLaunchKernelGGL((gate_scores_kernel<bf16_t, 4>), g1, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)pos, u, scores, (int)L, (int)D, (int)H, rpw);
+        hipLaunchKernelGGL(gate_stats_kernel, dim3((unsigned)(B * H)), dim3(256), 0, s, scores, mx, sm, (int)L);
+        hipLaunchKernelGGL(gate_apply_kernel<bf16_t>, dim3(g3), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)pos, scores,
+                           mx, sm, gamma, beta, (bf16_t*)y, (bf16_t*)ypos, a, mean, rstd, (int)L, (int)D, (int)H, M);
+    } else {
+        if (np_ == 1) hipLaunchKernelGGL((gate_scores_kernel<float, 1>), g1, dim3(256), 0, s, (const float*)x, (const float*)pos, u, scores, (int)L, (int)D, (int)H, rpw);
+        else if (np_ == 2) hipLaunchKernelGGL((gate_scores_kernel<float, 2>), g1, dim3(256), 0, s, (const float*)x, (const float*)pos, u, scores, (int)L, (int)D, (int)H, rpw);
+        else hipLaunchKernelGGL((gate_scores_kernel<float, 4>), g1, dim3(256), 0, s, (const float*)x, (const float*)pos, u, scores, (int)L, (int)D, (int)H, rpw);
+        hipLaunchKernelGGL(gate_stats_kernel, dim3((unsigned)(B * H)), dim3(256), 0, s, scores, mx, sm, (int)L);
+        hipLaunchKernelGGL(gate_apply_kernel<float>, dim3(g3), dim3(256), 0, s, (const float*)x, (const float*)pos, scores,
+                           mx, sm, gamma, beta, (float*)y, (float*)ypos, a, mean, rstd, (int)L, (int)D, (int)H, M);
+    }
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_gate_bwd(const void* dy, const void* dy2, const void* x, const void* pos, const float* u, const float* gamma,
+                  const float* a, const float* mean, const float* rstd, const float* ws, float* ws2, void* dx, float* du,
+                  float* dgamma, float* dbeta, int64_t B, int64_t L, int64_t D, int64_t H, int dtype, void* stream) {
+    if (!dy || !x || !pos || !u || !gamma || !a || !mean || !rstd || !ws || !ws2 || !dx || !du || !dgamma || !dbeta)
+        return SVOL_E_INVALID;
+    if (B <= 0 || L <= 0 || D <= 0 || H <= 0) return SVOL_E_INVALID;
+    if (D % 4 || D > GP * 256 || H > GH || B > 65535 || L > (1 << 24)) return SVOL_E_UNSUPPORTED;
+    if (dtype != SVOL_BF16 && dtype != SVOL_F32) return SVOL_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int np_ = D <= 256 ? 1 : (D <= 512 ? 2 : 4);
+    const float* scores = ws;
+    const float* mx = ws + B * H * L;
+    const float* sm = mx + B * H;
+    float* da = ws2;
+    float* cc = ws2 + B * L;
+    const int64_t M = B * L;
+    const int rpw1 = rows_per_wave(M, 4096);
+    const unsigned g1 = (unsigned)(((M + rpw1 - 1) / rpw1 + 3) / 4);
+    const int rpw3 = rows_per_wave(L, 2048 / (B > 2048 ? 2048 : B) + 1);
+    dim3 g3((unsigned)((L + 4 * rpw3 - 1) / (4 * rpw3)), (unsigned)B);
+    if (dtype == SVOL_BF16) {
+        hipLaunchKernelGGL(gate_bwd_ln_kernel<bf16_t>, dim3(g1), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)dy2,
+                           (const bf16_t*)x, a, gamma, mean, rstd, (bf16_t*)dx, da, dgamma, dbeta, M, (int)D, rpw1);
+        hipLaunchKernelGGL(gate_bwd_stats_kernel, dim3((unsigned)(B * H)), dim3(256), 0, s, scores, mx, sm, da, cc, (int)L,
+                           (int)H);
+        if (np_ == 1) hipLaunchKernelGGL((gate_bwd_apply_kernel<bf16_t, 1>), g3, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)pos, u, scores, mx, sm, da, cc, (bf16_t*)dx, du, (int)L, (int)D, (int)H, rpw3);
+        else if (np_ == 2) hipLaunchKernelGGL((gate_bwd_apply_kernel<bf16_t, 2>), g3, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)pos, u, scores, mx, sm, da, cc, (bf16_t*)dx, du, (int)L, (int)D, (int)H, rpw3);
+        else hipLaunchKernelGGL((gate_bwd_apply_kernel<bf16_t, 4>), g3, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)pos, u, scores, mx, sm, da, cc, (bf16_t*)dx, du, (int)L, (int)D, (int)H, rpw3);
+    } else {
+        hipLaunchKernelGGL(gate_bwd_ln_kernel<float>, dim3(g1), dim3(256), 0, s, (const float*)dy, (const float*)dy2,
+                           (const float*)x, a, gamma, mean, rstd, (float*)dx, da, dgamma, dbeta, M, (int)D, rpw1);
+        hipLaunchKernelGGL(gate_bwd_stats_kernel, dim3((unsigned)(B * H)), dim3(256), 0, s, scores, mx, sm, da, cc, (int)L,
+                           (int)H);
+        if (np_ == 1) hipLaunchKernelGGL((gate_bwd_apply_kernel<float, 1>), g3, dim3(256), 0, s, (const float*)x, (const float*)pos, u, scores, mx, sm, da, cc, (float*)dx, du, (int)L, (int)D, (int)H, rpw3);
+        else if (np_ == 2) hipLaunchKernelGGL((gate_bwd_apply_kernel<float, 2>), g3, dim3(256), 0, s, (const float*)x, (const float*)pos, u, scores, mx, sm, da, cc, (float*)dx, du, (int)L, (int)D, (int)H, rpw3);
+        else hipLaunchKernelGGL((gate_bwd_apply_kernel<float, 4>), g3, dim3(256), 0, s, (const float*)x, (const float*)pos, u, scores, mx, sm, da, cc, (float*)dx, du, (int)L, (int)D, (int)H, rpw3);
+    }
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+}  // extern "C"

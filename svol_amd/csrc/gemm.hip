@@ -1,0 +1,459 @@
+// GEMM kernels of libsvol_hip (gfx950 / CDNA4, wave64, MFMA).
+//
+//   svol_gemm_nt : C = act(A * B^T + bias) + residual      (nn.Linear forward, dX with pre-transposed W)
+//   svol_gemm_tn : dW += A^T * B                           (weight gradient, contraction over rows)
+//   svol_colsum  : bias gradient
+//   svol_cast / svol_cast_transpose / svol_act_bwd : dtype + activation plumbing
+//
+// Tiling: 128x128 output tile per 256-thread workgroup (2x2 waves, 64x64 per wave = 4x4 MFMA 16x16
+// tiles).  Operand tiles live in LDS as 128-byte rows of eight 16-byte chunks, XOR-swizzled
+// (chunk ^ (row & 7)) so the ds_read_b128 fragment reads of a 16x16 MFMA are bank-conflict free
+// (MI355X guide: ds_read_b128 banks = (addr/4) % 64, 16-lane groups).  One template serves both
+// element types: bf16 feeds v_mfma_f32_16x16x32_bf16 (one MFMA per chunk-group of 4 chunks), f32
+// feeds v_mfma_f32_16x16x4_f32 (four MFMAs per chunk group, element e of every lane's chunk) —
+// the contraction index permutation is identical for A and B so the sum is unchanged.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct Tr;
+template <> struct Tr<bf16_t> { static constexpr int EPC = 8; };  // elements per 16-byte chunk
+template <> struct Tr<float> { static constexpr int EPC = 4; };
+
+__device__ __forceinline__ void mma_chunk(f32x4& acc, const uint4& a, const uint4& b, bf16_t) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc,
+                                                  0, 0, 0);
+}
+__device__ __forceinline__ void mma_chunk(f32x4& acc, const uint4& a, const uint4& b, float) {
+    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], acc, 0, 0, 0);
+}
+
+struct NtArgs {
+    const void* A; const void* A2; const void* B; void* C;
+    const float* bias; void* pre; const void* res;
+    int64_t lda, ldb, ldc, ldr, n_split;
+    int M, N, K, act;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs p) {
+    constexpr int EPC = Tr<T>::EPC;
+    constexpr int BK = 8 * EPC;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 128 * 128];
+    char* sA = smem;
+    char* sB = smem + 128 * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bm = blockIdx.y * 128, bn = blockIdx.x * 128;
+    const T* A = reinterpret_cast<const T*>((p.A2 != nullptr && bn >= p.n_split) ? p.A2 : p.A);
+    const T* B = reinterpret_cast<const T*>(p.B);
+
+    uint4 ra[4], rb[4];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+            const int kk = k0 + ch * EPC;
+            const int gm = bm + row, gn = bn + row;
+            ra[i] = (gm < p.M && kk < p.K) ? *reinterpret_cast<const uint4*>(A + (int64_t)gm * p.lda + kk)
+                                           : make_uint4(0, 0, 0, 0);
+            rb[i] = (gn < p.N && kk < p.K) ? *reinterpret_cast<const uint4*>(B + (int64_t)gn * p.ldb + kk)
+                                           : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+            const int off = row * 128 + ((ch ^ (row & 7)) << 4);
+            *reinterpret_cast<uint4*>(sA + off) = ra[i];
+            *reinterpret_cast<uint4*>(sB + off) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    load_tile(0);
+    for (int k0 = 0; k0 < p.K; k0 += BK) {
+        store_tile();
+        __syncthreads();
+        if (k0 + BK < p.K) load_tile(k0 + BK);  // next tile's HBM latency hides under the MFMAs
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            uint4 af[4], bf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int rowA = wm * 64 + t * 16 + fr;
+                af[t] = *reinterpret_cast<const uint4*>(sA + rowA * 128 + (((4 * g + fq) ^ (rowA & 7)) << 4));
+                const int rowB = wn * 64 + t * 16 + fr;
+                bf[t] = *reinterpret_cast<const uint4*>(sB + rowB * 128 + (((4 * g + fq) ^ (rowB & 7)) << 4));
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) mma_chunk(acc[mt][nt], af[mt], bf[nt], T());
+        }
+        __syncthreads();
+    }
+
+    // epilogue: acc[mt][nt][r] -> C[m0 + mt*16 + fq*4 + r][n0 + nt*16 + fr]
+    T* C = reinterpret_cast<T*>(p.C);
+    T* pre = reinterpret_cast<T*>(p.pre);
+    const T* res = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = bn + wn * 64 + nt * 16 + fr;
+            if (n >= p.N) continue;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = bm + wm * 64 + mt * 16 + fq * 4 + r;
+                if (m >= p.M) continue;
+                float v = acc[mt][nt][r] + bv;
+                if (pre) pre[(int64_t)m * p.ldc + n] = from_f32<T>(v);
+                if (p.act == SVOL_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (p.act == SVOL_ACT_GELU) v = gelu_f(v);
+                else if (p.act == SVOL_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+                if (res) v += to_f32(res[(int64_t)m * p.ldr + n]);
+                C[(int64_t)m * p.ldc + n] = from_f32<T>(v);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// TN: C[n,k] += sum_m A[m,n] * B[m,k].  Contraction tiles [CT rows of m][128 cols] sit in LDS
+// row-major (as they are in HBM, so the loads stay coalesced); the MFMA operands need the
+// contraction index along the fragment's k, i.e. a TRANSPOSED read:
+//   bf16: ds_read_b64_tr_b16 (gfx950 hardware transpose read, 4 rows x 16 cols per 16-lane group);
+//         rows padded to 288 B so the 8 rows a 32-lane half touches land on distinct banks.  The
+//         fragment's k index 8g+j is mapped to tile row 4g + (j&3) + 16(j>>2) for BOTH operands
+//         (any common permutation of the contraction index leaves the sum unchanged), which makes
+//         each half-wave read 8 consecutive rows.
+//   f32 : v_mfma_f32_16x16x4_f32 takes one element per lane, k = lane>>4: a plain ds_read_b32 of
+//         row (k), column (lane&15); rows padded to 576 B so the two rows of a half-wave differ
+//         by 16 banks.
+// ---------------------------------------------------------------------------
+struct TnArgs {
+    const void* A; const void* B; float* C;
+    int64_t lda, ldb, ldc;
+    int Mc, N, K, m_chunk;
+};
+
+template <typename T> struct TnCfg;
+template <> struct TnCfg<bf16_t> { static constexpr int CT = 64, STRIDE = 288, CPR = 16; };  // chunks per row
+template <> struct TnCfg<float> { static constexpr int CT = 32, STRIDE = 576, CPR = 32; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
+    constexpr int EPC = Tr<T>::EPC;
+    constexpr int CT = TnCfg<T>::CT, S = TnCfg<T>::STRIDE, CPR = TnCfg<T>::CPR;
+    __shared__ __attribute__((aligned(16))) char smem[2 * CT * S];
+    char* sA = smem;
+    char* sB = smem + CT * S;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int n0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
+    const int m_begin = blockIdx.z * p.m_chunk;
+    const int m_end = min(p.Mc, m_begin + p.m_chunk);
+    const T* A = reinterpret_cast<const T*>(p.A);
+    const T* B = reinterpret_cast<const T*>(p.B);
+
+    uint4 ra[4], rb[4];
+    auto load_tile = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c / CPR, ch = c % CPR;
+            const int gm = m0 + row;
+            const int an = n0 + ch * EPC, bk = k0 + ch * EPC;
+            ra[i] = (gm < m_end && an < p.N) ? *reinterpret_cast<const uint4*>(A + (int64_t)gm * p.lda + an)
+                                             : make_uint4(0, 0, 0, 0);
+            rb[i] = (gm < m_end && bk < p.K) ? *reinterpret_cast<const uint4*>(B + (int64_t)gm * p.ldb + bk)
+                                             : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c / CPR, ch = c % CPR;
+            *reinterpret_cast<uint4*>(sA + row * S + ch * 16) = ra[i];
+            *reinterpret_cast<uint4*>(sB + row * S + ch * 16) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    load_tile(m_begin);
+    for (int m0 = m_begin; m0 < m_end; m0 += CT) {
+        store_tile();
+        __syncthreads();
+        if (m0 + CT < m_end) load_tile(m0 + CT);
+        if constexpr (sizeof(T) == 2) {
+            typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+            const int q = fr >> 2, pp = fr & 3;
+#pragma unroll
+            for (int ks = 0; ks < CT / 32; ++ks) {
+                const int row = ks * 32 + 4 * fq + q;
+                bf16x8 af[4], bfr[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int colA = wn * 64 + t * 16 + 4 * pp, colB = wk * 64 + t * 16 + 4 * pp;
+                    bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(sA + row * S + colA * 2));
+                    bf16x4 a1 =
+                        __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(sA + (row + 16) * S + colA * 2));
+                    bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(sB + row * S + colB * 2));
+                    bf16x4 b1 =
+                        __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(sB + (row + 16) * S + colB * 2));
+                    af[t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    bfr[t] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+                        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
+            }
+        } else {
+#pragma unroll 2
+            for (int ks = 0; ks < CT / 4; ++ks) {
+                const int row = ks * 4 + fq;
+                float af[4], bfr[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    af[t] = *reinterpret_cast<const float*>(sA + row * S + (wn * 64 + t * 16 + fr) * 4);
+                    bfr[t] = *reinterpret_cast<const float*>(sB + row * S + (wk * 64 + t * 16 + fr) * 4);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+                        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // C[n][k] += acc: row (output n) = nt*16 + fq*4 + r, col (output k) = kt*16 + fr
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int k = k0 + wk * 64 + kt * 16 + fr;
+            if (k >= p.K) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + nt * 16 + fq * 4 + r;
+                if (n < p.N) atomicAdd(p.C + (int64_t)n * p.ldc + k, acc[nt][kt][r]);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* X, int64_t ldx, float* out, int M, int N, int rows_per_block) {
+    // thread t owns column blockIdx.x*256 + t; rows [blockIdx.y*rpb, ...)
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    float s = 0.f;
+    for (int m = m0; m < m1; ++m) s += to_f32(X[(int64_t)m * ldx + n]);
+    atomicAdd(out + n, s);
+}
+
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* src, TD* dst, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = from_f32<TD>(to_f32(src[i]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* src, T* dst, T* dstT, int R, int C) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + 8 * j, c = c0 + tx;
+        float v = (r < R && c < C) ? src[(int64_t)r * C + c] : 0.f;
+        tile[ty + 8 * j][tx] = v;
+        if (dst && r < R && c < C) dst[(int64_t)r * C + c] = from_f32<T>(v);
+    }
+    __syncthreads();
+    if (dstT) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + ty + 8 * j, r = r0 + tx;
+            if (r < R && c < C) dstT[(int64_t)c * R + r] = from_f32<T>(tile[tx][ty + 8 * j]);
+        }
+    }
+}
+
+template <typename T>
+__global__ void act_bwd_kernel(const T* dy, const T* aux, T* dpre, int act, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float g = to_f32(dy[i]), a = to_f32(aux[i]);
+        float d;
+        if (act == SVOL_ACT_RELU) d = a > 0.f ? g : 0.f;
+        else if (act == SVOL_ACT_GELU) d = g * dgelu_f(a);
+        else if (act == SVOL_ACT_SIGMOID) d = g * a * (1.f - a);
+        else d = g;
+        dpre[i] = from_f32<T>(d);
+    }
+}
+
+inline int grid_1d(int64_t n, int block) {
+    int64_t g = (n + block - 1) / block;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int svol_abi_version(void) { return 1; }
+
+const char* svol_strerror(int code) {
+    switch (code) {
+        case SVOL_OK: return "ok";
+        case SVOL_E_INVALID: return "invalid argument (null pointer, bad size or misaligned buffer)";
+        case SVOL_E_UNSUPPORTED: return "shape not supported by the gfx950 kernels";
+        case SVOL_E_LAUNCH: return "kernel launch failed";
+        default: return "unknown error";
+    }
+}
+
+int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, const void* B, int64_t ldb, void* C,
+                 int64_t ldc, const float* bias, int act, void* pre_act_out, const void* residual, int64_t ldr,
+                 int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
+    if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return SVOL_E_INVALID;
+    if (M == 0 || N == 0) return SVOL_OK;
+    const int epc = dtype == SVOL_BF16 ? 8 : 4;
+    if (dtype != SVOL_BF16 && dtype != SVOL_F32) return SVOL_E_INVALID;
+    if (K % epc || lda % epc || ldb % epc) return SVOL_E_UNSUPPORTED;
+    if (!aligned16(A) || !aligned16(B) || (A2 && !aligned16(A2))) return SVOL_E_INVALID;
+    if (A2 && (n_split % 128)) return SVOL_E_UNSUPPORTED;
+    if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return SVOL_E_UNSUPPORTED;
+    NtArgs p{A, A2, B, C, bias, pre_act_out, residual, lda, ldb, ldc, ldr, n_split, (int)M, (int)N, (int)K, act};
+    dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
+    if (grid.y > 65535u) return SVOL_E_UNSUPPORTED;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == SVOL_BF16) hipLaunchKernelGGL(gemm_nt_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, dim3(256), 0, s, p);
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t Mc, int64_t N,
+                 int64_t K, int dtype, void* stream) {
+    if (!A || !B || !C || Mc < 0 || N <= 0 || K <= 0) return SVOL_E_INVALID;
+    if (Mc == 0) return SVOL_OK;
+    if (dtype != SVOL_BF16 && dtype != SVOL_F32) return SVOL_E_INVALID;
+    const int epc = dtype == SVOL_BF16 ? 8 : 4;
+    if (N % epc || K % epc || lda % epc || ldb % epc) return SVOL_E_UNSUPPORTED;
+    if (!aligned16(A) || !aligned16(B)) return SVOL_E_INVALID;
+    if (Mc > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return SVOL_E_UNSUPPORTED;
+    const int ct = dtype == SVOL_BF16 ? 64 : 32;
+    const int64_t tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    // split the contraction so that ~1024 workgroups exist (256 CUs x 4), chunk a multiple of CT
+    int64_t want = (1024 + tiles - 1) / tiles;
+    int64_t chunk = (Mc + want - 1) / want;
+    chunk = ((chunk + ct - 1) / ct) * ct;
+    if (chunk < 4 * ct) chunk = 4 * ct;
+    const int64_t splits = (Mc + chunk - 1) / chunk;
+    if (splits > 65535) return SVOL_E_UNSUPPORTED;
+    TnArgs p{A, B, C, lda, ldb, ldc, (int)Mc, (int)N, (int)K, (int)chunk};
+    dim3 grid((unsigned)((K + 127) / 128), (unsigned)((N + 127) / 128), (unsigned)splits);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == SVOL_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 0, s, p);
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_colsum(const void* X, int64_t ldx, float* out, int64_t M, int64_t N, int dtype, void* stream) {
+    if (!X || !out || M < 0 || N <= 0) return SVOL_E_INVALID;
+    if (M == 0) return SVOL_OK;
+    if (M > (1 << 30) || N > (1 << 30)) return SVOL_E_UNSUPPORTED;
+    const int colblocks = (int)((N + 255) / 256);
+    int rowblocks = (int)((M + 255) / 256);
+    int maxrb = 2048 / colblocks;
+    if (maxrb < 1) maxrb = 1;
+    if (rowblocks > maxrb) rowblocks = maxrb;
+    const int rpb = (int)((M + rowblocks - 1) / rowblocks);
+    dim3 grid(colblocks, (unsigned)((M + rpb - 1) / rpb));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == SVOL_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, ldx, out, (int)M, (int)N, rpb);
+    else if (dtype == SVOL_F32)
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)X, ldx, out, (int)M, (int)N, rpb);
+    else return SVOL_E_INVALID;
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_cast(const void* src, int dtype_src, void* dst, int dtype_dst, int64_t n, void* stream) {
+    if (!src || !dst || n < 0) return SVOL_E_INVALID;
+    if (n == 0) return SVOL_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int g = grid_1d(n, 256);
+    if (dtype_src == SVOL_F32 && dtype_dst == SVOL_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(g), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, n);
+    else if (dtype_src == SVOL_BF16 && dtype_dst == SVOL_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, n);
+    else if (dtype_src == SVOL_F32 && dtype_dst == SVOL_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, s, (const float*)src, (float*)dst, n);
+    else if (dtype_src == SVOL_BF16 && dtype_dst == SVOL_BF16)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
+    else return SVOL_E_INVALID;
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_cast_transpose(const float* src, void* dst, void* dstT, int dtype, int64_t R, int64_t C, void* stream) {
+    if (!src || R <= 0 || C <= 0 || (!dst && !dstT)) return SVOL_E_INVALID;
+    if (R > (1 << 30) || C > (1 << 30)) return SVOL_E_UNSUPPORTED;
+    dim3 grid((unsigned)((C + 31) / 32), (unsigned)((R + 31) / 32));
+    if (grid.y > 65535u) return SVOL_E_UNSUPPORTED;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == SVOL_BF16)
+        hipLaunchKernelGGL(cast_transpose_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, (bf16_t*)dstT, (int)R, (int)C);
+    else if (dtype == SVOL_F32)
+        hipLaunchKernelGGL(cast_transpose_kernel<float>, grid, dim3(256), 0, s, src, (float*)dst, (float*)dstT, (int)R, (int)C);
+    else return SVOL_E_INVALID;
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_act_bwd(const void* dy, const void* aux, void* dpre, int act, int64_t n, int dtype, void* stream) {
+    if (!dy || !aux || !dpre || n < 0) return SVOL_E_INVALID;
+    if (n == 0) return SVOL_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int g = grid_1d(n, 256);
+    if (dtype == SVOL_BF16)
+        hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)aux, (bf16_t*)dpre, act, n);
+    else if (dtype == SVOL_F32)
+        hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)dy, (const float*)aux, (float*)dpre, act, n);
+    else return SVOL_E_INVALID;
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+}  // extern "C"

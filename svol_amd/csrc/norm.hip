@@ -1,0 +1,243 @@
+// LayerNorm (+dropout, +positional add) and sine positional encoding — HBM-bound row kernels.
+// One wave (64 lanes) per row, 4 contiguous elements per lane per pass (8 B bf16 / 16 B f32
+// coalesced loads), fp32 statistics, wave shuffle reductions (no LDS).
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAX_PASSES = 4;  // D <= 4 * 64 * 4 = 1024
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     T* __restrict__ ypos, const T* __restrict__ pos, int64_t pos_rows,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int64_t M,
+                                                     int D, float p, float inv_keep, uint64_t seed) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const T* xr = x + row * D;
+    float v[LN_MAX_PASSES][4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAX_PASSES; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < D) {
+            Vec4<T> t; t.load(xr + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[j][e] = t.get(e); s += v[j][e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][e] = 0.f;
+        }
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAX_PASSES; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    const T* pr = pos ? pos + (row % pos_rows) * D : nullptr;
+#pragma unroll
+    for (int j = 0; j < LN_MAX_PASSES; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < D) {
+            Vec4<T> o, op, pv;
+            if (pr) pv.load(pr + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float r = (v[j][e] - mu) * rs * gamma[c + e] + beta[c + e];
+                if (p > 0.f) r *= dropout_scale(seed, (uint64_t)(row * D + c + e), p, inv_keep);
+                o.set(e, r);
+                if (pr) op.set(e, r + pv.get(e));
+            }
+            o.store(y + row * D + c);
+            if (ypos) op.store(ypos + row * D + c);
+        }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy_total * gamma (dropout mask applied first)
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
+                                                     const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     T* __restrict__ dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int64_t M, int D, float p,
+                                                     float inv_keep, uint64_t seed, int rows_per_wave) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t r0 = wave_id * rows_per_wave;
+    float dg[LN_MAX_PASSES][4], db[LN_MAX_PASSES][4];
+#pragma unroll
+    for (int j = 0; j < LN_MAX_PASSES; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dg[j][e] = 0.f; db[j][e] = 0.f; }
+
+    for (int64_t row = r0; row < r0 + rows_per_wave && row < M; ++row) {
+        const float mu = mean[row], rs = rstd[row];
+        float g[LN_MAX_PASSES][4], xh[LN_MAX_PASSES][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAX_PASSES; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            if (c < D) {
+                Vec4<T> a, b, xv;
+                a.load(dy + row * D + c);
+                if (dy2) b.load(dy2 + row * D + c);
+                xv.load(x + row * D + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float d = a.get(e) + (dy2 ? b.get(e) : 0.f);
+                    if (p > 0.f) d *= dropout_scale(seed, (uint64_t)(row * D + c + e), p, inv_keep);
+                    const float h = (xv.get(e) - mu) * rs;
+                    xh[j][e] = h;
+                    dg[j][e] += d * h;
+                    db[j][e] += d;
+                    const float gg = d * gamma[c + e];
+                    g[j][e] = gg;
+                    s1 += gg;
+                    s2 += gg * h;
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int j = 0; j < LN_MAX_PASSES; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            if (c < D) {
+                Vec4<T> o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.set(e, rs * (g[j][e] - s1 - xh[j][e] * s2));
+                o.store(dx + row * D + c);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LN_MAX_PASSES; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(dgamma + c + e, dg[j][e]);
+                atomicAdd(dbeta + c + e, db[j][e]);
+            }
+        }
+    }
+}
+
+// position_encoding.py:51-71 — one workgroup per batch row: inclusive scan of the mask over L,
+// then pos[l, 2i] = sin(x / t_i), pos[l, 2i+1] = cos(x / t_i) with x = cumsum/(last+1e-6)*2pi.
+// grid = (ceil(L/64), B): every block re-reduces the (tiny) mask prefix it needs, then writes 64 tokens.
+template <typename T>
+__global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ mask, T* __restrict__ pos, int L, int D) {
+    __shared__ float red[2][4];
+    __shared__ float xe[64];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* mr = mask + (int64_t)b * L;
+    const int l0 = blockIdx.x * 64;
+    float before = 0.f, all = 0.f;
+    for (int l = tid; l < L; l += 256) {
+        const float v = (mr[l] != 0.f) ? 1.f : 0.f;
+        all += v;
+        if (l < l0) before += v;
+    }
+    before = wave_sum(before);
+    all = wave_sum(all);
+    if (lane == 0) { red[0][wave] = before; red[1][wave] = all; }
+    __syncthreads();
+    if (tid == 0) {
+        float run = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        const float denom = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) + 1e-6f;
+        for (int i = 0; i < 64 && l0 + i < L; ++i) {
+            run += (mr[l0 + i] != 0.f) ? 1.f : 0.f;
+            xe[i] = run / denom * 6.283185307179586f;
+        }
+    }
+    __syncthreads();
+    const int ntok = min(64, L - l0);
+    for (int e = tid; e < ntok * D; e += 256) {
+        const int t = e / D, i = e - t * D;
+        const float dim_t = powf(10000.f, (float)(2 * (i / 2)) / (float)D);
+        const float a = xe[t] / dim_t;
+        pos[((int64_t)b * L + l0 + t) * D + i] = from_f32<T>((i & 1) ? cosf(a) : sinf(a));
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int svol_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, void* ypos, const void* pos,
+                       int64_t pos_rows, float* mean, float* rstd, int64_t M, int64_t D, float dropout_p,
+                       uint64_t seed, int dtype, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || M < 0 || D <= 0) return SVOL_E_INVALID;
+    if ((ypos != nullptr) != (pos != nullptr)) return SVOL_E_INVALID;
+    if (pos && pos_rows <= 0) return SVOL_E_INVALID;
+    if (D % 4 || D > LN_MAX_PASSES * 256) return SVOL_E_UNSUPPORTED;
+    if (dropout_p < 0.f || dropout_p >= 1.f) return SVOL_E_INVALID;
+    if (M == 0) return SVOL_OK;
+    const float inv_keep = 1.f / (1.f - dropout_p);
+    const unsigned grid = (unsigned)((M + 3) / 4);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == SVOL_BF16)
+        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y,
+                           (bf16_t*)ypos, (const bf16_t*)pos, pos_rows, mean, rstd, M, (int)D, dropout_p, inv_keep, seed);
+    else if (dtype == SVOL_F32)
+        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y,
+                           (float*)ypos, (const float*)pos, pos_rows, mean, rstd, M, (int)D, dropout_p, inv_keep, seed);
+    else return SVOL_E_INVALID;
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_layernorm_bwd(const void* dy, const void* dy2, const void* x, const float* gamma, const float* mean,
+                       const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t M, int64_t D, float dropout_p,
+                       uint64_t seed, int dtype, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || M < 0 || D <= 0) return SVOL_E_INVALID;
+    if (D % 4 || D > LN_MAX_PASSES * 256) return SVOL_E_UNSUPPORTED;
+    if (dropout_p < 0.f || dropout_p >= 1.f) return SVOL_E_INVALID;
+    if (M == 0) return SVOL_OK;
+    const float inv_keep = 1.f / (1.f - dropout_p);
+    // ~4096 waves; each wave walks `rpw` consecutive rows and issues one set of atomics
+    int64_t rpw = (M + 4095) / 4096;
+    if (rpw < 1) rpw = 1;
+    const int64_t waves = (M + rpw - 1) / rpw;
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == SVOL_BF16)
+        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)dy2,
+                           (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, dgamma, dbeta, M, (int)D, dropout_p, inv_keep,
+                           seed, (int)rpw);
+    else if (dtype == SVOL_F32)
+        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)dy2,
+                           (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, M, (int)D, dropout_p, inv_keep,
+                           seed, (int)rpw);
+    else return SVOL_E_INVALID;
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_posenc_sine(const float* mask, void* pos, int64_t B, int64_t L, int64_t D, int dtype, void* stream) {
+    if (!mask || !pos || B <= 0 || L <= 0 || D <= 0) return SVOL_E_INVALID;
+    if (L > (1 << 24) || D > 4096) return SVOL_E_UNSUPPORTED;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (B > 65535) return SVOL_E_UNSUPPORTED;
+    dim3 grid((unsigned)((L + 63) / 64), (unsigned)B);
+    if (dtype == SVOL_BF16)
+        hipLaunchKernelGGL(posenc_kernel<bf16_t>, grid, dim3(256), 0, s, mask, (bf16_t*)pos, (int)L, (int)D);
+    else if (dtype == SVOL_F32)
+        hipLaunchKernelGGL(posenc_kernel<float>, grid, dim3(256), 0, s, mask, (float*)pos, (int)L, (int)D);
+    else return SVOL_E_INVALID;
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+}  // extern "C"

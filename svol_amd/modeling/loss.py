@@ -1,0 +1,86 @@
+"""Set criterion (reference lib/modeling/loss.py:10-37,126-157,192-213) on the device kernels.
+
+``SetCriterion.forward(outputs, targets)`` returns the same dict of 0-d tensors
+(``loss_label``, ``class_error``, ``loss_bbox``, ``loss_giou`` and their
+``_{i}`` aux copies) and exposes the same ``weight_dict``.  Matching of ALL
+decoder layers (the reference re-matches every aux layer, loss.py:148-155),
+the losses and their gradients take three kernel launches and no host sync.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .. import ops
+from .matcher import build_matcher
+
+
+class SetCriterion(nn.Module):
+    def __init__(self, matcher, weight_dict, eos_coef, losses, bbox_type, sketch_head):
+        super().__init__()
+        self.matcher = matcher
+        self.weight_dict = weight_dict
+        self.losses = losses
+        self.bbox_type = bbox_type
+        self.sketch_head = sketch_head
+        self.foreground_label = 0
+        self.background_label = 1
+        self.eos_coef = eos_coef
+        empty_weight = torch.ones(2)
+        empty_weight[-1] = self.eos_coef
+        self.register_buffer('empty_weight', empty_weight)
+        for l_ in losses:
+            if l_ not in ('labels', 'boxes'):
+                raise AssertionError(f'do you really want to compute {l_} loss?')
+        self.last_match = None
+        self.last_packed = None
+
+    def forward(self, outputs, targets):
+        if self.sketch_head == 'sketch_detr':
+            raise NotImplementedError('sketch_detr is not constructible from the reference option surface '
+                                      '(SURVEY.md D1); only the svanet criterion path is built')
+        if '_svol_stacked' in outputs:
+            logits_all, boxes_all = outputs['_svol_stacked']
+        else:  # a hand-made outputs dict: aux layers first, last layer last (svanet.py:128-137 order)
+            aux = outputs.get('aux_outputs', [])
+            logits_all = torch.stack([a['pred_logits'] for a in aux] + [outputs['pred_logits']])
+            boxes_all = torch.stack([a['pred_boxes'] for a in aux] + [outputs['pred_boxes']])
+        if not logits_all.is_cuda:
+            raise RuntimeError('svol_amd.SetCriterion runs on the MI355X only (no CPU fallback)')
+        NL, B, N = logits_all.shape[:3]
+        m = self.matcher
+        packed = m.pack(targets, NL, B, N, logits_all.device)
+        losses, match = ops.SetCriterionFn.apply(logits_all, boxes_all, packed, m.cost_bbox, m.cost_giou,
+                                                 m.cost_class, self.eos_coef)
+        self.last_match, self.last_packed = match, packed
+        out = {}
+        names = []
+        if 'labels' in self.losses:
+            names += [(0, 'loss_label'), (3, 'class_error')]
+        if 'boxes' in self.losses:
+            names += [(1, 'loss_bbox'), (2, 'loss_giou')]
+        for col, name in names:
+            out[name] = losses[NL - 1, col]
+        for i in range(NL - 1):
+            for col, name in names:
+                out[f'{name}_{i}'] = losses[i, col]
+        return out
+
+    def last_indices(self):
+        """Reference-format matcher indices of the last forward, per layer (synchronises)."""
+        p = self.last_packed
+        p.check_status()
+        return [p.indices_from_match(self.last_match, l_) for l_ in range(p.n_layers)]
+
+
+def build_loss(args):
+    matcher = build_matcher(args)
+    weight_dict = {'loss_bbox': args.set_cost_bbox, 'loss_giou': args.set_cost_giou,
+                   'loss_label': args.set_cost_class}
+    if args.aux_loss:
+        aux = {}
+        for i in range(args.num_layers - 1):
+            aux.update({k + f'_{i}': v for k, v in weight_dict.items()})
+        weight_dict.update(aux)
+    return SetCriterion(matcher=matcher, weight_dict=weight_dict, eos_coef=args.eos_coef, losses=['labels', 'boxes'],
+                        bbox_type=args.bbox_type, sketch_head=args.sketch_head)

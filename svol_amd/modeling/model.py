@@ -1,0 +1,59 @@
+"""Model assembly (reference lib/modeling/model.py:8-44): backbone -> mask expansion -> head.
+
+``build_model(args)`` / ``SketchLocalizationModel.forward(src_sketch, src_video, src_sketch_mask,
+src_video_mask)`` keep the reference's signatures and the ``backbone.`` / ``head.`` state-dict
+prefixes.  The CNN / ViT feature extractors are outside this round's scope:
+``--backbone features`` plugs pre-extracted features in at the measured boundary;
+asking for ``resnet`` / ``vit`` raises instead of silently running something else.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .svanet import build_svanet
+
+
+class FeatureBackbone(nn.Module):
+    """Identity feature 'backbone': src_sketch [B,Ls,Dskch], src_video [B,T,P,Dvid] (or [B,T*P,Dvid])
+    are already features.  Returns (sketch [B,Ls,D], video [B,T*P,D]) like backbone.py:72-89."""
+
+    def forward(self, src_sketch, src_video):
+        if src_video.dim() == 4:
+            src_video = src_video.flatten(1, 2)
+        return src_sketch, src_video
+
+
+def build_backbone(args):
+    """Like backbone.py:116-152 this MUTATES args (input_vid_dim / input_skch_dim)."""
+    if args.backbone == 'features':
+        args.input_vid_dim = getattr(args, 'input_vid_dim', 512)
+        args.input_skch_dim = getattr(args, 'input_skch_dim', 512)
+        return FeatureBackbone()
+    raise NotImplementedError(
+        f"backbone '{args.backbone}' (torchvision ResNet-18/34 or HF ViT-B/16 with downloaded weights) is not part "
+        "of the MI355X hot-path build yet (SURVEY.md §8 f1/f4); use --backbone features with pre-extracted features")
+
+
+class SketchLocalizationModel(nn.Module):
+    def __init__(self, backbone, head):
+        super().__init__()
+        self.backbone = backbone
+        self.head = head
+
+    def forward(self, src_sketch, src_video, src_sketch_mask=None, src_video_mask=None):
+        T = src_video.shape[1]
+        src_sketch, src_video = self.backbone(src_sketch, src_video)
+        # per-token masks: one sketch-mask entry per sketch token, one frame-mask entry per patch (model.py:21-22)
+        src_sketch_mask = src_sketch_mask.repeat_interleave(src_sketch.shape[1], dim=1)
+        src_video_mask = src_video_mask.repeat_interleave(src_video.shape[1] // T, dim=1)
+        return self.head(src_sketch, src_sketch_mask, src_video, src_video_mask)
+
+
+def build_model(args):
+    backbone = build_backbone(args)
+    if args.sketch_head == 'svanet':
+        head = build_svanet(args)
+    else:  # 'sketch_detr' cannot be built from the reference's own option surface
+        raise NotImplementedError
+    return SketchLocalizationModel(backbone, head)

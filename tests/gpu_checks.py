@@ -1,0 +1,416 @@
+"""Parity checks of the HIP path (through the C-ABI) against the CPU oracle / plain torch fp64 math.
+
+Every function returns a dict {name: (error, tolerance)}; tests/test_gpu_*.py assert on them and
+tools/gpu_diag.py prints them all without stopping at the first failure.
+
+Error metric: max |got - ref| / (max|ref| + tiny)  ("relative to scale"), ref computed in fp64 on
+the CPU from the SAME (already rounded) inputs the kernel saw.
+"""
+import math
+
+import numpy as np
+import torch
+
+from oracle import svol_oracle as O
+from svol_amd import ops
+from svol_amd import synthetic as syn
+
+DEV = 'cuda'
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2}
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def rel_err(got, ref):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    if not torch.isfinite(got).all():
+        return float('inf')
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
+
+
+def _rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def _act(x, act):
+    if act == ops.ACT_RELU:
+        return torch.relu(x)
+    if act == ops.ACT_GELU:
+        return O.gelu_erf(x)
+    if act == ops.ACT_SIGMOID:
+        return torch.sigmoid(x)
+    return x
+
+
+# ---------------------------------------------------------------------------
+def check_gemm_nt():
+    res = {}
+    shapes = [(300, 200, 96), (128, 128, 64), (50, 2, 32), (1, 256, 512), (257, 130, 8), (640, 2048, 256)]
+    for dt in DTYPES:
+        for (M, N, K) in shapes:
+            for act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_GELU, ops.ACT_SIGMOID):
+                if act != ops.ACT_NONE and (M, N, K) != (300, 200, 96):
+                    continue
+                A = _rnd((M, K), dt, 1)
+                Bm = _rnd((N, K), dt, 2, 1.0 / math.sqrt(K))
+                bias = _rnd((N,), torch.float32, 3)
+                R = _rnd((M, N), dt, 4)
+                out = ops.gemm_nt(A.to(DEV), Bm.to(DEV), bias.to(DEV), act, residual=R.to(DEV),
+                                  want_pre=(act == ops.ACT_GELU))
+                pre_ref = A.double() @ Bm.double().t() + bias.double()
+                ref = _act(pre_ref, act) + R.double()
+                if act == ops.ACT_GELU:
+                    out, pre = out
+                    res[f'gemm_nt/{dt}/{M}x{N}x{K}/pre'] = (rel_err(pre, pre_ref), TOL[dt])
+                res[f'gemm_nt/{dt}/{M}x{N}x{K}/act{act}'] = (rel_err(out, ref), TOL[dt])
+        # column-slice operands (leading dimension != width)
+        big = _rnd((100, 96), dt, 5)
+        W = _rnd((64, 32), dt, 6)
+        outb = torch.zeros((100, 128), dtype=dt, device=DEV)
+        ops.gemm_nt(big.to(DEV)[:, 32:64], W.to(DEV), out=outb[:, 64:])
+        ref = big[:, 32:64].double() @ W.double().t()
+        res[f'gemm_nt/{dt}/slices'] = (rel_err(outb[:, 64:], ref), TOL[dt])
+        res[f'gemm_nt/{dt}/slices_untouched'] = (float(outb[:, :64].abs().max()), 0.0)
+    return res
+
+
+def check_gemm_tn():
+    res = {}
+    for dt in DTYPES:
+        for (Mc, N, K) in [(1000, 64, 32), (333, 200, 136), (64, 8, 8), (5000, 256, 256), (70, 2048, 32)]:
+            A = _rnd((Mc, N), dt, 7)
+            Bm = _rnd((Mc, K), dt, 8)
+            # asymmetric integer-valued data catches row/col swaps exactly
+            out = ops.gemm_tn(A.to(DEV), Bm.to(DEV))
+            ref = A.double().t() @ Bm.double()
+            res[f'gemm_tn/{dt}/{Mc}x{N}x{K}'] = (rel_err(out, ref), 5e-5 if dt == torch.float32 else 2e-5)
+        Ai = torch.randint(-3, 4, (96, 24), generator=torch.Generator().manual_seed(1)).to(dt)
+        Bi = torch.randint(-3, 4, (96, 40), generator=torch.Generator().manual_seed(2)).to(dt)
+        out = ops.gemm_tn(Ai.to(DEV), Bi.to(DEV))
+        res[f'gemm_tn/{dt}/integer_exact'] = (float((out.cpu().double() - Ai.double().t() @ Bi.double()).abs().max()), 0.0)
+    return res
+
+
+def check_small_ops():
+    res = {}
+    for dt in DTYPES:
+        X = _rnd((777, 130), dt, 9)
+        res[f'colsum/{dt}'] = (rel_err(ops.colsum(X.to(DEV)), X.double().sum(0)), 1e-5)
+        W = _rnd((70, 50), torch.float32, 10)
+        a, b = ops.cast_transpose(W.to(DEV), dt)
+        res[f'cast_transpose/{dt}/a'] = (rel_err(a, W.to(dt)), 0.0)
+        res[f'cast_transpose/{dt}/b'] = (rel_err(b, W.to(dt).t()), 0.0)
+        dy, aux = _rnd((1000,), dt, 11), _rnd((1000,), dt, 12)
+        for act in (ops.ACT_RELU, ops.ACT_GELU, ops.ACT_SIGMOID):
+            a64 = aux.double().requires_grad_(True)
+            aux_in = aux
+            if act == ops.ACT_GELU:
+                y = O.gelu_erf(a64)
+            elif act == ops.ACT_RELU:
+                y = torch.relu(a64)
+            else:  # sigmoid: aux is the OUTPUT y
+                aux_in = torch.sigmoid(aux.double()).to(dt)
+                a64 = aux_in.double()
+            if act == ops.ACT_SIGMOID:
+                ref = dy.double() * a64 * (1 - a64)
+            elif act == ops.ACT_RELU:
+                ref = dy.double() * (aux.double() > 0)
+            else:
+                y.backward(dy.double())
+                ref = a64.grad
+            got = ops.act_bwd(dy.to(DEV), aux_in.to(DEV), act)
+            res[f'act_bwd/{dt}/act{act}'] = (rel_err(got, ref), TOL[dt])
+        x32 = _rnd((1000,), torch.float32, 13)
+        res[f'cast/{dt}'] = (rel_err(ops.cast(x32.to(DEV), dt), x32.to(dt)), 0.0)
+    return res
+
+
+def check_layernorm():
+    res = {}
+    for dt in DTYPES:
+        for (M, D, prow) in [(100, 32, 100), (77, 256, 11), (33, 512, 33), (5, 1024, 5), (64, 64, 8)]:
+            x = _rnd((M, D), dt, 14)
+            g = (1 + 0.1 * _rnd((D,), torch.float32, 15))
+            b = 0.1 * _rnd((D,), torch.float32, 16)
+            pos = _rnd((prow, D), dt, 17)
+            dy, dyp = _rnd((M, D), dt, 18), _rnd((M, D), dt, 19)
+            y, ypos, mean, rstd = ops.layernorm_fwd(x.to(DEV), g.to(DEV), b.to(DEV), pos.to(DEV))
+            x64 = x.double().requires_grad_(True)
+            g64, b64 = g.double().requires_grad_(True), b.double().requires_grad_(True)
+            yr = O.layer_norm(x64, g64, b64)
+            ypr = yr + pos.double().repeat(M // prow, 1)
+            res[f'ln_fwd/{dt}/{M}x{D}/y'] = (rel_err(y, yr), TOL[dt])
+            res[f'ln_fwd/{dt}/{M}x{D}/ypos'] = (rel_err(ypos, ypr), TOL[dt])
+            (yr * dy.double() + ypr * dyp.double()).sum().backward()
+            dx, dg, db = ops.layernorm_bwd(dy.to(DEV), dyp.to(DEV), x.to(DEV), g.to(DEV), mean, rstd)
+            res[f'ln_bwd/{dt}/{M}x{D}/dx'] = (rel_err(dx, x64.grad), TOL[dt])
+            res[f'ln_bwd/{dt}/{M}x{D}/dgamma'] = (rel_err(dg, g64.grad), 1e-4)
+            res[f'ln_bwd/{dt}/{M}x{D}/dbeta'] = (rel_err(db, b64.grad), 1e-4)
+    # dropout: mask statistics, fwd/bwd consistency (fp32)
+    M, D, p = 512, 256, 0.4
+    x = _rnd((M, D), torch.float32, 20)
+    g = torch.ones(D) * 1.5
+    b = torch.ones(D) * 4.0  # keeps LN output away from 0 so the mask is recoverable
+    y0, _, mean, rstd = ops.layernorm_fwd(x.to(DEV), g.to(DEV), b.to(DEV))
+    y1, _, _, _ = ops.layernorm_fwd(x.to(DEV), g.to(DEV), b.to(DEV), None, p, 1234)
+    ratio = (y1 / y0).cpu()
+    keep = ratio.abs() > 1e-6
+    res['dropout/keep_fraction'] = (abs(float(keep.float().mean()) - (1 - p)), 0.01)
+    res['dropout/scale'] = (float((ratio[keep] - 1 / (1 - p)).abs().max()), 1e-5)
+    y2, _, _, _ = ops.layernorm_fwd(x.to(DEV), g.to(DEV), b.to(DEV), None, p, 1235)
+    res['dropout/seed_changes_mask'] = (0.0 if float(((y2 != 0) != (y1 != 0)).float().mean()) > 0.2 else 1.0, 0.5)
+    dy = _rnd((M, D), torch.float32, 21)
+    dx, dg, db = ops.layernorm_bwd(dy.to(DEV), None, x.to(DEV), g.to(DEV), mean, rstd, p, 1234)
+    x64 = x.double().requires_grad_(True)
+    (O.layer_norm(x64, g.double(), b.double()) * (keep.double() / (1 - p)) * dy.double()).sum().backward()
+    res['dropout/bwd_dx'] = (rel_err(dx, x64.grad), 2e-5)
+    return res
+
+
+def check_posenc():
+    res = {}
+    mask = torch.ones(3, 150)
+    mask[1, 100:] = 0
+    mask[2, 7:] = 0
+    for dt in DTYPES:
+        for D in (32, 256):
+            got = ops.posenc_sine(mask.to(DEV), D, dt)
+            ref = O.position_embedding_sine(mask.bool(), D)
+            res[f'posenc/{dt}/{D}'] = (rel_err(got, ref), 2e-5 if dt == torch.float32 else 8e-3)
+    return res
+
+
+def _attn_ref(q, k, v, B, H, Lq, Lk, dh, kbias):
+    q4 = q.double().view(B, Lq, H, dh).transpose(1, 2)
+    k4 = k.double().view(B, Lk, H, dh).transpose(1, 2)
+    v4 = v.double().view(B, Lk, H, dh).transpose(1, 2)
+    s = q4 @ k4.transpose(-1, -2) / math.sqrt(dh)
+    if kbias is not None:
+        s = s + kbias.double()[:, None, None, :]
+    p = torch.softmax(s, -1)
+    o = (p @ v4).transpose(1, 2).reshape(B * Lq, H * dh)
+    lse2 = torch.logsumexp(s, -1) / math.log(2.0)
+    return o, lse2
+
+
+def check_attention():
+    res = {}
+    cases = [(2, 4, 70, 150, 8, True), (1, 8, 200, 200, 32, False), (2, 8, 100, 333, 32, True), (1, 2, 129, 64, 16, False),
+             (1, 8, 384, 384, 32, False)]
+    for dt in DTYPES:
+        for (B, H, Lq, Lk, dh, masked) in cases:
+            d = H * dh
+            q, k, v = _rnd((B * Lq, d), dt, 30, 1.5), _rnd((B * Lk, d), dt, 31, 1.5), _rnd((B * Lk, d), dt, 32)
+            do = _rnd((B * Lq, d), dt, 33)
+            kb = None
+            if masked:
+                kb = torch.zeros(B, Lk)
+                kb[:, Lk - Lk // 4:] = float('-inf')
+                kb[0, 3] = float('-inf')
+            tag = f'attn/{dt}/B{B}H{H}q{Lq}k{Lk}d{dh}{"m" if masked else ""}'
+            qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+            o, lse2 = ops.attn_fwd(qd, kd, vd, B, H, Lq, Lk, dh, kb.to(DEV) if masked else None)
+            q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
+            o_ref, lse_ref = _attn_ref(q64, k64, v64, B, H, Lq, Lk, dh, kb)
+            res[tag + '/o'] = (rel_err(o, o_ref), TOL[dt])
+            res[tag + '/lse2'] = (rel_err(lse2, lse_ref), 1e-5 if dt == torch.float32 else 3e-3)
+            (o_ref * do.double()).sum().backward()
+            dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+            ops.attn_bwd(qd, kd, vd, o, do.to(DEV), lse2, B, H, Lq, Lk, dh, dq, dk, dv, kb.to(DEV) if masked else None)
+            res[tag + '/dq'] = (rel_err(dq, q64.grad), TOL[dt] * 2)
+            res[tag + '/dk'] = (rel_err(dk, k64.grad), TOL[dt] * 2)
+            res[tag + '/dv'] = (rel_err(dv, v64.grad), TOL[dt] * 2)
+        # packed [M,3d] buffer with column slices (the layout the model uses)
+        B, H, L, dh = 2, 4, 96, 8
+        d = H * dh
+        qkv = _rnd((B * L, 3 * d), dt, 34).to(DEV)
+        o, _ = ops.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, L, L, dh)
+        c = qkv.cpu()
+        o_ref, _ = _attn_ref(c[:, :d], c[:, d:2 * d], c[:, 2 * d:], B, H, L, L, dh, None)
+        res[f'attn/{dt}/packed'] = (rel_err(o, o_ref), TOL[dt])
+    return res
+
+
+def _gate_ref(x, pos, u, gamma, beta, H):
+    B, L, D = x.shape
+    s = torch.einsum('bld,bhd->bhl', x + pos, u)
+    a = torch.softmax(s, -1).mean(1)  # [B,L]
+    y = O.layer_norm(x * (1 + a[..., None]), gamma, beta)
+    return y, y + pos
+
+
+def check_gate():
+    res = {}
+    for dt in DTYPES:
+        for (B, L, D, H) in [(2, 50, 32, 4), (3, 200, 256, 8), (1, 77, 512, 8), (2, 24, 64, 8)]:
+            x, pos = _rnd((B, L, D), dt, 40), _rnd((B, L, D), dt, 41)
+            u = _rnd((B, H, D), torch.float32, 42, 0.2)
+            g = 1 + 0.1 * _rnd((D,), torch.float32, 43)
+            b = 0.1 * _rnd((D,), torch.float32, 44)
+            dy, dyp = _rnd((B, L, D), dt, 45), _rnd((B, L, D), dt, 46)
+            xd = x.to(DEV).requires_grad_(True)
+            ud = u.to(DEV).requires_grad_(True)
+            gd, bd = g.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+            y, ypos = ops.gate(xd, pos.to(DEV), ud, gd, bd, H)
+            x64, u64 = x.double().requires_grad_(True), u.double().requires_grad_(True)
+            g64, b64 = g.double().requires_grad_(True), b.double().requires_grad_(True)
+            yr, ypr = _gate_ref(x64, pos.double(), u64, g64, b64, H)
+            tag = f'gate/{dt}/B{B}L{L}D{D}H{H}'
+            res[tag + '/y'] = (rel_err(y, yr), TOL[dt])
+            res[tag + '/ypos'] = (rel_err(ypos, ypr), TOL[dt])
+            (yr * dy.double() + ypr * dyp.double()).sum().backward()
+            torch.autograd.backward([y, ypos], [dy.to(DEV), dyp.to(DEV)])
+            res[tag + '/dx'] = (rel_err(xd.grad, x64.grad), TOL[dt] * 2)
+            res[tag + '/du'] = (rel_err(ud.grad, u64.grad), 2e-4 if dt == torch.float32 else 2e-2)
+            res[tag + '/dgamma'] = (rel_err(gd.grad, g64.grad), 1e-4 if dt == torch.float32 else 1e-2)
+            res[tag + '/dbeta'] = (rel_err(bd.grad, b64.grad), 1e-4 if dt == torch.float32 else 1e-2)
+    return res
+
+
+# ---------------------------------------------------------------------------
+def check_criterion(z, meta, name):
+    """Criterion-only golden: indices bit exact, losses 1e-5, grads 1e-4."""
+    from svol_amd.modeling.loss import build_loss
+    res = {}
+    args = syn.head_args(**meta['args'])
+    crit = build_loss(args).to(DEV)
+    logits, boxes = syn.synth_head_outputs(meta['B'], meta['N'], seed=1)
+    lg = logits.to(DEV).requires_grad_(True)
+    bx = boxes.to(DEV).requires_grad_(True)
+    tg = syn.synth_targets(meta['B'], meta['T'], seed=1, max_per_frame=meta['max_per_frame'])
+    ld = crit({'pred_logits': lg, 'pred_boxes': bx}, tg)
+    idx = crit.last_indices()[0]
+    p, t, o = z['idx/pred'], z['idx/tgt'], z['idx/offs']
+    bad = 0
+    for b, (pi, ti) in enumerate(idx):
+        if pi.tolist() != p[o[b]:o[b + 1]].tolist() or ti.tolist() != t[o[b]:o[b + 1]].tolist():
+            bad += 1
+    res[f'{name}/indices_mismatching_videos'] = (float(bad), 0.0)
+    # the matcher module's own reference-format forward
+    idx2 = crit.matcher({'pred_logits': lg.detach(), 'pred_boxes': bx.detach()}, tg)
+    bad2 = sum(1 for (a, b_), (c, d) in zip(idx, idx2) if a.tolist() != c.tolist() or b_.tolist() != d.tolist())
+    res[f'{name}/matcher_forward_vs_criterion'] = (float(bad2), 0.0)
+    names = str(z['loss_names']).split('\n')
+    for k, v in zip(names, z['loss_values']):
+        res[f'{name}/{k}'] = (abs(float(ld[k]) - v) / max(1.0, abs(v)), 1e-5)
+    wd = crit.weight_dict
+    tot = sum(ld[k] * wd[k] for k in ld.keys() if k in wd)
+    tot.backward()
+    res[f'{name}/g_logits'] = (rel_err(lg.grad, torch.from_numpy(z['g_logits'])), 1e-4)
+    res[f'{name}/g_boxes'] = (rel_err(bx.grad, torch.from_numpy(z['g_boxes'])), 1e-4)
+    return res
+
+
+def check_lsap_vs_scipy(n_cases=60):
+    """Device LSAP vs scipy on random rectangular blocks incl. heavy ties (bit exact)."""
+    from scipy.optimize import linear_sum_assignment
+    from svol_amd import _lib
+    rng = np.random.RandomState(5)
+    shapes = [(rng.randint(1, 120), rng.randint(1, 70)) for _ in range(n_cases)] + [(100, 64), (320, 45), (10, 2), (4, 12)]
+    costs = []
+    for i, (nr, nc) in enumerate(shapes):
+        if i % 3 == 0:
+            costs.append(rng.randint(0, 3, size=(nr, nc)).astype(np.float32))
+        elif i % 3 == 1:
+            costs.append(rng.random_sample((nr, nc)).astype(np.float32))
+        else:
+            costs.append(np.zeros((nr, nc), np.float32))
+    P = len(costs)
+    pred_cnt = np.array([c.shape[0] for c in costs], np.int32)
+    tgt_cnt = np.array([c.shape[1] for c in costs], np.int32)
+    pred_off = np.concatenate([[0], np.cumsum(pred_cnt)[:-1]]).astype(np.int32)
+    tgt_off = np.concatenate([[0], np.cumsum(tgt_cnt)[:-1]]).astype(np.int32)
+    cost_off = np.concatenate([[0], np.cumsum(pred_cnt.astype(np.int64) * tgt_cnt)[:-1]]).astype(np.int64)
+    flat = torch.from_numpy(np.concatenate([c.reshape(-1) for c in costs])).to(DEV)
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    match = torch.empty((int(pred_cnt.sum()),), dtype=torch.int32, device=DEV)
+    status = torch.empty((P,), dtype=torch.int32, device=DEV)
+    po, pc, to, tc, co = d(pred_off), d(pred_cnt), d(tgt_off), d(tgt_cnt), d(cost_off)
+    rc = _lib.lib().svol_lsap_batched(flat.data_ptr(), co.data_ptr(), po.data_ptr(), pc.data_ptr(), to.data_ptr(),
+                                      tc.data_ptr(), match.data_ptr(), status.data_ptr(), P,
+                                      int(max(pred_cnt.max(), tgt_cnt.max())), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, 'svol_lsap_batched')
+    m = match.cpu().numpy()
+    bad = 0
+    for i, c in enumerate(costs):
+        r, cc = linear_sum_assignment(c)
+        mm = m[pred_off[i]:pred_off[i] + pred_cnt[i]]
+        gr = np.nonzero(mm >= 0)[0]
+        gc = mm[gr] - tgt_off[i]
+        if gr.tolist() != r.tolist() or gc.tolist() != cc.tolist():
+            bad += 1
+    return {'lsap/mismatching_problems': (float(bad), 0.0), 'lsap/status_nonzero': (float(status.abs().max()), 0.0)}
+
+
+# ---------------------------------------------------------------------------
+def run_head_case(name, dtype):
+    """Full head + criterion forward/backward through the product modules; returns
+    (outputs dict, loss dict, total, model, criterion)."""
+    from svol_amd.modeling.loss import build_loss
+    from svol_amd.modeling.svanet import build_svanet
+    from tests.helpers import head_case
+    z, meta, args, sd, inp, tg = head_case(name)
+    args.compute_dtype = 'fp32' if dtype == torch.float32 else 'bf16'
+    model = build_svanet(args)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).eval()
+    crit = build_loss(args).to(DEV).eval()
+    out = model(inp['src_sketch'].to(DEV), inp['src_sketch_mask'].to(DEV), inp['src_video'].to(DEV),
+                inp['src_video_mask'].to(DEV))
+    ld = crit(out, tg)
+    wd = crit.weight_dict
+    tot = sum(ld[k] * wd[k] for k in ld.keys() if k in wd)
+    tot.backward()
+    return z, meta, args, out, ld, tot, model, crit
+
+
+def check_head_case(name, dtype):
+    from tests.helpers import unpack_indices
+    tol = 1e-3 if dtype == torch.float32 else 1e-2  # north_star: 1e-3 fp32 / 1e-2 bf16
+    res = {}
+    z, meta, args, out, ld, tot, model, crit = run_head_case(name, dtype)
+    tag = f'head/{name}/{"fp32" if dtype == torch.float32 else "bf16"}'
+    res[tag + '/pred_logits_abs'] = (float((out['pred_logits'].cpu() - torch.from_numpy(z['pred_logits'])).abs().max()), tol)
+    res[tag + '/pred_boxes_abs'] = (float((out['pred_boxes'].cpu() - torch.from_numpy(z['pred_boxes'])).abs().max()), tol)
+    if 'aux_logits' in z.files:
+        al = torch.stack([a['pred_logits'] for a in out['aux_outputs']]).cpu()
+        ab = torch.stack([a['pred_boxes'] for a in out['aux_outputs']]).cpu()
+        res[tag + '/aux_logits_abs'] = (float((al - torch.from_numpy(z['aux_logits'])).abs().max()), tol)
+        res[tag + '/aux_boxes_abs'] = (float((ab - torch.from_numpy(z['aux_boxes'])).abs().max()), tol)
+    names = str(z['loss_names']).split('\n')
+    idx_all = crit.last_indices()
+    nl = len(idx_all)
+    # the criterion stacks [aux0..aux(n-2), last]
+    tags = [f'aux{i}' for i in range(nl - 1)] + ['last']
+    mism = 0
+    for tg_, idx in zip(tags, idx_all):
+        ref = unpack_indices(z, 'idx/' + tg_)
+        for (p, t), (rp, rt) in zip(idx, ref):
+            if p.tolist() != rp.tolist() or t.tolist() != rt.tolist():
+                mism += 1
+    res[tag + '/assignment_mismatch_videos'] = (float(mism), 0.0)
+    if mism == 0:  # losses are only comparable when the (discrete) assignment agrees
+        for k, v in zip(names, z['loss_values']):
+            if 'class_error' in k:
+                continue
+            res[tag + '/' + k] = (abs(float(ld[k]) - v), tol * max(1.0, abs(v)))
+        res[tag + '/loss_total'] = (abs(float(tot) - float(z['loss_total'])), tol * max(1.0, abs(float(z['loss_total']))))
+        gtol = 2e-3 if dtype == torch.float32 else 6e-2
+        worst, worst_key = 0.0, ''
+        for k, p in model.named_parameters():
+            if f'gnone/{k}' in z.files:
+                continue
+            if f'g/{k}' in z.files:
+                ref = torch.from_numpy(z[f'g/{k}']).double()
+                got = p.grad.detach().double().cpu()
+            else:
+                flat = p.grad.detach().double().cpu().reshape(-1)
+                step = max(1, flat.numel() // 256)
+                got = flat[::step][:256]
+                ref = torch.from_numpy(z[f'gsample/{k}']).double()
+            e = float((got - ref).abs().max() / (ref.abs().max() + 1e-7))
+            if e > worst:
+                worst, worst_key = e, k
+        res[tag + f'/worst_param_grad_rel[{worst_key}]'] = (worst, gtol)
+    return res

@@ -1,0 +1,62 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): every HIP op, through the C-ABI, against
+fp64 torch math / the CPU oracle on identical inputs."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert(res):
+    bad = {k: v for k, v in res.items() if not (v[0] <= v[1])}
+    assert not bad, '\n'.join(f'{k}: err={e:.3e} tol={t:.1e}' for k, (e, t) in bad.items())
+
+
+@pytest.fixture(scope='module')
+def G():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from tests import gpu_checks
+    return gpu_checks
+
+
+def test_native_library_loaded():
+    from svol_amd import _lib
+    assert _lib.lib().svol_abi_version() == 1
+
+
+def test_gemm_nt(G):
+    _assert(G.check_gemm_nt())
+
+
+def test_gemm_tn(G):
+    _assert(G.check_gemm_tn())
+
+
+def test_small_ops(G):
+    _assert(G.check_small_ops())
+
+
+def test_layernorm_and_dropout(G):
+    _assert(G.check_layernorm())
+
+
+def test_posenc(G):
+    _assert(G.check_posenc())
+
+
+def test_attention_fwd_bwd(G):
+    _assert(G.check_attention())
+
+
+def test_gate_fwd_bwd(G):
+    _assert(G.check_gate())
+
+
+def test_lsap_bit_exact_vs_scipy(G):
+    _assert(G.check_lsap_vs_scipy())
+
+
+@pytest.mark.parametrize('name', ['crit_video_B8_N100_T32', 'crit_frame_B8_N320_T32', 'crit_frame_B3_N8_T4_over',
+                                  'crit_video_B2_N4_T4_tall'])
+def test_criterion_golden(G, name):
+    from tests.helpers import load_golden
+    _assert(G.check_criterion(*load_golden(name), name))
