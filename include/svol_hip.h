@@ -57,12 +57,14 @@ int svol_cast_transpose(const float* src, void* dst, void* dstT, int dtype, int6
  *   A2/n_split: output columns n >= n_split read their A operand from A2 instead of A
  *               (fused q/k-with-pos vs v-without-pos projection, cross_modal_transformer.py:137-138);
  *               pass A2=NULL, n_split=0 when unused.  n_split must be a multiple of 128.
- *   bias fp32 or NULL; residual (dtype, ld = ldr) or NULL; pre_act_out (dtype, ld = ldc) or NULL
- *   receives the pre-activation (saved for backward).  Replaces nn.Linear/F.relu/F.gelu:
+ *   bias fp32 or NULL; pre_act_out (dtype, ld = ldp) or NULL receives the pre-activation (saved
+ *   for backward); residual (ld = ldr) or NULL.  out_f32 != 0: C and residual are fp32 regardless of
+ *   dtype (the fp32 residual stream that feeds the post-norms).  Replaces nn.Linear/F.relu/F.gelu:
  *   svanet.py:174-181, cross_modal_transformer.py:163-179, svanet.py:144-156. */
 int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, const void* B, int64_t ldb,
-                 void* C, int64_t ldc, const float* bias, int act, void* pre_act_out, const void* residual,
-                 int64_t ldr, int64_t M, int64_t N, int64_t K, int dtype, void* stream);
+                 void* C, int64_t ldc, const float* bias, int act, void* pre_act_out, int64_t ldp,
+                 const void* residual, int64_t ldr, int out_f32, int64_t M, int64_t N, int64_t K, int dtype,
+                 void* stream);
 /* dW[N,K] (fp32, ld = ldc) (+)= A[Mc,N]^T * B[Mc,K]   (contraction over the Mc rows; weight gradient).
  * The output is accumulated with fp32 atomics: the caller zeroes C first unless it wants accumulation. */
 int svol_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t Mc,
@@ -72,17 +74,23 @@ int svol_colsum(const void* X, int64_t ldx, float* out, int64_t M, int64_t N, in
 /* dpre[i] = dy[i] * act'(aux[i]); aux = post-activation for RELU/SIGMOID, pre-activation for GELU. */
 int svol_act_bwd(const void* dy, const void* aux, void* dpre, int act, int64_t n, int dtype, void* stream);
 
-/* ---- LayerNorm (+ dropout, + positional add) ---------------------------- */
-/* y = dropout(LN(x) ; p, seed);  ypos = y + pos (optional; pos has `pos_rows` rows and is indexed
- * row % pos_rows so a [N,d] query embedding broadcasts over the batch).  mean/rstd fp32 [M] saved.
- * nn.LayerNorm + nn.Dropout of svanet.py:168-178; post-norms cross_modal_transformer.py:127-158. */
-int svol_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, void* ypos, const void* pos,
-                       int64_t pos_rows, float* mean, float* rstd, int64_t M, int64_t D, float dropout_p,
-                       uint64_t seed, int dtype, void* stream);
-/* dx = LN'(dy [+ dy2]) ; dgamma/dbeta (fp32) accumulated with atomics (caller zeroes). */
-int svol_layernorm_bwd(const void* dy, const void* dy2, const void* x, const float* gamma, const float* mean,
-                       const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t M, int64_t D,
+/* ---- LayerNorm (+ dropout, + positional add) ----------------------------
+ * The post-norm residual stream is kept in fp32 even when dtype is bf16 (x_f32 != 0: x is fp32);
+ * the kernel emits the fp32 value (y32, feeds the next residual add) and the compute-dtype copies the
+ * GEMMs consume (y, and ypos = y + pos).  Any of y32 / y may be NULL (not both); ypos/pos go together.
+ * pos has `pos_rows` rows and is indexed row % pos_rows so a [N,d] query embedding broadcasts over
+ * the batch.  Dropout (p, seed) is a stateless counter-based mask applied to LN's output.  mean/rstd
+ * fp32 [M] are saved for backward.  nn.LayerNorm + nn.Dropout of svanet.py:168-178; post-norms
+ * cross_modal_transformer.py:127-158. */
+int svol_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float* beta, float* y32, void* y,
+                       void* ypos, const void* pos, int64_t pos_rows, float* mean, float* rstd, int64_t M, int64_t D,
                        float dropout_p, uint64_t seed, int dtype, void* stream);
+/* dx = LN'(dy32 + dy + dy2) (each may be NULL, not all); outputs dx32 (fp32) and/or dx (dtype);
+ * dgamma/dbeta (fp32) accumulated with atomics (caller zeroes). */
+int svol_layernorm_bwd(const float* dy32, const void* dy, const void* dy2, const void* x, int x_f32,
+                       const float* gamma, const float* mean, const float* rstd, float* dx32, void* dx,
+                       float* dgamma, float* dbeta, int64_t M, int64_t D, float dropout_p, uint64_t seed, int dtype,
+                       void* stream);
 
 /* ---- sine positional encoding (position_encoding.py:51-71) -------------- */
 /* mask [B,L] float (1 = valid) -> pos [B,L,D] (dtype). */
@@ -109,16 +117,17 @@ int svol_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const 
  *   scores[b,h,l] = (x[b,l,:] + pos[b,l,:]) . u[b,h,:]
  *   a[b,l]        = mean_h softmax_l(scores[b,h,:])
  *   y             = LN1(x * (1 + a)) ;  ypos = y + pos
+ * x32 is the fp32 residual stream [B*L, D]; pos / y / ypos are `dtype`; y32 fp32 (may be NULL).
  * ws: fp32 workspace of B*H*(L+2) floats (scores, then per-(b,h) max and sum). */
-int svol_gate_fwd(const void* x, const void* pos, const float* u, const float* gamma, const float* beta, void* y,
-                  void* ypos, float* a, float* mean, float* rstd, float* ws, int64_t B, int64_t L, int64_t D,
-                  int64_t H, int dtype, void* stream);
-/* dy (+ dy2) -> dx, du (fp32, caller zeroes), dgamma/dbeta (fp32 atomics, caller zeroes).
- * ws: the forward's workspace (scores/max/sum); ws2: B*L + B*H fp32 scratch. */
-int svol_gate_bwd(const void* dy, const void* dy2, const void* x, const void* pos, const float* u,
-                  const float* gamma, const float* a, const float* mean, const float* rstd, const float* ws,
-                  float* ws2, void* dx, float* du, float* dgamma, float* dbeta, int64_t B, int64_t L, int64_t D,
-                  int64_t H, int dtype, void* stream);
+int svol_gate_fwd(const float* x32, const void* pos, const float* u, const float* gamma, const float* beta,
+                  float* y32, void* y, void* ypos, float* a, float* mean, float* rstd, float* ws, int64_t B,
+                  int64_t L, int64_t D, int64_t H, int dtype, void* stream);
+/* (dy32 + dy + dy2) -> dx32 (fp32), du (fp32, caller zeroes), dgamma/dbeta (fp32 atomics, caller
+ * zeroes).  ws: the forward's workspace (scores/max/sum); ws2: B*L + B*H fp32 scratch. */
+int svol_gate_bwd(const float* dy32, const void* dy, const void* dy2, const float* x32, const void* pos,
+                  const float* u, const float* gamma, const float* a, const float* mean, const float* rstd,
+                  const float* ws, float* ws2, float* dx32, float* du, float* dgamma, float* dbeta, int64_t B,
+                  int64_t L, int64_t D, int64_t H, int dtype, void* stream);
 
 /* ---- set matching + criterion (matcher.py:38-159, loss.py:39-157) -------
  * A "problem" is one LSAP block the reference solves with scipy: one video for
@@ -146,10 +155,15 @@ int svol_lsap_batched(const float* cost, const int64_t* cost_off, const int32_t*
  *                                 loss_giou (mean(1-GIoU) over matched; loss.py:96-102),
  *                                 class_error (100 - top1 acc on matched; loss.py:59)
  * and the unit gradients g_label[R,2] = d loss_label/d logits, g_bbox[R,4] = d loss_bbox/d boxes,
- * g_giou[R,4] = d loss_giou/d boxes (the backward pass scales them by the upstream loss weights). */
+ * g_giou[R,4] = d loss_giou/d boxes (the backward pass scales them by the upstream loss weights).
+ * rebase_vid_off (int32 [B], first global target row of each video) non-NULL reproduces
+ * PerFrameMatcher's target-id re-basing (matcher.py:114-115 + loss.py:87): the loss target of a matched
+ * query is row vid_off[b] + (match - min matched id of video b); rows_per_video = N.  NULL for
+ * HungarianMatcher. */
 int svol_set_loss(const float* logits, const float* boxes, const float* tgt_boxes, const int32_t* match,
                   float* losses, float* g_label, float* g_bbox, float* g_giou, int32_t n_layers,
-                  int32_t rows_per_layer, float eos_coef, void* stream);
+                  int32_t rows_per_layer, float eos_coef, const int32_t* rebase_vid_off, int32_t rows_per_video,
+                  void* stream);
 
 #ifdef __cplusplus
 }

@@ -235,19 +235,31 @@ __global__ __launch_bounds__(256) void set_loss_kernel(const float* __restrict__
                                                        const float* __restrict__ tgt, const int32_t* __restrict__ match,
                                                        float* __restrict__ losses, float* __restrict__ g_label,
                                                        float* __restrict__ g_bbox, float* __restrict__ g_giou, int rows,
-                                                       float eos) {
+                                                       float eos, const int32_t* __restrict__ vid_off, int rows_per_video) {
     __shared__ double red[4];
+    extern __shared__ int vmin[];  // per-video minimum matched target id (PerFrameMatcher re-basing quirk)
     const int layer = blockIdx.x;
     const int64_t base = (int64_t)layer * rows;
+    const int nvid = vid_off ? rows / rows_per_video : 0;
+    for (int b = threadIdx.x; b < nvid; b += 256) vmin[b] = 0x7fffffff;
+    __syncthreads();
     double cnt = 0.0;
-    for (int r = threadIdx.x; r < rows; r += 256) cnt += match[base + r] >= 0 ? 1.0 : 0.0;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        const int m = match[base + r];
+        cnt += m >= 0 ? 1.0 : 0.0;
+        if (vid_off && m >= 0) atomicMin(&vmin[r / rows_per_video], m);
+    }
     const double K = block_sum_d(cnt, red);
     const float invK = K > 0 ? (float)(1.0 / K) : 0.f;
     const float invR = 1.f / (float)rows;
     double s_nll = 0.0, s_l1 = 0.0, s_g = 0.0, s_ok = 0.0;
     for (int r = threadIdx.x; r < rows; r += 256) {
         const int64_t row = base + r;
-        const int m = match[row];
+        int m = match[row];
+        // matcher.py:114-115 hands the criterion target ids re-based by the smallest MATCHED id of the
+        // video; loss.py:87 then indexes the video's own box list with them.  Identical to the true
+        // target unless the video's first box is unmatched (a frame with more boxes than queries).
+        if (vid_off && m >= 0) { const int b = r / rows_per_video; m = vid_off[b] + (m - vmin[b]); }
         const float l0 = logits[row * 2], l1 = logits[row * 2 + 1];
         const float mx = fmaxf(l0, l1);
         const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
@@ -327,12 +339,18 @@ int svol_lsap_batched(const float* cost, const int64_t* cost_off, const int32_t*
 
 int svol_set_loss(const float* logits, const float* boxes, const float* tgt_boxes, const int32_t* match, float* losses,
                   float* g_label, float* g_bbox, float* g_giou, int32_t n_layers, int32_t rows_per_layer, float eos_coef,
-                  void* stream) {
+                  const int32_t* rebase_vid_off, int32_t rows_per_video, void* stream) {
     if (!logits || !boxes || !tgt_boxes || !match || !losses || !g_label || !g_bbox || !g_giou) return SVOL_E_INVALID;
     if (n_layers <= 0 || rows_per_layer <= 0) return SVOL_E_INVALID;
+    size_t lds = 0;
+    if (rebase_vid_off) {
+        if (rows_per_video <= 0 || rows_per_layer % rows_per_video) return SVOL_E_INVALID;
+        lds = sizeof(int) * (size_t)(rows_per_layer / rows_per_video);
+        if (lds > 32768) return SVOL_E_UNSUPPORTED;
+    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(set_loss_kernel, dim3((unsigned)n_layers), dim3(256), 0, s, logits, boxes, tgt_boxes, match, losses,
-                       g_label, g_bbox, g_giou, (int)rows_per_layer, eos_coef);
+    hipLaunchKernelGGL(set_loss_kernel, dim3((unsigned)n_layers), dim3(256), lds, s, logits, boxes, tgt_boxes, match, losses,
+                       g_label, g_bbox, g_giou, (int)rows_per_layer, eos_coef, rebase_vid_off, (int)rows_per_video);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }

@@ -15,7 +15,7 @@ constexpr int GH = 8;  // max heads
 
 // scores[b,hh,l] = (x+pos)[b,l,:] . u[b,hh,:]      grid = (ceil(L / (4*rpw)), B), one wave per row
 template <typename T, int NP>
-__global__ __launch_bounds__(256) void gate_scores_kernel(const T* __restrict__ x, const T* __restrict__ pos,
+__global__ __launch_bounds__(256) void gate_scores_kernel(const float* __restrict__ x, const T* __restrict__ pos,
                                                           const float* __restrict__ u, float* __restrict__ scores, int L,
                                                           int D, int H, int rpw) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void gate_scores_kernel(const T* __restrict__ 
         for (int j = 0; j < NP; ++j) {
             const int c = (lane + 64 * j) * 4;
             if (c < D) {
-                Vec4<T> xv, pv;
+                Vec4<float> xv;
+                Vec4<T> pv;
                 xv.load(x + row * D + c);
                 pv.load(pos + row * D + c);
 #pragma unroll
@@ -101,10 +102,11 @@ __global__ __launch_bounds__(256) void gate_bwd_stats_kernel(const float* __rest
 
 // a[b,l] = mean_h softmax ; s1 = x*(1+a) ; y = LN(s1) ; ypos = y + pos        one wave per row
 template <typename T>
-__global__ __launch_bounds__(256) void gate_apply_kernel(const T* __restrict__ x, const T* __restrict__ pos,
+__global__ __launch_bounds__(256) void gate_apply_kernel(const float* __restrict__ x, const T* __restrict__ pos,
                                                          const float* __restrict__ scores, const float* __restrict__ mx,
                                                          const float* __restrict__ sm, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, T* __restrict__ y,
+                                                         const float* __restrict__ beta, float* __restrict__ y32,
+                                                         T* __restrict__ y,
                                                          T* __restrict__ ypos, float* __restrict__ a_out,
                                                          float* __restrict__ mean, float* __restrict__ rstd, int L, int D,
                                                          int H, int64_t M) {
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void gate_apply_kernel(const T* __restrict__ x
     for (int j = 0; j < GP; ++j) {
         const int c = (lane + 64 * j) * 4;
         if (c < D) {
-            Vec4<T> t;
+            Vec4<float> t;
             t.load(x + row * D + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[j][e] = t.get(e) * (1.f + a); s += v[j][e]; }
@@ -150,14 +152,17 @@ __global__ __launch_bounds__(256) void gate_apply_kernel(const T* __restrict__ x
         const int c = (lane + 64 * j) * 4;
         if (c < D) {
             Vec4<T> o, op, pv;
+            Vec4<float> o32;
             pv.load(pos + row * D + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float r = (v[j][e] - mu) * rs * gamma[c + e] + beta[c + e];
                 o.set(e, r);
+                o32.set(e, r);
                 op.set(e, r + pv.get(e));
             }
-            o.store(y + row * D + c);
+            if (y32) o32.store(y32 + row * D + c);
+            if (y) o.store(y + row * D + c);
             if (ypos) op.store(ypos + row * D + c);
         }
     }
@@ -165,10 +170,11 @@ __global__ __launch_bounds__(256) void gate_apply_kernel(const T* __restrict__ x
 
 // backward pass 1: LN1 backward, dx_part = ds1*(1+a), da[row] = sum_d ds1*x ; dgamma/dbeta atomics
 template <typename T>
-__global__ __launch_bounds__(256) void gate_bwd_ln_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
-                                                          const T* __restrict__ x, const float* __restrict__ a_in,
+__global__ __launch_bounds__(256) void gate_bwd_ln_kernel(const float* __restrict__ dy32, const T* __restrict__ dy,
+                                                          const T* __restrict__ dy2, const float* __restrict__ x,
+                                                          const float* __restrict__ a_in,
                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                          const float* __restrict__ rstd, T* __restrict__ dx,
+                                                          const float* __restrict__ rstd, float* __restrict__ dx,
                                                           float* __restrict__ da, float* __restrict__ dgamma,
                                                           float* __restrict__ dbeta, int64_t M, int D, int rpw) {
     const int lane = threadIdx.x & 63;
@@ -186,13 +192,15 @@ __global__ __launch_bounds__(256) void gate_bwd_ln_kernel(const T* __restrict__ 
         for (int j = 0; j < GP; ++j) {
             const int c = (lane + 64 * j) * 4;
             if (c < D) {
-                Vec4<T> p, p2, xv;
-                p.load(dy + row * D + c);
+                Vec4<T> p, p2;
+                Vec4<float> p32, xv;
+                if (dy32) p32.load(dy32 + row * D + c);
+                if (dy) p.load(dy + row * D + c);
                 if (dy2) p2.load(dy2 + row * D + c);
                 xv.load(x + row * D + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float d = p.get(e) + (dy2 ? p2.get(e) : 0.f);
+                    const float d = (dy32 ? p32.get(e) : 0.f) + (dy ? p.get(e) : 0.f) + (dy2 ? p2.get(e) : 0.f);
                     xs[j][e] = xv.get(e);
                     const float hv = (xs[j][e] * (1.f + a) - mu) * rs;
                     xh[j][e] = hv;
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(256) void gate_bwd_ln_kernel(const T* __restrict__ 
         for (int j = 0; j < GP; ++j) {
             const int c = (lane + 64 * j) * 4;
             if (c < D) {
-                Vec4<T> o;
+                Vec4<float> o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float ds = rs * (g[j][e] - s1 - xh[j][e] * s2);
@@ -240,11 +248,11 @@ __global__ __launch_bounds__(256) void gate_bwd_ln_kernel(const T* __restrict__ 
 
 // backward pass 3: dscore[hh] = p_hh[l] * (da[l]/H - c[b,hh]) ; dx += sum_hh dscore*u ; du += dscore*(x+pos)
 template <typename T, int NP>
-__global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ pos,
+__global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const float* __restrict__ x, const T* __restrict__ pos,
                                                              const float* __restrict__ u, const float* __restrict__ scores,
                                                              const float* __restrict__ mx, const float* __restrict__ sm,
                                                              const float* __restrict__ da, const float* __restrict__ cc,
-                                                             T* __restrict__ dx, float* __restrict__ du, int L, int D,
+                                                             float* __restrict__ dx, float* __restrict__ du, int L, int D,
                                                              int H, int rpw) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
@@ -277,7 +285,8 @@ __global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const T* __restrict
         for (int j = 0; j < NP; ++j) {
             const int c = (lane + 64 * j) * 4;
             if (c < D) {
-                Vec4<T> xv, pv, dv;
+                Vec4<float> xv, dv;
+                Vec4<T> pv;
                 xv.load(x + row * D + c);
                 pv.load(pos + row * D + c);
                 dv.load(dx + row * D + c);
@@ -317,10 +326,10 @@ int rows_per_wave(int64_t rows, int64_t target_waves) {
 
 extern "C" {
 
-int svol_gate_fwd(const void* x, const void* pos, const float* u, const float* gamma, const float* beta, void* y,
-                  void* ypos, float* a, float* mean, float* rstd, float* ws, int64_t B, int64_t L, int64_t D, int64_t H,
+int svol_gate_fwd(const float* x32, const void* pos, const float* u, const float* gamma, const float* beta, float* y32,
+                  void* y, void* ypos, float* a, float* mean, float* rstd, float* ws, int64_t B, int64_t L, int64_t D, int64_t H,
                   int dtype, void* stream) {
-    if (!x || !pos || !u || !gamma || !beta || !y || !a || !mean || !rstd || !ws) return SVOL_E_INVALID;
+    if (!x32 || !pos || !u || !gamma || !beta || (!y && !y32) || !a || !mean || !rstd || !ws) return SVOL_E_INVALID;
     if (B <= 0 || L <= 0 || D <= 0 || H <= 0) return SVOL_E_INVALID;
     if (D % 4 || D > GP * 256 || H > GH || B > 65535 || L > (1 << 24)) return SVOL_E_UNSUPPORTED;
     if (dtype != SVOL_BF16 && dtype != SVOL_F32) return SVOL_E_INVALID;
@@ -333,29 +342,28 @@ int svol_gate_fwd(const void* x, const void* pos, const float* u, const float* g
     dim3 g1((unsigned)((L + 4 * rpw - 1) / (4 * rpw)), (unsigned)B);
     const int64_t M = B * L;
     const unsigned g3 = (unsigned)((M + 3) / 4);
-    if (dtype == SVOL_BF16) {
-        if (np_ == 1) hipLaunchKernelGGL((gate_scores_kernel<bf16_t, 1>), g1, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)pos, u, scores, (int)L, (int)D, (int)H, rpw);
-        else if (np_ == 2) hipLaunchKernelGGL((gate_scores_kernel<bf16_t, 2>), g1, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)pos, u, scores, (int)L, (int)D, (int)H, rpw);
-        else hipLaunchKernelGGL((gate_scores_kernel<bf16_t, 4>), g1, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)pos, u, scores, (int)L, (int)D, (int)H, rpw);
-        hipLaunchKernelGGL(gate_stats_kernel, dim3((unsigned)(B * H)), dim3(256), 0, s, scores, mx, sm, (int)L);
-        hipLaunchKernelGGL(gate_apply_kernel<bf16_t>, dim3(g3), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)pos, scores,
-                           mx, sm, gamma, beta, (bf16_t*)y, (bf16_t*)ypos, a, mean, rstd, (int)L, (int)D, (int)H, M);
-    } else {
-        if (np_ == 1) hipLaunchKernelGGL((gate_scores_kernel<float, 1>), g1, dim3(256), 0, s, (const float*)x, (const float*)pos, u, scores, (int)L, (int)D, (int)H, rpw);
-        else if (np_ == 2) hipLaunchKernelGGL((gate_scores_kernel<float, 2>), g1, dim3(256), 0, s, (const float*)x, (const float*)pos, u, scores, (int)L, (int)D, (int)H, rpw);
-        else hipLaunchKernelGGL((gate_scores_kernel<float, 4>), g1, dim3(256), 0, s, (const float*)x, (const float*)pos, u, scores, (int)L, (int)D, (int)H, rpw);
-        hipLaunchKernelGGL(gate_stats_kernel, dim3((unsigned)(B * H)), dim3(256), 0, s, scores, mx, sm, (int)L);
-        hipLaunchKernelGGL(gate_apply_kernel<float>, dim3(g3), dim3(256), 0, s, (const float*)x, (const float*)pos, scores,
-                           mx, sm, gamma, beta, (float*)y, (float*)ypos, a, mean, rstd, (int)L, (int)D, (int)H, M);
-    }
+#define SVOL_GATE_FWD(TT)                                                                                                   \
+    do {                                                                                                                    \
+        if (np_ == 1) hipLaunchKernelGGL((gate_scores_kernel<TT, 1>), g1, dim3(256), 0, s, x32, (const TT*)pos, u, scores, (int)L, (int)D, (int)H, rpw); \
+        else if (np_ == 2) hipLaunchKernelGGL((gate_scores_kernel<TT, 2>), g1, dim3(256), 0, s, x32, (const TT*)pos, u, scores, (int)L, (int)D, (int)H, rpw); \
+        else hipLaunchKernelGGL((gate_scores_kernel<TT, 4>), g1, dim3(256), 0, s, x32, (const TT*)pos, u, scores, (int)L, (int)D, (int)H, rpw); \
+        hipLaunchKernelGGL(gate_stats_kernel, dim3((unsigned)(B * H)), dim3(256), 0, s, scores, mx, sm, (int)L);            \
+        hipLaunchKernelGGL(gate_apply_kernel<TT>, dim3(g3), dim3(256), 0, s, x32, (const TT*)pos, scores, mx, sm, gamma, beta, \
+                           y32, (TT*)y, (TT*)ypos, a, mean, rstd, (int)L, (int)D, (int)H, M);                               \
+    } while (0)
+    if (dtype == SVOL_BF16) SVOL_GATE_FWD(bf16_t);
+    else SVOL_GATE_FWD(float);
+#undef SVOL_GATE_FWD
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }
 
-int svol_gate_bwd(const void* dy, const void* dy2, const void* x, const void* pos, const float* u, const float* gamma,
-                  const float* a, const float* mean, const float* rstd, const float* ws, float* ws2, void* dx, float* du,
-                  float* dgamma, float* dbeta, int64_t B, int64_t L, int64_t D, int64_t H, int dtype, void* stream) {
-    if (!dy || !x || !pos || !u || !gamma || !a || !mean || !rstd || !ws || !ws2 || !dx || !du || !dgamma || !dbeta)
+int svol_gate_bwd(const float* dy32, const void* dy, const void* dy2, const float* x32, const void* pos, const float* u,
+                  const float* gamma, const float* a, const float* mean, const float* rstd, const float* ws, float* ws2,
+                  float* dx32, float* du, float* dgamma, float* dbeta, int64_t B, int64_t L, int64_t D, int64_t H, int dtype,
+                  void* stream) {
+    if ((!dy32 && !dy && !dy2) || !x32 || !pos || !u || !gamma || !a || !mean || !rstd || !ws || !ws2 || !dx32 || !du ||
+        !dgamma || !dbeta)
         return SVOL_E_INVALID;
     if (B <= 0 || L <= 0 || D <= 0 || H <= 0) return SVOL_E_INVALID;
     if (D % 4 || D > GP * 256 || H > GH || B > 65535 || L > (1 << 24)) return SVOL_E_UNSUPPORTED;
@@ -372,23 +380,19 @@ int svol_gate_bwd(const void* dy, const void* dy2, const void* x, const void* po
     const unsigned g1 = (unsigned)(((M + rpw1 - 1) / rpw1 + 3) / 4);
     const int rpw3 = rows_per_wave(L, 2048 / (B > 2048 ? 2048 : B) + 1);
     dim3 g3((unsigned)((L + 4 * rpw3 - 1) / (4 * rpw3)), (unsigned)B);
-    if (dtype == SVOL_BF16) {
-        hipLaunchKernelGGL(gate_bwd_ln_kernel<bf16_t>, dim3(g1), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)dy2,
-                           (const bf16_t*)x, a, gamma, mean, rstd, (bf16_t*)dx, da, dgamma, dbeta, M, (int)D, rpw1);
-        hipLaunchKernelGGL(gate_bwd_stats_kernel, dim3((unsigned)(B * H)), dim3(256), 0, s, scores, mx, sm, da, cc, (int)L,
-                           (int)H);
-        if (np_ == 1) hipLaunchKernelGGL((gate_bwd_apply_kernel<bf16_t, 1>), g3, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)pos, u, scores, mx, sm, da, cc, (bf16_t*)dx, du, (int)L, (int)D, (int)H, rpw3);
-        else if (np_ == 2) hipLaunchKernelGGL((gate_bwd_apply_kernel<bf16_t, 2>), g3, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)pos, u, scores, mx, sm, da, cc, (bf16_t*)dx, du, (int)L, (int)D, (int)H, rpw3);
-        else hipLaunchKernelGGL((gate_bwd_apply_kernel<bf16_t, 4>), g3, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)pos, u, scores, mx, sm, da, cc, (bf16_t*)dx, du, (int)L, (int)D, (int)H, rpw3);
-    } else {
-        hipLaunchKernelGGL(gate_bwd_ln_kernel<float>, dim3(g1), dim3(256), 0, s, (const float*)dy, (const float*)dy2,
-                           (const float*)x, a, gamma, mean, rstd, (float*)dx, da, dgamma, dbeta, M, (int)D, rpw1);
-        hipLaunchKernelGGL(gate_bwd_stats_kernel, dim3((unsigned)(B * H)), dim3(256), 0, s, scores, mx, sm, da, cc, (int)L,
-                           (int)H);
-        if (np_ == 1) hipLaunchKernelGGL((gate_bwd_apply_kernel<float, 1>), g3, dim3(256), 0, s, (const float*)x, (const float*)pos, u, scores, mx, sm, da, cc, (float*)dx, du, (int)L, (int)D, (int)H, rpw3);
-        else if (np_ == 2) hipLaunchKernelGGL((gate_bwd_apply_kernel<float, 2>), g3, dim3(256), 0, s, (const float*)x, (const float*)pos, u, scores, mx, sm, da, cc, (float*)dx, du, (int)L, (int)D, (int)H, rpw3);
-        else hipLaunchKernelGGL((gate_bwd_apply_kernel<float, 4>), g3, dim3(256), 0, s, (const float*)x, (const float*)pos, u, scores, mx, sm, da, cc, (float*)dx, du, (int)L, (int)D, (int)H, rpw3);
-    }
+#define SVOL_GATE_BWD(TT)                                                                                                   \
+    do {                                                                                                                    \
+        hipLaunchKernelGGL(gate_bwd_ln_kernel<TT>, dim3(g1), dim3(256), 0, s, dy32, (const TT*)dy, (const TT*)dy2, x32, a,  \
+                           gamma, mean, rstd, dx32, da, dgamma, dbeta, M, (int)D, rpw1);                                    \
+        hipLaunchKernelGGL(gate_bwd_stats_kernel, dim3((unsigned)(B * H)), dim3(256), 0, s, scores, mx, sm, da, cc, (int)L, \
+                           (int)H);                                                                                         \
+        if (np_ == 1) hipLaunchKernelGGL((gate_bwd_apply_kernel<TT, 1>), g3, dim3(256), 0, s, x32, (const TT*)pos, u, scores, mx, sm, da, cc, dx32, du, (int)L, (int)D, (int)H, rpw3); \
+        else if (np_ == 2) hipLaunchKernelGGL((gate_bwd_apply_kernel<TT, 2>), g3, dim3(256), 0, s, x32, (const TT*)pos, u, scores, mx, sm, da, cc, dx32, du, (int)L, (int)D, (int)H, rpw3); \
+        else hipLaunchKernelGGL((gate_bwd_apply_kernel<TT, 4>), g3, dim3(256), 0, s, x32, (const TT*)pos, u, scores, mx, sm, da, cc, dx32, du, (int)L, (int)D, (int)H, rpw3); \
+    } while (0)
+    if (dtype == SVOL_BF16) SVOL_GATE_BWD(bf16_t);
+    else SVOL_GATE_BWD(float);
+#undef SVOL_GATE_BWD
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }

@@ -33,11 +33,12 @@ __device__ __forceinline__ void mma_chunk(f32x4& acc, const uint4& a, const uint
 struct NtArgs {
     const void* A; const void* A2; const void* B; void* C;
     const float* bias; void* pre; const void* res;
-    int64_t lda, ldb, ldc, ldr, n_split;
+    int64_t lda, ldb, ldc, ldr, ldp, n_split;
     int M, N, K, act;
 };
 
-template <typename T>
+// TC = element type of C and of the residual (T, or float for the fp32 residual stream)
+template <typename T, typename TC>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs p) {
     constexpr int EPC = Tr<T>::EPC;
     constexpr int BK = 8 * EPC;
@@ -105,9 +106,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs p) {
     }
 
     // epilogue: acc[mt][nt][r] -> C[m0 + mt*16 + fq*4 + r][n0 + nt*16 + fr]
-    T* C = reinterpret_cast<T*>(p.C);
+    TC* C = reinterpret_cast<TC*>(p.C);
     T* pre = reinterpret_cast<T*>(p.pre);
-    const T* res = reinterpret_cast<const T*>(p.res);
+    const TC* res = reinterpret_cast<const TC*>(p.res);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
@@ -120,12 +121,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs p) {
                 const int m = bm + wm * 64 + mt * 16 + fq * 4 + r;
                 if (m >= p.M) continue;
                 float v = acc[mt][nt][r] + bv;
-                if (pre) pre[(int64_t)m * p.ldc + n] = from_f32<T>(v);
+                if (pre) pre[(int64_t)m * p.ldp + n] = from_f32<T>(v);
                 if (p.act == SVOL_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (p.act == SVOL_ACT_GELU) v = gelu_f(v);
                 else if (p.act == SVOL_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
                 if (res) v += to_f32(res[(int64_t)m * p.ldr + n]);
-                C[(int64_t)m * p.ldc + n] = from_f32<T>(v);
+                C[(int64_t)m * p.ldc + n] = from_f32<TC>(v);
             }
         }
     }
@@ -341,8 +342,8 @@ const char* svol_strerror(int code) {
 }
 
 int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, const void* B, int64_t ldb, void* C,
-                 int64_t ldc, const float* bias, int act, void* pre_act_out, const void* residual, int64_t ldr,
-                 int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
+                 int64_t ldc, const float* bias, int act, void* pre_act_out, int64_t ldp, const void* residual,
+                 int64_t ldr, int out_f32, int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
     if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return SVOL_E_INVALID;
     if (M == 0 || N == 0) return SVOL_OK;
     const int epc = dtype == SVOL_BF16 ? 8 : 4;
@@ -351,12 +352,16 @@ int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, co
     if (!aligned16(A) || !aligned16(B) || (A2 && !aligned16(A2))) return SVOL_E_INVALID;
     if (A2 && (n_split % 128)) return SVOL_E_UNSUPPORTED;
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return SVOL_E_UNSUPPORTED;
-    NtArgs p{A, A2, B, C, bias, pre_act_out, residual, lda, ldb, ldc, ldr, n_split, (int)M, (int)N, (int)K, act};
+    NtArgs p{A, A2, B, C, bias, pre_act_out, residual, lda, ldb, ldc, ldr, ldp, n_split, (int)M, (int)N, (int)K, act};
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
     if (grid.y > 65535u) return SVOL_E_UNSUPPORTED;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == SVOL_BF16) hipLaunchKernelGGL(gemm_nt_kernel<bf16_t>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, dim3(256), 0, s, p);
+    if (dtype == SVOL_BF16) {
+        if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, p);
+    } else {
+        hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, dim3(256), 0, s, p);
+    }
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }

@@ -7,23 +7,25 @@ namespace {
 
 constexpr int LN_MAX_PASSES = 4;  // D <= 4 * 64 * 4 = 1024
 
-template <typename T>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, T* __restrict__ y,
-                                                     T* __restrict__ ypos, const T* __restrict__ pos, int64_t pos_rows,
-                                                     float* __restrict__ mean, float* __restrict__ rstd, int64_t M,
-                                                     int D, float p, float inv_keep, uint64_t seed) {
+// T  = element type of the compute-dtype outputs / gradients, TX = element type of the LN input
+// (float when the input is the fp32 residual stream).
+template <typename T, typename TX>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y32,
+                                                     T* __restrict__ y, T* __restrict__ ypos, const T* __restrict__ pos,
+                                                     int64_t pos_rows, float* __restrict__ mean, float* __restrict__ rstd,
+                                                     int64_t M, int D, float p, float inv_keep, uint64_t seed) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const T* xr = x + row * D;
+    const TX* xr = x + row * D;
     float v[LN_MAX_PASSES][4];
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < LN_MAX_PASSES; ++j) {
         const int c = (lane + 64 * j) * 4;
         if (c < D) {
-            Vec4<T> t; t.load(xr + c);
+            Vec4<TX> t; t.load(xr + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[j][e] = t.get(e); s += v[j][e]; }
         } else {
@@ -49,25 +51,29 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         const int c = (lane + 64 * j) * 4;
         if (c < D) {
             Vec4<T> o, op, pv;
+            Vec4<float> o32;
             if (pr) pv.load(pr + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float r = (v[j][e] - mu) * rs * gamma[c + e] + beta[c + e];
                 if (p > 0.f) r *= dropout_scale(seed, (uint64_t)(row * D + c + e), p, inv_keep);
                 o.set(e, r);
+                o32.set(e, r);
                 if (pr) op.set(e, r + pv.get(e));
             }
-            o.store(y + row * D + c);
+            if (y32) o32.store(y32 + row * D + c);
+            if (y) o.store(y + row * D + c);
             if (ypos) op.store(ypos + row * D + c);
         }
     }
 }
 
-// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy_total * gamma (dropout mask applied first)
-template <typename T>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
-                                                     const T* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = (dy32 + dy + dypos) * gamma (dropout mask applied first)
+template <typename T, typename TX>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy32, const T* __restrict__ dy,
+                                                     const T* __restrict__ dy2, const TX* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, float* __restrict__ dx32,
                                                      T* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int64_t M, int D, float p,
                                                      float inv_keep, uint64_t seed, int rows_per_wave) {
@@ -88,13 +94,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         for (int j = 0; j < LN_MAX_PASSES; ++j) {
             const int c = (lane + 64 * j) * 4;
             if (c < D) {
-                Vec4<T> a, b, xv;
-                a.load(dy + row * D + c);
+                Vec4<T> a, b;
+                Vec4<float> a32;
+                Vec4<TX> xv;
+                if (dy32) a32.load(dy32 + row * D + c);
+                if (dy) a.load(dy + row * D + c);
                 if (dy2) b.load(dy2 + row * D + c);
                 xv.load(x + row * D + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float d = a.get(e) + (dy2 ? b.get(e) : 0.f);
+                    float d = (dy32 ? a32.get(e) : 0.f) + (dy ? a.get(e) : 0.f) + (dy2 ? b.get(e) : 0.f);
                     if (p > 0.f) d *= dropout_scale(seed, (uint64_t)(row * D + c + e), p, inv_keep);
                     const float h = (xv.get(e) - mu) * rs;
                     xh[j][e] = h;
@@ -114,9 +123,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             const int c = (lane + 64 * j) * 4;
             if (c < D) {
                 Vec4<T> o;
+                Vec4<float> o32;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o.set(e, rs * (g[j][e] - s1 - xh[j][e] * s2));
-                o.store(dx + row * D + c);
+                for (int e = 0; e < 4; ++e) {
+                    const float r = rs * (g[j][e] - s1 - xh[j][e] * s2);
+                    o.set(e, r);
+                    o32.set(e, r);
+                }
+                if (dx32) o32.store(dx32 + row * D + c);
+                if (dx) o.store(dx + row * D + c);
             }
         }
     }
@@ -175,35 +190,40 @@ __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ m
 
 extern "C" {
 
-int svol_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, void* ypos, const void* pos,
-                       int64_t pos_rows, float* mean, float* rstd, int64_t M, int64_t D, float dropout_p,
-                       uint64_t seed, int dtype, void* stream) {
-    if (!x || !gamma || !beta || !y || !mean || !rstd || M < 0 || D <= 0) return SVOL_E_INVALID;
+int svol_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float* beta, float* y32, void* y,
+                       void* ypos, const void* pos, int64_t pos_rows, float* mean, float* rstd, int64_t M, int64_t D,
+                       float dropout_p, uint64_t seed, int dtype, void* stream) {
+    if (!x || !gamma || !beta || (!y && !y32) || !mean || !rstd || M < 0 || D <= 0) return SVOL_E_INVALID;
     if ((ypos != nullptr) != (pos != nullptr)) return SVOL_E_INVALID;
     if (pos && pos_rows <= 0) return SVOL_E_INVALID;
     if (D % 4 || D > LN_MAX_PASSES * 256) return SVOL_E_UNSUPPORTED;
     if (dropout_p < 0.f || dropout_p >= 1.f) return SVOL_E_INVALID;
+    if (dtype != SVOL_BF16 && dtype != SVOL_F32) return SVOL_E_INVALID;
     if (M == 0) return SVOL_OK;
     const float inv_keep = 1.f / (1.f - dropout_p);
     const unsigned grid = (unsigned)((M + 3) / 4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == SVOL_BF16)
-        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y,
-                           (bf16_t*)ypos, (const bf16_t*)pos, pos_rows, mean, rstd, M, (int)D, dropout_p, inv_keep, seed);
-    else if (dtype == SVOL_F32)
-        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y,
-                           (float*)ypos, (const float*)pos, pos_rows, mean, rstd, M, (int)D, dropout_p, inv_keep, seed);
-    else return SVOL_E_INVALID;
+    if (dtype == SVOL_BF16 && x_f32)
+        hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, (const float*)x, gamma, beta, y32,
+                           (bf16_t*)y, (bf16_t*)ypos, (const bf16_t*)pos, pos_rows, mean, rstd, M, (int)D, dropout_p, inv_keep, seed);
+    else if (dtype == SVOL_BF16)
+        hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, y32,
+                           (bf16_t*)y, (bf16_t*)ypos, (const bf16_t*)pos, pos_rows, mean, rstd, M, (int)D, dropout_p, inv_keep, seed);
+    else
+        hipLaunchKernelGGL((ln_fwd_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)x, gamma, beta, y32,
+                           (float*)y, (float*)ypos, (const float*)pos, pos_rows, mean, rstd, M, (int)D, dropout_p, inv_keep, seed);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }
 
-int svol_layernorm_bwd(const void* dy, const void* dy2, const void* x, const float* gamma, const float* mean,
-                       const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t M, int64_t D, float dropout_p,
-                       uint64_t seed, int dtype, void* stream) {
-    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || M < 0 || D <= 0) return SVOL_E_INVALID;
+int svol_layernorm_bwd(const float* dy32, const void* dy, const void* dy2, const void* x, int x_f32, const float* gamma,
+                       const float* mean, const float* rstd, float* dx32, void* dx, float* dgamma, float* dbeta, int64_t M,
+                       int64_t D, float dropout_p, uint64_t seed, int dtype, void* stream) {
+    if ((!dy32 && !dy && !dy2) || !x || !gamma || !mean || !rstd || (!dx && !dx32) || !dgamma || !dbeta || M < 0 || D <= 0)
+        return SVOL_E_INVALID;
     if (D % 4 || D > LN_MAX_PASSES * 256) return SVOL_E_UNSUPPORTED;
     if (dropout_p < 0.f || dropout_p >= 1.f) return SVOL_E_INVALID;
+    if (dtype != SVOL_BF16 && dtype != SVOL_F32) return SVOL_E_INVALID;
     if (M == 0) return SVOL_OK;
     const float inv_keep = 1.f / (1.f - dropout_p);
     // ~4096 waves; each wave walks `rpw` consecutive rows and issues one set of atomics
@@ -212,15 +232,15 @@ int svol_layernorm_bwd(const void* dy, const void* dy2, const void* x, const flo
     const int64_t waves = (M + rpw - 1) / rpw;
     const unsigned grid = (unsigned)((waves + 3) / 4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == SVOL_BF16)
-        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)dy2,
-                           (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, dgamma, dbeta, M, (int)D, dropout_p, inv_keep,
-                           seed, (int)rpw);
-    else if (dtype == SVOL_F32)
-        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)dy2,
-                           (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, M, (int)D, dropout_p, inv_keep,
-                           seed, (int)rpw);
-    else return SVOL_E_INVALID;
+    if (dtype == SVOL_BF16 && x_f32)
+        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, dy32, (const bf16_t*)dy, (const bf16_t*)dy2,
+                           (const float*)x, gamma, mean, rstd, dx32, (bf16_t*)dx, dgamma, dbeta, M, (int)D, dropout_p, inv_keep, seed, (int)rpw);
+    else if (dtype == SVOL_BF16)
+        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, dy32, (const bf16_t*)dy, (const bf16_t*)dy2,
+                           (const bf16_t*)x, gamma, mean, rstd, dx32, (bf16_t*)dx, dgamma, dbeta, M, (int)D, dropout_p, inv_keep, seed, (int)rpw);
+    else
+        hipLaunchKernelGGL((ln_bwd_kernel<float, float>), dim3(grid), dim3(256), 0, s, dy32, (const float*)dy, (const float*)dy2,
+                           (const float*)x, gamma, mean, rstd, dx32, (float*)dx, dgamma, dbeta, M, (int)D, dropout_p, inv_keep, seed, (int)rpw);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }

@@ -8,12 +8,15 @@ purely as PARAMETER CONTAINERS: their ``forward`` is never called.  All
 arithmetic goes through ``svol_amd.ops`` (hand-written HIP behind the C-ABI):
 
   per layer (reference :105-160)
-    gate        : GateFn       (folded 1-query attention + x*(1+a) + LN1, one fused op)
-    video SA    : AttnResFn    (packed QKV GEMMs, flash attention, out_proj + residual)   + LN2
-    MLP1        : MLPResFn     (fc1+GELU, fc2 + residual)                                 + LN3 (+pos)
-    query SA    : AttnResFn                                                               + LN4 (+query_pos)
-    cross-attn  : AttnResFn    (key_padding_mask as additive bias)                        + LN5
-    MLP2        : MLPResFn                                                                + LN6 (+query_pos)
+    gate        : GateFn    (folded 1-query attention + x*(1+a) + LN1, one fused op)
+    video SA    : AttnLNFn  (packed QKV GEMMs, flash attention, out_proj + residual, LN2)
+    MLP1        : MLPLNFn   (fc1+GELU, fc2 + residual, LN3 (+pos))
+    query SA    : AttnLNFn  (... LN4 (+query_pos))
+    cross-attn  : AttnLNFn  (key_padding_mask as additive bias, LN5)
+    MLP2        : MLPLNFn   (... LN6 (+query_pos))
+
+The post-norm residual stream (every LN input and output) is carried in fp32 even in bf16 mode;
+each block also emits the bf16 copies (x, x + pos) that feed the MFMA GEMMs.
 
 The [B,L,L] attention-weight stacks the reference returns (never consumed by
 SVANet.forward, svanet.py:91) are not materialised.
@@ -31,13 +34,13 @@ D_FF = 2048  # the reference hard-codes dim_feedforward=2048 here and ignores --
 
 
 class MLP(nn.Module):
+    """fc1 / fc2 parameter container (reference MLP, :163-179); the arithmetic is fused with the
+    residual add and the following post-norm in ``ops.mlp_ln``."""
+
     def __init__(self, in_features, hidden_features):
         super().__init__()
         self.fc1 = nn.Linear(in_features, hidden_features)
         self.fc2 = nn.Linear(hidden_features, in_features)
-
-    def forward(self, x):  # x + fc2(gelu(fc1(x)))  (the residual is fused here)
-        return ops.mlp_res(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
 
 
 class CrossModalTransformerLayer(nn.Module):
@@ -68,24 +71,23 @@ class CrossModalTransformerLayer(nn.Module):
         wk = m.in_proj_weight[d:2 * d].view(h, dh, d)
         return torch.einsum('bhe,hed->bhd', q.view(-1, h, dh), wk) * (dh ** -0.5)
 
-    def forward(self, mem, skch32, out, outpos, pos, qpos, kbias):
+    def forward(self, mem32, skch32, out, pos, qpos, kbias):
+        """mem32: fp32 video stream [B,L,d]; out = (out32, out, out + query_pos) query stream triple."""
         h = self.nhead
-        u = self.gate_vectors(skch32)
-        mem1, mem1pos = ops.gate(mem, pos, u, self.norm1.weight, self.norm1.bias, h)
-        a = self.content_self_attn
-        s = ops.self_attn_res(mem1pos, mem1, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, h)
-        mem2 = ops.layer_norm(s, self.norm2.weight, self.norm2.bias)
-        mem3, mem3pos = ops.layer_norm(self.mlp1(mem2), self.norm3.weight, self.norm3.bias, pos=pos)
-
-        a = self.token_self_attn
-        s = ops.self_attn_res(outpos, out, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, h)
-        out4, out4pos = ops.layer_norm(s, self.norm4.weight, self.norm4.bias, pos=qpos)
-        a = self.content_token_cross_attn
-        s = ops.cross_attn_res(out4pos, out4, mem3pos, mem3, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight,
-                               a.out_proj.bias, h, kbias)
-        out5 = ops.layer_norm(s, self.norm5.weight, self.norm5.bias)
-        out6, out6pos = ops.layer_norm(self.mlp2(out5), self.norm6.weight, self.norm6.bias, pos=qpos)
-        return mem3, out6, out6pos
+        n = lambda m: (m.weight, m.bias)
+        mha = lambda m: (m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias)
+        mlp = lambda m: (m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
+        # video ("encoder-like") half, :122-143
+        m32, m, mpos = ops.gate(mem32, pos, self.gate_vectors(skch32), *n(self.norm1), h)
+        m32, m = ops.self_attn_ln(m32, m, mpos, *mha(self.content_self_attn), *n(self.norm2), None, h)
+        m32, m, mpos = ops.mlp_ln(m32, m, *mlp(self.mlp1), *n(self.norm3), pos)
+        # query ("decoder-like") half, :145-158
+        o32, o, opos = out
+        o32, o, opos = ops.self_attn_ln(o32, o, opos, *mha(self.token_self_attn), *n(self.norm4), qpos, h)
+        o32, o = ops.cross_attn_ln(o32, o, opos, mpos, m, *mha(self.content_token_cross_attn), *n(self.norm5), None, h,
+                                   kbias)
+        out = ops.mlp_ln(o32, o, *mlp(self.mlp2), *n(self.norm6), qpos)
+        return m32, out
 
 
 class CrossModalTransformer(nn.Module):
@@ -98,20 +100,22 @@ class CrossModalTransformer(nn.Module):
                 nn.init.xavier_uniform_(p)
         self.d_model, self.nhead, self.num_layers = d_model, nhead, num_layers
 
-    def forward(self, src_vid, src_skch, kbias, vid_pos, query_embed):
-        """src_vid [B,L,d] (compute dtype), src_skch [B,1,d], kbias [B,L] fp32 additive key mask,
-        vid_pos [B,L,d], query_embed [N,d] fp32 parameter.  Returns hs [num_layers,B,N,d]."""
-        B = src_vid.shape[0]
-        dt = src_vid.dtype
+    def forward(self, src_vid32, src_skch32, kbias, vid_pos, query_embed):
+        """src_vid32 [B,L,d] fp32 (projected video tokens = start of the fp32 residual stream),
+        src_skch32 [B,d] fp32, kbias [B,L] fp32 additive key mask, vid_pos [B,L,d] compute dtype,
+        query_embed [N,d] fp32 parameter.  Returns hs [num_layers,B,N,d] fp32."""
+        B = src_vid32.shape[0]
+        dt = vid_pos.dtype
         qpos = ops.cast_ag(query_embed, dt)
-        skch32 = ops.cast_ag(src_skch.reshape(B, -1), torch.float32)
-        out = torch.zeros((B,) + tuple(qpos.shape), dtype=dt, device=src_vid.device)  # reference :56
-        outpos = qpos.unsqueeze(0).expand(B, -1, -1).contiguous()
-        mem = src_vid
+        N, d = qpos.shape
+        out = (torch.zeros((B, N, d), dtype=torch.float32, device=vid_pos.device),  # reference :56
+               torch.zeros((B, N, d), dtype=dt, device=vid_pos.device),
+               qpos.unsqueeze(0).expand(B, -1, -1).contiguous())
+        mem32 = src_vid32
         outputs = []
         for layer in self.layers:
-            mem, out, outpos = layer(mem, skch32, out, outpos, vid_pos, qpos, kbias)
-            outputs.append(out)
+            mem32, out = layer(mem32, src_skch32, out, vid_pos, qpos, kbias)
+            outputs.append(out[0])
         return torch.stack(outputs)
 
 

@@ -76,6 +76,10 @@ class PackedTargets:
         self.tgt_boxes = tgt.to(device, non_blocking=True).contiguous()
         self.status = torch.zeros((self.n_problems,), dtype=torch.int32, device=device)
         self.vid_off = vid_off
+        # PerFrameMatcher hands the criterion re-based target ids (matcher.py:114-115); the loss kernel
+        # reproduces that with the per-video first-box offsets
+        self.rebase_vid_off = (torch.from_numpy(vid_off.astype(np.int32)).to(device, non_blocking=True)
+                               if matcher == 'per_frame_matcher' else None)
         self.last_cost = None
 
     def check_status(self):

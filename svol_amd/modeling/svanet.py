@@ -44,14 +44,14 @@ class LinearLayer(nn.Module):
             self.LayerNorm = nn.LayerNorm(in_hsz)
         self.net = nn.Sequential(nn.Dropout(dropout), nn.Linear(in_hsz, out_hsz))
 
-    def forward(self, x, seed=0):
+    def forward(self, x, seed=0, out_f32=False):
         p = self.p if self.training else 0.0
         if self.layer_norm:
-            x = ops.layer_norm(x, self.LayerNorm.weight, self.LayerNorm.bias, None, p, seed)
+            x = ops.layer_norm(x, self.LayerNorm.weight, self.LayerNorm.bias, p, seed)
         elif p > 0.0:
             raise NotImplementedError('dropout without LayerNorm is not on the reference path')
         lin = self.net[1]
-        return ops.linear(x, lin.weight, lin.bias, ops.ACT_RELU if self.relu else ops.ACT_NONE)
+        return ops.linear(x, lin.weight, lin.bias, ops.ACT_RELU if self.relu else ops.ACT_NONE, out_f32)
 
 
 class SVANet(nn.Module):
@@ -89,8 +89,10 @@ class SVANet(nn.Module):
         self.base_seed = 1
 
     def _proj(self, seq, x, salt):
+        """input projection; the last layer emits fp32 (start of the fp32 residual stream)."""
+        n = len(seq)
         for j, layer in enumerate(seq):
-            x = layer(x, seed=(self.base_seed << 32) + (self._step << 8) + salt * 16 + j)
+            x = layer(x, seed=(self.base_seed << 32) + (self._step << 8) + salt * 16 + j, out_f32=(j == n - 1))
         return x
 
     def forward(self, src_sketch, src_sketch_mask, src_video, src_video_mask):
@@ -108,10 +110,11 @@ class SVANet(nn.Module):
         skch = self._proj(self.input_sketch_proj, ops.cast_ag(src_sketch.float(), dt), 1)
         # key_padding_mask (True on pads) as an additive bias for the cross-attention kernel
         kbias = torch.zeros_like(mask_f).masked_fill_(mask_f == 0, float('-inf'))
-        hs = self.transformer(vid, skch, kbias, pos_video, self.query_embed.weight)  # [NL,B,N,d]
-        hs32 = ops.cast_ag(hs, torch.float32)  # heads run in fp32 (tiny, keeps box coordinates exact)
-        outputs_class = ops.linear(hs32, self.class_embed.weight, self.class_embed.bias)
-        outputs_coord = self.bbox_embed(hs32, last_act=ops.ACT_SIGMOID)
+        hs = self.transformer(vid, skch.reshape(skch.shape[0], -1), kbias, pos_video,
+                              self.query_embed.weight)  # [NL,B,N,d] fp32
+        # heads run in fp32 (tiny; keeps logits / box coordinates at full precision)
+        outputs_class = ops.linear(hs, self.class_embed.weight, self.class_embed.bias)
+        outputs_coord = self.bbox_embed(hs, last_act=ops.ACT_SIGMOID)
         out = {'pred_logits': outputs_class[-1], 'pred_boxes': outputs_coord[-1]}
         if self.aux_loss:
             out['aux_outputs'] = [{'pred_logits': a, 'pred_boxes': b}

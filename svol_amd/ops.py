@@ -69,21 +69,22 @@ def cast_transpose(w: torch.Tensor, dtype: torch.dtype, want: bool = True, want_
     return d, dT
 
 
-def gemm_nt(A, B, bias=None, act=ACT_NONE, residual=None, want_pre=False, out=None, K=None, N=None):
+def gemm_nt(A, B, bias=None, act=ACT_NONE, residual=None, want_pre=False, out=None, out_f32=False):
     """out[M,N] = act(A[M,K] @ B[N,K]^T + bias) + residual.  A/B/out/residual may be column slices
-    of wider row-major buffers (stride(0) is the leading dimension)."""
+    of wider row-major buffers (stride(0) is the leading dimension).  out_f32: `out` and `residual`
+    are fp32 (the fp32 residual stream) whatever the operand dtype."""
     assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
-    M = A.shape[0]
-    K = A.shape[1] if K is None else K
-    N = B.shape[0] if N is None else N
+    M, K = A.shape
+    N = B.shape[0]
+    cdt = torch.float32 if out_f32 else A.dtype
     if out is None:
-        out = torch.empty((M, N), dtype=A.dtype, device=A.device)
+        out = torch.empty((M, N), dtype=cdt, device=A.device)
+    assert out.dtype == cdt and (residual is None or residual.dtype == cdt)
     pre = torch.empty((M, N), dtype=A.dtype, device=A.device) if want_pre else None
-    if pre is not None:
-        assert out.stride(0) == pre.stride(0)
     rc = _lib.lib().svol_gemm_nt(_ptr(A), A.stride(0), 0, 0, _ptr(B), B.stride(0), _ptr(out), out.stride(0),
-                                 _ptr(bias), act, _ptr(pre), _ptr(residual),
-                                 residual.stride(0) if residual is not None else 0, M, N, K, _dt(A), _stream())
+                                 _ptr(bias), act, _ptr(pre), pre.stride(0) if pre is not None else 0, _ptr(residual),
+                                 residual.stride(0) if residual is not None else 0, 1 if out_f32 else 0, M, N, K,
+                                 _dt(A), _stream())
     _lib.check(rc, 'svol_gemm_nt')
     return (out, pre) if want_pre else out
 
@@ -120,35 +121,44 @@ def act_bwd(dy, aux, act):
     return out
 
 
-def layernorm_fwd(x, gamma, beta, pos=None, p=0.0, seed=0):
+def layernorm_fwd(x, gamma, beta, dtype, pos=None, p=0.0, seed=0, want32=False, want_t=True):
+    """x [M,D] (fp32 residual stream or `dtype`) -> (y32 | None, y | None, ypos | None, mean, rstd)."""
     x = x.contiguous()
     M, D = x.shape
-    y = torch.empty_like(x)
-    ypos = torch.empty_like(x) if pos is not None else None
+    x_f32 = 1 if (x.dtype == torch.float32 and dtype != torch.float32) else 0
+    assert x.dtype in (dtype, torch.float32)
+    y32 = torch.empty((M, D), dtype=torch.float32, device=x.device) if want32 else None
+    y = torch.empty((M, D), dtype=dtype, device=x.device) if want_t else None
+    ypos = torch.empty((M, D), dtype=dtype, device=x.device) if pos is not None else None
     mean = torch.empty((M,), dtype=torch.float32, device=x.device)
     rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
     if pos is not None:
         pos = pos.contiguous()
-        assert pos.dtype == x.dtype and pos.shape[-1] == D
-    rc = _lib.lib().svol_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(ypos), _ptr(pos),
-                                       pos.numel() // D if pos is not None else 0, _ptr(mean), _ptr(rstd), M, D,
-                                       float(p), int(seed), _dt(x), _stream())
+        assert pos.dtype == dtype and pos.shape[-1] == D
+    rc = _lib.lib().svol_layernorm_fwd(_ptr(x), x_f32, _ptr(gamma), _ptr(beta), _ptr(y32), _ptr(y), _ptr(ypos),
+                                       _ptr(pos), pos.numel() // D if pos is not None else 0, _ptr(mean), _ptr(rstd),
+                                       M, D, float(p), int(seed), _DT[dtype], _stream())
     _lib.check(rc, 'svol_layernorm_fwd')
-    return y, ypos, mean, rstd
+    return y32, y, ypos, mean, rstd
 
 
-def layernorm_bwd(dy, dy2, x, gamma, mean, rstd, p=0.0, seed=0):
-    dy = dy.contiguous()
-    if dy2 is not None:
-        dy2 = dy2.contiguous()
+def layernorm_bwd(dy32, dy, dy2, x, gamma, mean, rstd, dtype, p=0.0, seed=0, want32=False, want_t=True):
+    """LN backward; any of dy32 (fp32) / dy / dy2 (`dtype`) may be None.  Returns (dx32|None, dx|None, dg, db)."""
     M, D = x.shape
-    dx = torch.empty_like(x)
+    x_f32 = 1 if (x.dtype == torch.float32 and dtype != torch.float32) else 0
+    cont = lambda t: None if t is None else t.reshape(M, D).contiguous()
+    dy32, dy, dy2 = cont(dy32), cont(dy), cont(dy2)
+    assert dy32 is None or dy32.dtype == torch.float32
+    assert (dy is None or dy.dtype == dtype) and (dy2 is None or dy2.dtype == dtype)
+    dx32 = torch.empty((M, D), dtype=torch.float32, device=x.device) if want32 else None
+    dx = torch.empty((M, D), dtype=dtype, device=x.device) if want_t else None
     dg = torch.zeros((D,), dtype=torch.float32, device=x.device)
     db = torch.zeros((D,), dtype=torch.float32, device=x.device)
-    rc = _lib.lib().svol_layernorm_bwd(_ptr(dy), _ptr(dy2), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx),
-                                       _ptr(dg), _ptr(db), M, D, float(p), int(seed), _dt(x), _stream())
+    rc = _lib.lib().svol_layernorm_bwd(_ptr(dy32), _ptr(dy), _ptr(dy2), _ptr(x), x_f32, _ptr(gamma), _ptr(mean),
+                                       _ptr(rstd), _ptr(dx32), _ptr(dx), _ptr(dg), _ptr(db), M, D, float(p), int(seed),
+                                       _DT[dtype], _stream())
     _lib.check(rc, 'svol_layernorm_bwd')
-    return dx, dg, db
+    return dx32, dx, dg, db
 
 
 def posenc_sine(mask_f32: torch.Tensor, D: int, dtype: torch.dtype) -> torch.Tensor:
@@ -187,26 +197,29 @@ def attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias=None):
 # optimizer bumps the tensor version.  One cast per weight per step.
 # ----------------------------------------------------------------------------
 class _WeightCache:
-    def __init__(self):
-        self._c = {}
+    """The cached copies live ON the parameter object (attribute ``_svol_cache``) and are validated by
+    (tensor version, data pointer), so a freed-and-reallocated parameter can never alias a stale entry."""
 
     def get(self, w: torch.Tensor, dtype: torch.dtype):
-        key = (w.data_ptr(), dtype, tuple(w.shape))
-        ent = self._c.get(key)
-        ver = w._version
-        if ent is None or ent[0] != ver:
+        cache = getattr(w, '_svol_cache', None)
+        if cache is None:
+            cache = {}
+            try:
+                w._svol_cache = cache
+            except Exception:  # pragma: no cover  (non-leaf views etc.: just do not cache)
+                pass
+        ent = cache.get(dtype)
+        tag = (w._version, w.data_ptr())
+        if ent is None or ent[0] != tag:
             wd = w.detach()
             if dtype == torch.float32:
                 _, wt = cast_transpose(wd, dtype, want=False)
-                ent = (ver, wd.contiguous(), wt)
+                ent = (tag, wd.contiguous(), wt)
             else:
                 wc, wt = cast_transpose(wd, dtype)
-                ent = (ver, wc, wt)
-            self._c[key] = ent
+                ent = (tag, wc, wt)
+            cache[dtype] = ent
         return ent[1], ent[2]
-
-    def clear(self):
-        self._c.clear()
 
 
 weights = _WeightCache()
@@ -215,55 +228,50 @@ weights = _WeightCache()
 # ----------------------------------------------------------------------------
 # autograd Functions
 # ----------------------------------------------------------------------------
+def _pos_grad(dypos, pos_shape, D):
+    """gradient of a broadcast positional operand (the learnable query embedding): sum over the batch."""
+    rows = 1
+    for n in pos_shape[:-1]:
+        rows *= n
+    g = colsum(dypos.reshape(-1, rows * D).contiguous())
+    return cast(g.view(pos_shape), dypos.dtype)
+
+
 class LayerNormFn(torch.autograd.Function):
-    """y = dropout(LN(x)) [, ypos = y + pos].  svanet.py:168-178 / post-norms of
-    cross_modal_transformer.py:127-158."""
+    """y = dropout(LN(x)), compute dtype in / out (input projections, svanet.py:168-178)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, pos, p, seed):
-        ctx.set_materialize_grads(False)
+    def forward(ctx, x, gamma, beta, p, seed):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
-        y, ypos, mean, rstd = layernorm_fwd(x2, gamma, beta, pos, p, seed)
+        _, y, _, mean, rstd = layernorm_fwd(x2, gamma, beta, x.dtype, None, p, seed)
         ctx.save_for_backward(x2, gamma, mean, rstd)
-        ctx.p, ctx.seed, ctx.shp, ctx.has_pos = p, seed, shp, pos is not None
-        if pos is not None:
-            ctx.pos_numel, ctx.pos_shape = pos.numel(), pos.shape
-        if pos is not None:
-            return y.view(shp), ypos.view(shp)
+        ctx.p, ctx.seed, ctx.shp = p, seed, shp
         return y.view(shp)
 
     @staticmethod
-    def backward(ctx, dy, dypos=None):
+    def backward(ctx, dy):
         x2, gamma, mean, rstd = ctx.saved_tensors
-        D = x2.shape[1]
-        if dy is None:
-            dy, dypos = dypos, None
-        dpos = None
-        if ctx.has_pos and ctx.needs_input_grad[3]:
-            src = dypos if dypos is not None else dy  # dy was swapped in when only ypos was used
-            rows = ctx.pos_numel // D
-            dpos = colsum(src.reshape(-1, rows * D).contiguous()).view(ctx.pos_shape).to(src.dtype)
-        dx, dg, db = layernorm_bwd(dy.reshape(-1, D), dypos.reshape(-1, D) if dypos is not None else None, x2, gamma,
-                                   mean, rstd, ctx.p, ctx.seed)
-        return dx.view(ctx.shp), dg, db, dpos, None, None
+        _, dx, dg, db = layernorm_bwd(None, dy, None, x2, gamma, mean, rstd, x2.dtype, ctx.p, ctx.seed)
+        return dx.view(ctx.shp), dg, db, None, None
 
 
-def layer_norm(x, gamma, beta, pos=None, p=0.0, seed=0):
-    return LayerNormFn.apply(x, gamma, beta, pos, p, seed)
+def layer_norm(x, gamma, beta, p=0.0, seed=0):
+    return LayerNormFn.apply(x, gamma, beta, p, seed)
 
 
 class LinearFn(torch.autograd.Function):
-    """y = act(x W^T + b) (nn.Linear + F.relu / sigmoid)."""
+    """y = act(x W^T + b) (nn.Linear + F.relu / sigmoid).  out_f32: y is emitted in fp32 (it starts the
+    fp32 residual stream); its gradient then arrives in fp32 and is cast once."""
 
     @staticmethod
-    def forward(ctx, x, W, b, act):
+    def forward(ctx, x, W, b, act, out_f32):
+        if act == ACT_GELU:
+            raise _lib.SvolHipError('LinearFn: GELU is only available fused in MLPLNFn')
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
-        if act == ACT_GELU:
-            raise _lib.SvolHipError('LinearFn: GELU is only available fused in MLPResFn')
         Wc, WcT = weights.get(W, x.dtype)
-        y = gemm_nt(x2, Wc, b, act)
+        y = gemm_nt(x2, Wc, b, act, out_f32=out_f32)
         ctx.save_for_backward(x2, y if act != ACT_NONE else None)
         ctx.WcT, ctx.act, ctx.shp, ctx.has_b = WcT, act, shp, b is not None
         ctx.need_dx = ctx.needs_input_grad[0]
@@ -276,6 +284,8 @@ class LinearFn(torch.autograd.Function):
         d = dy.reshape(-1, N)
         if not d.is_contiguous():
             d = d.contiguous()
+        if d.dtype != x2.dtype:
+            d = cast(d, x2.dtype)
         if ctx.act != ACT_NONE:
             d = act_bwd(d, y, ctx.act)
         db = colsum(d) if ctx.has_b else None
@@ -292,109 +302,132 @@ class LinearFn(torch.autograd.Function):
             d, WcT = dp, wp
         dW = gemm_tn(d, x2)[:N]
         dx = gemm_nt(d, WcT).view(ctx.shp) if ctx.need_dx else None
-        return dx, dW, db, None
+        return dx, dW, db, None, None
 
 
-def linear(x, W, b=None, act=ACT_NONE):
-    return LinearFn.apply(x, W, b, act)
+def linear(x, W, b=None, act=ACT_NONE, out_f32=False):
+    return LinearFn.apply(x, W, b, act, out_f32)
 
 
-class MLPResFn(torch.autograd.Function):
-    """y = x + fc2(gelu(fc1(x)))  — cross_modal_transformer.py:142,157 + MLP :163-179."""
+# ---- residual-stream blocks ------------------------------------------------------------------
+# Every block maps the stream triple (x32 fp32 residual value, x compute-dtype copy, xpos = x + pos)
+# to the next triple; the pre-norm sum s = x32 + f(x) stays fp32 and never leaves the block.
+def _ln_out(s32, gamma, beta, pos_out, dt):
+    y32, y, ypos, mean, rstd = layernorm_fwd(s32, gamma, beta, dt, pos_out, want32=True)
+    return y32, y, ypos, mean, rstd
+
+
+class MLPLNFn(torch.autograd.Function):
+    """LN(x + fc2(gelu(fc1(x))))  — cross_modal_transformer.py:142-143,157-158 + MLP :163-179."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2):
+    def forward(ctx, x32, x, W1, b1, W2, b2, gamma, beta, pos_out):
+        ctx.set_materialize_grads(False)
         shp = x.shape
-        x2 = x.reshape(-1, shp[-1])
-        W1c, W1T = weights.get(W1, x.dtype)
-        W2c, W2T = weights.get(W2, x.dtype)
+        D = shp[-1]
+        dt = x.dtype
+        x2, x32_2 = x.reshape(-1, D), x32.reshape(-1, D)
+        W1c, W1T = weights.get(W1, dt)
+        W2c, W2T = weights.get(W2, dt)
         hid, pre = gemm_nt(x2, W1c, b1, ACT_GELU, want_pre=True)
-        y = gemm_nt(hid, W2c, b2, ACT_NONE, residual=x2)
-        ctx.save_for_backward(x2, pre, hid)
+        s32 = gemm_nt(hid, W2c, b2, ACT_NONE, residual=x32_2, out_f32=True)
+        y32, y, ypos, mean, rstd = _ln_out(s32, gamma, beta, pos_out, dt)
+        ctx.save_for_backward(x2, pre, hid, s32, gamma, mean, rstd)
         ctx.W1T, ctx.W2T, ctx.shp = W1T, W2T, shp
-        return y.view(shp)
+        ctx.pos_shape = pos_out.shape if pos_out is not None else None
+        if pos_out is not None:
+            return y32.view(shp), y.view(shp), ypos.view(shp)
+        return y32.view(shp), y.view(shp)
 
     @staticmethod
-    def backward(ctx, dy):
-        x2, pre, hid = ctx.saved_tensors
-        d = dy.reshape(-1, dy.shape[-1])
-        if not d.is_contiguous():
-            d = d.contiguous()
-        dW2 = gemm_tn(d, hid)
-        db2 = colsum(d)
-        dh = gemm_nt(d, ctx.W2T)
+    def backward(ctx, dy32, dy, dypos=None):
+        x2, pre, hid, s32, gamma, mean, rstd = ctx.saved_tensors
+        dt = x2.dtype
+        D = x2.shape[1]
+        dpos = None
+        if ctx.pos_shape is not None and ctx.needs_input_grad[8] and dypos is not None:
+            dpos = _pos_grad(dypos, ctx.pos_shape, D)
+        ds32, ds, dg, dbt = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True)
+        dW2 = gemm_tn(ds, hid)
+        db2 = colsum(ds)
+        dh = gemm_nt(ds, ctx.W2T)
         dpre = act_bwd(dh, pre, ACT_GELU)
         del dh
         dW1 = gemm_tn(dpre, x2)
         db1 = colsum(dpre)
-        dx = gemm_nt(dpre, ctx.W1T, residual=d)
-        return dx.view(ctx.shp), dW1, db1, dW2, db2
+        dx = gemm_nt(dpre, ctx.W1T)
+        return ds32.view(ctx.shp), dx.view(ctx.shp), dW1, db1, dW2, db2, dg, dbt, dpos
 
 
-def mlp_res(x, W1, b1, W2, b2):
-    return MLPResFn.apply(x, W1, b1, W2, b2)
-
-
-class AttnResFn(torch.autograd.Function):
-    """y = xq + out_proj(MHA(q = Wq xq_pos, k = Wk xk_pos, v = Wv xv)) with packed in_proj
-    (nn.MultiheadAttention, cross_modal_transformer.py:137-141,145-149,151-156).
+class AttnLNFn(torch.autograd.Function):
+    """LN(xq + out_proj(MHA(q = Wq xq_pos, k = Wk xk_pos, v = Wv xv))) with packed in_proj
+    (nn.MultiheadAttention + post-norm, cross_modal_transformer.py:137-141,145-149,151-156).
     ``self_attn``: xk_pos is xq_pos and xv is xq (one packed projection buffer)."""
 
     @staticmethod
-    def forward(ctx, xq_pos, xq, xk_pos, xv, W_in, b_in, W_o, b_o, H, kbias, self_attn):
+    def forward(ctx, xq32, xq, xq_pos, xk_pos, xv, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, kbias, self_attn):
+        ctx.set_materialize_grads(False)
         B, Lq, d = xq.shape
-        Lk = xv.shape[1]
+        dt = xq.dtype
+        Lk = Lq if self_attn else xv.shape[1]
         dh = d // H
-        Wc, WcT = weights.get(W_in, xq.dtype)
-        Woc, WoT = weights.get(W_o, xq.dtype)
+        Wc, WcT = weights.get(W_in, dt)
+        Woc, WoT = weights.get(W_o, dt)
         a_qp = xq_pos.reshape(B * Lq, d)
         a_q = xq.reshape(B * Lq, d)
         a_kp = a_qp if self_attn else xk_pos.reshape(B * Lk, d)
         a_v = a_q if self_attn else xv.reshape(B * Lk, d)
         if self_attn:
-            qkv = torch.empty((B * Lq, 3 * d), dtype=xq.dtype, device=xq.device)
+            qkv = torch.empty((B * Lq, 3 * d), dtype=dt, device=xq.device)
             gemm_nt(a_qp, Wc[:2 * d], b_in[:2 * d], out=qkv[:, :2 * d])
             gemm_nt(a_q, Wc[2 * d:], b_in[2 * d:], out=qkv[:, 2 * d:])
             q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         else:
             q = gemm_nt(a_qp, Wc[:d], b_in[:d])
-            kv = torch.empty((B * Lk, 2 * d), dtype=xq.dtype, device=xq.device)
+            kv = torch.empty((B * Lk, 2 * d), dtype=dt, device=xq.device)
             gemm_nt(a_kp, Wc[d:2 * d], b_in[d:2 * d], out=kv[:, :d])
             gemm_nt(a_v, Wc[2 * d:], b_in[2 * d:], out=kv[:, d:])
             k, v = kv[:, :d], kv[:, d:]
         o, lse2 = attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias)
-        y = gemm_nt(o, Woc, b_o, residual=a_q)
-        ctx.save_for_backward(a_qp, a_q, a_kp, a_v, q, k, v, o, lse2, kbias)
+        s32 = gemm_nt(o, Woc, b_o, residual=xq32.reshape(B * Lq, d), out_f32=True)
+        y32, y, ypos, mean, rstd = _ln_out(s32, gamma, beta, pos_out, dt)
+        ctx.save_for_backward(a_qp, a_q, a_kp, a_v, q, k, v, o, lse2, kbias, s32, gamma, mean, rstd)
         ctx.WcT, ctx.WoT, ctx.dims, ctx.self_attn = WcT, WoT, (B, H, Lq, Lk, dh, d), self_attn
-        return y.view(B, Lq, d)
+        ctx.pos_shape = pos_out.shape if pos_out is not None else None
+        shp = (B, Lq, d)
+        if pos_out is not None:
+            return y32.view(shp), y.view(shp), ypos.view(shp)
+        return y32.view(shp), y.view(shp)
 
     @staticmethod
-    def backward(ctx, dy):
-        a_qp, a_q, a_kp, a_v, q, k, v, o, lse2, kbias = ctx.saved_tensors
+    def backward(ctx, dy32, dy, dypos=None):
+        a_qp, a_q, a_kp, a_v, q, k, v, o, lse2, kbias, s32, gamma, mean, rstd = ctx.saved_tensors
         B, H, Lq, Lk, dh, d = ctx.dims
+        dt = a_q.dtype
         WcT, WoT = ctx.WcT, ctx.WoT  # WcT: [d, 3d] ; WoT: [d, d]
-        g = dy.reshape(B * Lq, d)
-        if not g.is_contiguous():
-            g = g.contiguous()
+        dpos = None
+        if ctx.pos_shape is not None and ctx.needs_input_grad[11] and dypos is not None:
+            dpos = _pos_grad(dypos, ctx.pos_shape, d)
+        ds32, g, dg, dbt = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True)
         dWo = gemm_tn(g, o)
         dbo = colsum(g)
         do = gemm_nt(g, WoT)
         dW_in = torch.zeros((3 * d, d), dtype=torch.float32, device=g.device)
         db_in = torch.zeros((3 * d,), dtype=torch.float32, device=g.device)
+        shq = (B, Lq, d)
         if ctx.self_attn:
-            dqkv = torch.empty((B * Lq, 3 * d), dtype=g.dtype, device=g.device)
+            dqkv = torch.empty((B * Lq, 3 * d), dtype=dt, device=g.device)
             dq, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
             attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias)
             gemm_tn(dqkv[:, :2 * d], a_qp, out=dW_in[:2 * d])
             gemm_tn(dv, a_q, out=dW_in[2 * d:])
             colsum(dqkv, out=db_in)
-            # d(xq_pos) = [dq dk] W_qk ; d(xq) = dv W_v + dy (residual)
-            dxq_pos = gemm_nt(dqkv[:, :2 * d], WcT[:, :2 * d])
-            dxq = gemm_nt(dv, WcT[:, 2 * d:], residual=g)
-            return (dxq_pos.view(B, Lq, d), dxq.view(B, Lq, d), None, None, dW_in, db_in, dWo, dbo, None, None,
-                    None)
-        dq = torch.empty((B * Lq, d), dtype=g.dtype, device=g.device)
-        dkv = torch.empty((B * Lk, 2 * d), dtype=g.dtype, device=g.device)
+            dxq_pos = gemm_nt(dqkv[:, :2 * d], WcT[:, :2 * d])  # d(x + pos) = [dq dk] W_qk
+            dxq = gemm_nt(dv, WcT[:, 2 * d:])                    # d(x) through V
+            return (ds32.view(shq), dxq.view(shq), dxq_pos.view(shq), None, None, dW_in, db_in, dWo, dbo, dg, dbt,
+                    dpos, None, None, None)
+        dq = torch.empty((B * Lq, d), dtype=dt, device=g.device)
+        dkv = torch.empty((B * Lk, 2 * d), dtype=dt, device=g.device)
         dk, dv = dkv[:, :d], dkv[:, d:]
         attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias)
         gemm_tn(dq, a_qp, out=dW_in[:d])
@@ -405,65 +438,72 @@ class AttnResFn(torch.autograd.Function):
         dxq_pos = gemm_nt(dq, WcT[:, :d])
         dxk_pos = gemm_nt(dk, WcT[:, d:2 * d])
         dxv = gemm_nt(dv, WcT[:, 2 * d:])
-        return (dxq_pos.view(B, Lq, d), g.view(B, Lq, d), dxk_pos.view(B, Lk, d), dxv.view(B, Lk, d), dW_in, db_in,
-                dWo, dbo, None, None, None)
+        shk = (B, Lk, d)
+        return (ds32.view(shq), None, dxq_pos.view(shq), dxk_pos.view(shk), dxv.view(shk), dW_in, db_in, dWo, dbo, dg,
+                dbt, dpos, None, None, None)
 
 
-def self_attn_res(x_pos, x, W_in, b_in, W_o, b_o, H):
-    return AttnResFn.apply(x_pos, x, None, x, W_in, b_in, W_o, b_o, H, None, True)
+def mlp_ln(x32, x, W1, b1, W2, b2, gamma, beta, pos_out=None):
+    return MLPLNFn.apply(x32, x, W1, b1, W2, b2, gamma, beta, pos_out)
 
 
-def cross_attn_res(xq_pos, xq, xk_pos, xv, W_in, b_in, W_o, b_o, H, kbias):
-    return AttnResFn.apply(xq_pos, xq, xk_pos, xv, W_in, b_in, W_o, b_o, H, kbias, False)
+def self_attn_ln(x32, x, x_pos, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H):
+    return AttnLNFn.apply(x32, x, x_pos, None, None, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, None, True)
+
+
+def cross_attn_ln(xq32, xq, xq_pos, xk_pos, xv, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, kbias):
+    return AttnLNFn.apply(xq32, xq, xq_pos, xk_pos, xv, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, kbias, False)
 
 
 class GateFn(torch.autograd.Function):
-    """(mem, mem + pos) with mem = LN1(x * (1 + a)), a = head-mean softmax of the 1-query
+    """(mem32, mem, mem + pos) with mem = LN1(x * (1 + a)), a = head-mean softmax of the 1-query
     sketch->video attention (cross_modal_transformer.py:122-127); u = per-(batch, head) folded
-    key projection [B,H,d] fp32."""
+    key projection [B,H,d] fp32.  x32 is the fp32 residual stream."""
 
     @staticmethod
-    def forward(ctx, x, pos, u, gamma, beta, H):
+    def forward(ctx, x32, pos, u, gamma, beta, H):
         ctx.set_materialize_grads(False)
-        B, L, D = x.shape
-        x2 = x.reshape(B * L, D)
-        pos2 = pos.reshape(B * L, D)
+        B, L, D = x32.shape
+        dt = pos.dtype
+        x2 = x32.reshape(B * L, D).contiguous()
+        assert x2.dtype == torch.float32
+        pos2 = pos.reshape(B * L, D).contiguous()
         u = u.contiguous().float()
-        y = torch.empty_like(x2)
-        ypos = torch.empty_like(x2)
-        a = torch.empty((B * L,), dtype=torch.float32, device=x.device)
+        y32 = torch.empty((B * L, D), dtype=torch.float32, device=x2.device)
+        y = torch.empty((B * L, D), dtype=dt, device=x2.device)
+        ypos = torch.empty((B * L, D), dtype=dt, device=x2.device)
+        a = torch.empty((B * L,), dtype=torch.float32, device=x2.device)
         mean = torch.empty_like(a)
         rstd = torch.empty_like(a)
-        ws = torch.empty((B * H * (L + 2),), dtype=torch.float32, device=x.device)
-        rc = _lib.lib().svol_gate_fwd(_ptr(x2), _ptr(pos2), _ptr(u), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(ypos),
-                                      _ptr(a), _ptr(mean), _ptr(rstd), _ptr(ws), B, L, D, H, _dt(x2), _stream())
+        ws = torch.empty((B * H * (L + 2),), dtype=torch.float32, device=x2.device)
+        rc = _lib.lib().svol_gate_fwd(_ptr(x2), _ptr(pos2), _ptr(u), _ptr(gamma), _ptr(beta), _ptr(y32), _ptr(y),
+                                      _ptr(ypos), _ptr(a), _ptr(mean), _ptr(rstd), _ptr(ws), B, L, D, H, _DT[dt],
+                                      _stream())
         _lib.check(rc, 'svol_gate_fwd')
         ctx.save_for_backward(x2, pos2, u, gamma, a, mean, rstd, ws)
         ctx.dims = (B, L, D, H)
-        return y.view(B, L, D), ypos.view(B, L, D)
+        return y32.view(B, L, D), y.view(B, L, D), ypos.view(B, L, D)
 
     @staticmethod
-    def backward(ctx, dy, dypos):
+    def backward(ctx, dy32, dy, dypos):
         x2, pos2, u, gamma, a, mean, rstd, ws = ctx.saved_tensors
         B, L, D, H = ctx.dims
-        if dy is None:
-            dy, dypos = dypos, None
-        dy2 = dy.reshape(B * L, D).contiguous()
-        dyp2 = dypos.reshape(B * L, D).contiguous() if dypos is not None else None
-        dx = torch.empty_like(x2)
+        cont = lambda t: None if t is None else t.reshape(B * L, D).contiguous()
+        dy32, dy, dypos = cont(dy32), cont(dy), cont(dypos)
+        dx32 = torch.empty_like(x2)
         du = torch.zeros((B, H, D), dtype=torch.float32, device=x2.device)
         dg = torch.zeros((D,), dtype=torch.float32, device=x2.device)
         db = torch.zeros((D,), dtype=torch.float32, device=x2.device)
         ws2 = torch.empty((B * L + B * H,), dtype=torch.float32, device=x2.device)
-        rc = _lib.lib().svol_gate_bwd(_ptr(dy2), _ptr(dyp2), _ptr(x2), _ptr(pos2), _ptr(u), _ptr(gamma), _ptr(a),
-                                      _ptr(mean), _ptr(rstd), _ptr(ws), _ptr(ws2), _ptr(dx), _ptr(du), _ptr(dg),
-                                      _ptr(db), B, L, D, H, _dt(x2), _stream())
+        rc = _lib.lib().svol_gate_bwd(_ptr(dy32), _ptr(dy), _ptr(dypos), _ptr(x2), _ptr(pos2), _ptr(u), _ptr(gamma),
+                                      _ptr(a), _ptr(mean), _ptr(rstd), _ptr(ws), _ptr(ws2), _ptr(dx32), _ptr(du),
+                                      _ptr(dg), _ptr(db), B, L, D, H, _DT[pos2.dtype], _stream())
         _lib.check(rc, 'svol_gate_bwd')
-        return dx.view(B, L, D), None, du, dg, db, None
+        return dx32.view(B, L, D), None, du, dg, db, None
 
 
-def gate(x, pos, u, gamma, beta, H):
-    return GateFn.apply(x, pos, u, gamma, beta, H)
+def gate(x32, pos, u, gamma, beta, H):
+    return GateFn.apply(x32, pos, u, gamma, beta, H)
 
 
 class CastFn(torch.autograd.Function):
@@ -499,7 +539,8 @@ class SetCriterionFn(torch.autograd.Function):
         g_bbox = torch.empty_like(bx)
         g_giou = torch.empty_like(bx)
         rc = _lib.lib().svol_set_loss(_ptr(lg), _ptr(bx), _ptr(packed.tgt_boxes), _ptr(match), _ptr(losses),
-                                      _ptr(g_label), _ptr(g_bbox), _ptr(g_giou), NL, rows, float(eos_coef), _stream())
+                                      _ptr(g_label), _ptr(g_bbox), _ptr(g_giou), NL, rows, float(eos_coef),
+                                      _ptr(packed.rebase_vid_off), logits.shape[2], _stream())
         _lib.check(rc, 'svol_set_loss')
         ctx.save_for_backward(g_label, g_bbox, g_giou)
         ctx.mark_non_differentiable(match)
