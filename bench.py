@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the SVOL hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by the driver as  python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+     --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...; one rank per GPU over RCCL)
+
+metric  : frames/sec of forward + matcher/criterion + backward (BASELINE.json), whole job over N GPUs
+workload: BASELINE.json configs[1]  — B=8 videos per GPU, T=32 frames, P=196 tokens/frame (L=6272),
+          d=256, 8 heads, 6 layers (6 video + 6 query blocks), N=100 queries,
+          video_matcher, Din=512 features at the head boundary, bf16 MFMA
+          compute with an fp32 residual stream, train mode (input dropout on), synthetic data,
+          weights: module default init.  One step = zero_grad, forward, criterion (all 6 layers matched on
+          device), backward (+ bucketed RCCL gradient all-reduce overlapped with backward when N > 1), and
+          the AdamW step (so that the per-step fp32->bf16 weight refresh is inside the timed region).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+FWD_BWD_GF_PER_FRAME = 34.07    # BASELINE.md §3 (algorithmic, fwd + 2x bwd, no recompute credit)
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """Reference CPU path timed beside the GPU number: the oracle (CPU restatement proven equal to the
+    reference by the golden vectors) on a BOUNDED sample of the same workload — one of the 8 videos of
+    configs[1] (B=1, T=32, P=196, d=256, 6 layers, N=100, fp32, fwd + matcher + bwd).  Videos are
+    independent, so frames/s does not depend on B."""
+    import torch
+    from oracle import svol_oracle as O
+    from svol_amd import synthetic as syn
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    args = syn.cfg2_args('video_matcher')
+    B, T, P = 1, 32, 196
+    sd = {k: v.clone().requires_grad_(True) for k, v in syn.synth_state_dict(args, seed=1).items()}
+    inp = syn.synth_inputs(args, B, T, P, seed=1)
+    tg = syn.synth_targets(B, T, seed=1)
+    times = []
+    t_start = time.time()
+    for it in range(4):
+        for p in sd.values():
+            p.grad = None
+        t0 = time.time()
+        O.train_step(sd, args, inp, tg)
+        dt = time.time() - t0
+        if it > 0:
+            times.append(dt)
+        if time.time() - t_start > seconds_budget and times:
+            break
+    t = sorted(times)[len(times) // 2]
+    return {'value': B * T / t, 'unit': 'frames/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle (CPU restatement, fp32, torch {torch.__version__}) on 1 of the 8 videos of configs[1]: '
+                      f'B=1,T=32,P=196,d=256,6 layers,N=100, fwd+matcher+bwd, median of {len(times)} steps '
+                      f'({t * 1e3:.0f} ms/step)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--batch', type=int, default=8, help='videos per GPU')
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from svol_amd import ops, parallel
+    from svol_amd import synthetic as syn
+    from svol_amd.modeling.loss import build_loss
+    from svol_amd.modeling.svanet import build_svanet
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+
+    B, T, P = a.batch, 32, 196
+    args = syn.cfg2_args('video_matcher')
+    args.compute_dtype = a.dtype
+    torch.manual_seed(1)  # reference default seed (configs.py:17): identical initial weights on every rank
+    model = build_svanet(args).to(dev).train()
+    crit = build_loss(args).to(dev).train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    reducer = parallel.BucketedGradAllReduce(params, skip=parallel.unused_parameters(model))
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, fused=True)  # train.py:98-99
+    # weak scaling: every rank gets its own B videos (different seeds = a properly sharded global batch)
+    inp = {k: v.to(dev) for k, v in syn.synth_inputs(args, B, T, P, seed=1 + rank).items()}
+    tg = syn.synth_targets(B, T, seed=1 + rank)
+    wd = crit.weight_dict
+
+    def step():
+        reducer.zero_grad()
+        out = model(inp['src_sketch'], inp['src_sketch_mask'], inp['src_video'], inp['src_video_mask'])
+        ld = crit(out, tg)
+        loss = sum(ld[k] * wd[k] for k in ld.keys() if k in wd)  # train.py:227-228
+        loss.backward()
+        reducer.finish()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        loss = step()
+    ops.timer.enable(['attn_fwd', 'attn_bwd'])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.timer.disable()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss)
+    assert final_loss == final_loss, 'loss is NaN'
+
+    ms_per_step = elapsed / a.steps * 1e3
+    frames = B * T * world
+    fps = frames / (elapsed / a.steps)
+
+    # ---- roofline of the dominant kernel: video self-attention (L x L, 67 % of the layer's FLOPs) ----
+    L = T * P
+    dh = args.hidden_dim // args.nheads
+    summ = ops.timer.summary()
+    fwd = summ.get(('attn_fwd', (B, args.nheads, L, L, dh)))
+    bwd = summ.get(('attn_bwd', (B, args.nheads, L, L, dh)))
+    attn_fwd_flop = 4.0 * L * L * args.hidden_dim * B          # QK^T + PV  (4 L^2 d per sample)
+    roof = None
+    if fwd and bwd:
+        # backward = 2x forward algorithmically (dV, dP, dQ, dK products; the S recompute gets no credit)
+        which = 'attn_bwd (delta + dQ pass + dK/dV pass)' if bwd[1] >= fwd[1] else 'attn_fwd'
+        flop, ms = (2.0 * attn_fwd_flop, bwd[1]) if bwd[1] >= fwd[1] else (attn_fwd_flop, fwd[1])
+        ach = flop / (ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'kernel': which, 'achieved': ach, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': ach / PEAK_BF16_MFMA_TFLOPS, 'traffic': None,
+                'launch_ms': ms, 'launches_timed': bwd[0] if bwd[1] >= fwd[1] else fwd[0],
+                'attn_fwd_ms': fwd[1], 'attn_bwd_ms': bwd[1],
+                'attn_fwd_tflops': attn_fwd_flop / (fwd[1] * 1e-3) / 1e12,
+                'whole_step_tflops': fps * FWD_BWD_GF_PER_FRAME / 1e3 / world,
+                'whole_step_frac_of_peak': fps * FWD_BWD_GF_PER_FRAME / 1e3 / world / PEAK_BF16_MFMA_TFLOPS}
+
+    if rank == 0:
+        res = {
+            'metric': 'frames/sec (fwd+matcher+bwd), T=32·P=196·d=256',
+            'value': fps, 'unit': 'frames/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': a.dtype, 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: SVANet head + Hungarian/GIoU criterion, B=%d/GPU, T=32, P=196, '
+                                   'd=256, h=8, 6 layers, N=100, video_matcher, Din=512, train mode; step = fwd + '
+                                   'criterion + bwd (+RCCL grad all-reduce) + AdamW' % B,
+                       'global_batch': B * world, 'parallelism': f'dp{world}'},
+            'final_loss': final_loss,
+        }
+        if roof:
+            res['roofline'] = roof
+        if world == 1 and not a.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -38,11 +38,50 @@ def _ptr(t: Optional[torch.Tensor]) -> int:
     return t.data_ptr()
 
 
-def _rows(t: torch.Tensor) -> torch.Tensor:
-    """view [..., D] as a 2-D row-major matrix (last dim contiguous)."""
-    if t.stride(-1) != 1:
-        t = t.contiguous()
-    return t
+class KernelTimer:
+    """Optional per-kernel timing with HIP events recorded on the launch stream (the stream every
+    C-ABI call is enqueued on = torch's current stream).  Disabled by default (zero overhead);
+    bench.py enables it for the dominant kernels to report the live roofline numbers."""
+
+    def __init__(self):
+        self.enabled = False
+        self.names = set()
+        self.records = {}
+
+    def enable(self, names):
+        self.enabled, self.names, self.records = True, set(names), {}
+
+    def disable(self):
+        self.enabled = False
+
+    def clear(self):
+        self.records = {}
+
+    def start(self, name, meta=None):
+        if not self.enabled or name not in self.names:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (name, meta, e0, e1)
+
+    def stop(self, tok):
+        if tok is None:
+            return
+        name, meta, e0, e1 = tok
+        e1.record()
+        self.records.setdefault((name, meta), []).append((e0, e1))
+
+    def summary(self):
+        """{(name, meta): (launches, mean_ms)} — call after torch.cuda.synchronize()."""
+        out = {}
+        for k, evs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[k] = (len(ms), sum(ms) / len(ms))
+        return out
+
+
+timer = KernelTimer()
 
 
 # ----------------------------------------------------------------------------
@@ -174,9 +213,11 @@ def attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias=None):
     """q/k/v: 2-D [B*L, >=H*dh] views (column slices allowed). Returns o [B*Lq, H*dh], lse2 [B,H,Lq]."""
     o = torch.empty((B * Lq, H * dh), dtype=q.dtype, device=q.device)
     lse2 = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
+    tok = timer.start('attn_fwd', (B, H, Lq, Lk, dh))
     rc = _lib.lib().svol_attn_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o),
                                   o.stride(0), _ptr(lse2), _ptr(kbias), B, H, Lq, Lk, dh, 1.0 / math.sqrt(dh),
                                   _dt(q), _stream())
+    timer.stop(tok)
     _lib.check(rc, 'svol_attn_fwd')
     return o, lse2
 
@@ -185,10 +226,12 @@ def attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias=None):
     """Writes dq/dk/dv (2-D views, column slices allowed)."""
     do = do if do.stride(1) == 1 else do.contiguous()
     delta = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
+    tok = timer.start('attn_bwd', (B, H, Lq, Lk, dh))
     rc = _lib.lib().svol_attn_bwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o),
                                   o.stride(0), _ptr(do), do.stride(0), _ptr(lse2), _ptr(delta), _ptr(kbias),
                                   _ptr(dq), dq.stride(0), _ptr(dk), dk.stride(0), _ptr(dv), dv.stride(0), B, H, Lq,
                                   Lk, dh, 1.0 / math.sqrt(dh), _dt(q), _stream())
+    timer.stop(tok)
     _lib.check(rc, 'svol_attn_bwd')
 
 

@@ -1,0 +1,142 @@
+"""Data-parallel gradient exchange for the SVOL training step: one process per GPU, bucketed
+all-reduce over RCCL / xGMI (``torch.distributed`` backend "nccl" IS RCCL on ROCm), overlapped with
+the backward pass.
+
+The reference wraps the model in apex ``DistributedDataParallel(delay_allreduce=True)`` (train.py:124):
+ONE flattened all-reduce of every gradient after backward has finished, no overlap.  Semantics kept:
+the result is the MEAN over ranks of the per-rank gradients (each rank's loss is a mean over its LOCAL
+batch / matched pairs, i.e. mean-of-means — SURVEY.md §8e), parameters that receive no gradient
+(``sketch_video_cross_attn.out_proj.*``, ``class_head.*``) are skipped on every rank.
+
+MI355X-first differences:
+* gradients live in a few large flat fp32 buckets (``param.grad`` is a VIEW into its bucket), so a
+  bucket is reduced in place with no gather/scatter copies;
+* buckets are filled in reverse parameter order (= backward order: heads and the last layer first) and
+  each bucket's all-reduce is issued on a side stream the moment its last gradient has been accumulated,
+  so the exchange of layer k overlaps the backward kernels of layers < k;
+* xGMI is point-to-point (7 links x ~153 GB/s per GPU): the 74.4 MiB fp32 gradient of the benchmark
+  head is cut into ~16 MiB buckets — large enough that each ring step is bandwidth- not latency-bound
+  (per-link ring time ~ 2*(7/8)*16 MiB / 153 GB/s ~ 0.19 ms), small enough that the last bucket (the
+  input projections, ready only at the very end of backward) exposes little un-overlapped time.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class BucketedGradAllReduce:
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 16 << 20,
+                 skip: Optional[Iterable[torch.nn.Parameter]] = None, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        skip_ids = {id(p) for p in (skip or [])}
+        plist = [p for p in params if p.requires_grad and id(p) not in skip_ids]
+        if not plist:
+            raise ValueError('no parameters to reduce')
+        self.device = plist[0].device
+        self.on_gpu = self.device.type == 'cuda'
+        # reverse order ~ the order in which backward produces gradients
+        order = list(reversed(plist))
+        self.buckets: List[dict] = []
+        cur, cur_bytes = [], 0
+        for p in order:
+            nbytes = p.numel() * 4
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                self._make_bucket(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self._make_bucket(cur)
+        self._handles = []
+        self._hooks = []
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        for bi, b in enumerate(self.buckets):
+            for p in b['params']:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+
+    def _make_bucket(self, params):
+        n = sum(p.numel() for p in params)
+        flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
+        off = 0
+        for p in params:
+            assert p.dtype == torch.float32, 'master parameters are fp32'
+            p.grad = flat[off:off + p.numel()].view_as(p)  # autograd accumulates in place into the view
+            off += p.numel()
+        self.buckets.append({'params': params, 'flat': flat, 'pending': len(params), 'n': len(params)})
+
+    def _make_hook(self, bi):
+        def hook(_p):
+            b = self.buckets[bi]
+            b['pending'] -= 1
+            if b['pending'] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        if self.world == 1:
+            return
+        if self.on_gpu:
+            # the bucket's gradients were produced on the current (compute) stream
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                h = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            h = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._handles.append((h, b))
+
+    def zero_grad(self):
+        """Zero the flat buckets (replaces optimizer.zero_grad(); keeps the grad views alive)."""
+        for b in self.buckets:
+            b['flat'].zero_()
+            b['pending'] = b['n']
+            for p in b['params']:
+                if p.grad is None or p.grad.data_ptr() < b['flat'].data_ptr() or \
+                        p.grad.data_ptr() >= b['flat'].data_ptr() + b['flat'].numel() * 4:
+                    raise RuntimeError('a parameter gradient was re-bound (zero_grad(set_to_none=True)?); use '
+                                       'BucketedGradAllReduce.zero_grad() instead of optimizer.zero_grad()')
+
+    def finish(self):
+        """Wait for every in-flight bucket and turn sums into means.  Call after backward()."""
+        for b in self.buckets:
+            if b['pending'] != 0 and self.world > 1:
+                # a parameter of this bucket got no gradient this step (should not happen for a fixed
+                # architecture); reduce what we have so that ranks stay in lock-step
+                self._launch(b)
+        for h, b in self._handles:
+            h.wait()
+        if self.on_gpu and self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self.world > 1:
+            inv = 1.0 / self.world
+            for b in self.buckets:
+                b['flat'].mul_(inv)
+        self._handles.clear()
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks.clear()
+
+
+def unused_parameters(model: torch.nn.Module):
+    """Parameters of the SVANet head that never receive a gradient (reference: grad None):
+    the gate MHA's out_proj (only its attention WEIGHTS are used) and the unused ``class_head``."""
+    out = []
+    for name, p in model.named_parameters():
+        if 'sketch_video_cross_attn.out_proj' in name or 'class_head' in name:
+            out.append(p)
+    return out
+
+
+def reduce_scalar_mean(t: torch.Tensor) -> torch.Tensor:
+    """reduce_tensor of the reference (lib/utils/comm.py:21-25): mean of a logged scalar over ranks."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return t.clone()
+    rt = t.detach().clone()
+    dist.all_reduce(rt, op=dist.ReduceOp.SUM)
+    rt /= dist.get_world_size()
+    return rt
