@@ -233,16 +233,27 @@ __global__ __launch_bounds__(256) void gate_bwd_ln_kernel(const float* __restric
         dacc = wave_sum(dacc);
         if (lane == 0) da[row] = dacc;
     }
+    __shared__ float red[2][GP * 256];
+    const int wave = threadIdx.x >> 6;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
 #pragma unroll
-    for (int j = 0; j < GP; ++j) {
-        const int c = (lane + 64 * j) * 4;
-        if (c < D) {
+            for (int j = 0; j < GP; ++j) {
+                const int c = (lane + 64 * j) * 4;
+                if (c < D) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                atomicAdd(dgamma + c + e, dg[j][e]);
-                atomicAdd(dbeta + c + e, db[j][e]);
+                    for (int e = 0; e < 4; ++e) {
+                        if (w == 0) { red[0][c + e] = dg[j][e]; red[1][c + e] = db[j][e]; }
+                        else { red[0][c + e] += dg[j][e]; red[1][c + e] += db[j][e]; }
+                    }
+                }
             }
         }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < D; c += 256) {
+        atomicAdd(dgamma + c, red[0][c]);
+        atomicAdd(dbeta + c, red[1][c]);
     }
 }
 
@@ -376,7 +387,7 @@ int svol_gate_bwd(const float* dy32, const void* dy, const void* dy2, const floa
     float* da = ws2;
     float* cc = ws2 + B * L;
     const int64_t M = B * L;
-    const int rpw1 = rows_per_wave(M, 4096);
+    const int rpw1 = rows_per_wave(M, 2048);
     const unsigned g1 = (unsigned)(((M + rpw1 - 1) / rpw1 + 3) / 4);
     const int rpw3 = rows_per_wave(L, 2048 / (B > 2048 ? 2048 : B) + 1);
     dim3 g3((unsigned)((L + 4 * rpw3 - 1) / (4 * rpw3)), (unsigned)B);

@@ -135,16 +135,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             }
         }
     }
+    // one set of atomics per WORKGROUP: the 4 waves' partial sums are combined in LDS first (every wave
+    // of every workgroup adding to the same D addresses is the contended-atomic worst case)
+    __shared__ float red[2][LN_MAX_PASSES * 256];
+    const int wave = threadIdx.x >> 6;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
 #pragma unroll
-    for (int j = 0; j < LN_MAX_PASSES; ++j) {
-        const int c = (lane + 64 * j) * 4;
-        if (c < D) {
+            for (int j = 0; j < LN_MAX_PASSES; ++j) {
+                const int c = (lane + 64 * j) * 4;
+                if (c < D) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                atomicAdd(dgamma + c + e, dg[j][e]);
-                atomicAdd(dbeta + c + e, db[j][e]);
+                    for (int e = 0; e < 4; ++e) {
+                        if (w == 0) { red[0][c + e] = dg[j][e]; red[1][c + e] = db[j][e]; }
+                        else { red[0][c + e] += dg[j][e]; red[1][c + e] += db[j][e]; }
+                    }
+                }
             }
         }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < D; c += 256) {
+        atomicAdd(dgamma + c, red[0][c]);
+        atomicAdd(dbeta + c, red[1][c]);
     }
 }
 
@@ -226,8 +239,8 @@ int svol_layernorm_bwd(const float* dy32, const void* dy, const void* dy2, const
     if (dtype != SVOL_BF16 && dtype != SVOL_F32) return SVOL_E_INVALID;
     if (M == 0) return SVOL_OK;
     const float inv_keep = 1.f / (1.f - dropout_p);
-    // ~4096 waves; each wave walks `rpw` consecutive rows and issues one set of atomics
-    int64_t rpw = (M + 4095) / 4096;
+    // ~2048 waves (512 workgroups); each wave walks `rpw` consecutive rows; one set of atomics per workgroup
+    int64_t rpw = (M + 2047) / 2048;
     if (rpw < 1) rpw = 1;
     const int64_t waves = (M + rpw - 1) / rpw;
     const unsigned grid = (unsigned)((waves + 3) / 4);

@@ -102,6 +102,7 @@ class SVANet(nn.Module):
                                'inputs to cuda (there is no CPU path — the CPU oracle lives under oracle/).')
         dt = self.compute_dtype
         d = self.transformer.d_model
+        ops.weights.new_epoch()  # re-cast every fp32 master weight once per forward (see ops._WeightCache)
         if self.training:
             self._step += 1
         vid = self._proj(self.input_video_proj, ops.cast_ag(src_video.float(), dt), 0)

@@ -240,8 +240,22 @@ def attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias=None):
 # optimizer bumps the tensor version.  One cast per weight per step.
 # ----------------------------------------------------------------------------
 class _WeightCache:
-    """The cached copies live ON the parameter object (attribute ``_svol_cache``) and are validated by
-    (tensor version, data pointer), so a freed-and-reallocated parameter can never alias a stale entry."""
+    """fp32 master weight -> compute-dtype copies (W and W^T).
+
+    The copies live ON the parameter object (attribute ``_svol_cache``).  They are refreshed whenever
+    the cache EPOCH advances — the model advances it at the start of every forward, so each weight is
+    cast exactly once per step — because tensor version counters cannot be trusted to see optimizer
+    updates (``torch.optim.AdamW(fused=True)`` rewrites parameters without bumping ``_version`` on
+    ROCm).  With ``static=True`` (frozen weights, e.g. serving) entries are validated by
+    (version, data pointer) instead."""
+
+    def __init__(self):
+        self.epoch = 0
+        self.static = False
+
+    def new_epoch(self):
+        if not self.static:
+            self.epoch += 1
 
     def get(self, w: torch.Tensor, dtype: torch.dtype):
         cache = getattr(w, '_svol_cache', None)
@@ -252,7 +266,7 @@ class _WeightCache:
             except Exception:  # pragma: no cover  (non-leaf views etc.: just do not cache)
                 pass
         ent = cache.get(dtype)
-        tag = (w._version, w.data_ptr())
+        tag = (self.epoch, w._version, w.data_ptr())
         if ent is None or ent[0] != tag:
             wd = w.detach()
             if dtype == torch.float32:

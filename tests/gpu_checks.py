@@ -412,7 +412,7 @@ def check_head_case(name, dtype):
       agrees.
     * parameter gradients vs the golden (only when the assignment agrees): per parameter, error relative
       to that parameter's largest gradient; parameters whose reference gradient is numerical noise
-      (< 1e-6 of the largest gradient in the model: the whole sketch/gate branch — LN1 is invariant to the
+      (< 1e-4 of the largest gradient in the model: the whole sketch/gate branch — LN1 is invariant to the
       gate's per-token scale — and layer 0's query self-attention weights) are compared on the global scale.
     """
     from types import SimpleNamespace
@@ -479,7 +479,7 @@ def check_head_case(name, dtype):
                 step = max(1, flat.numel() // 256)
                 got = flat[::step][:256]
                 ref = torch.from_numpy(z[f'gsample/{k}']).double()
-            scale = max(float(ref.abs().max()), 1e-6 * gmax)
+            scale = max(float(ref.abs().max()), 1e-4 * gmax)
             e = float((got - ref).abs().max()) / scale
             if e > worst:
                 worst, worst_key = e, k
