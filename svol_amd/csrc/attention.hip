@@ -19,7 +19,8 @@
 // dQ is produced by its own pass instead of fp32 atomics: with d_h = 32 there are only 64 FLOP per
 // atomic byte and the chip-wide atomic rate (~1.3 TB/s) would bound the kernel (guide, Guideline 12).
 //
-// Element types: bf16 -> v_mfma_f32_32x32x16_bf16, f32 -> v_mfma_f32_32x32x2_f32 (exact fp32).
+// Element types: this file's generic template serves f32 (v_mfma_f32_32x32x2_f32, exact fp32 — the parity
+// mode); bf16 (v_mfma_f32_32x32x16_bf16) is dispatched to the tuned kernels of attention_bf16.hip.
 // Softmax runs in the log2 domain with fp32 statistics; exp via v_exp_f32.
 #include "common.h"
 
@@ -186,7 +187,7 @@ template <typename T> struct Smem {
 
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[Smem<T>::NAT + Smem<T>::TR + 64 * 4];
     char* sK = smem;
     char* sVt = smem + Smem<T>::NAT;
@@ -288,7 +289,7 @@ __global__ void attn_delta_kernel(AttnArgs p) {
 
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * Smem<T>::NAT + Smem<T>::TR + 64 * 4];
     char* sK = smem;
     char* sV = smem + Smem<T>::NAT;
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * Smem<T>::NAT + 2 * Smem<T>::TR + 128 * 4];
     char* sQ = smem;
     char* sdO = smem + Smem<T>::NAT;
@@ -442,6 +443,15 @@ bool ld_ok(int64_t ld, int dtype) { return ld % (dtype == SVOL_BF16 ? 8 : 4) == 
 
 }  // namespace
 
+// bf16 fast path (attention_bf16.hip)
+int svol_attn_fwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
+                              int64_t ldo, float* lse2, const float* kbias, int B, int H, int Lq, int Lk, int dh, float scale,
+                              hipStream_t s);
+int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                              const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta,
+                              const float* kbias, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int B,
+                              int H, int Lq, int Lk, int dh, float scale, hipStream_t s);
+
 extern "C" {
 
 int svol_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
@@ -458,8 +468,10 @@ int svol_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const 
     p.B = (int)B; p.H = (int)H; p.Lq = (int)Lq; p.Lk = (int)Lk; p.dh = (int)dh; p.scale = scale;
     dim3 grid((unsigned)((Lq + 127) / 128), (unsigned)H, (unsigned)B);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == SVOL_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), 0, s, p);
+    if (dtype == SVOL_BF16)
+        return svol_attn_fwd_bf16_launch(q, ldq, k, ldk, v, ldv, o, ldo, lse2, kbias, (int)B, (int)H, (int)Lq, (int)Lk, (int)dh,
+                                         scale, s);
+    hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), 0, s, p);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }
@@ -487,15 +499,12 @@ int svol_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const 
     dim3 gd((unsigned)((total + 255) / 256));
     dim3 gq((unsigned)((Lq + 127) / 128), (unsigned)H, (unsigned)B);
     dim3 gk((unsigned)((Lk + 127) / 128), (unsigned)H, (unsigned)B);
-    if (dtype == SVOL_BF16) {
-        hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, gd, dim3(256), 0, s, p);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, gq, dim3(256), 0, s, p);
-        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<bf16_t>, gk, dim3(256), 0, s, p);
-    } else {
-        hipLaunchKernelGGL(attn_delta_kernel<float>, gd, dim3(256), 0, s, p);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, gq, dim3(256), 0, s, p);
-        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<float>, gk, dim3(256), 0, s, p);
-    }
+    if (dtype == SVOL_BF16)
+        return svol_attn_bwd_bf16_launch(q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse2, delta, kbias, dq, lddq, dk, lddk, dv,
+                                         lddv, (int)B, (int)H, (int)Lq, (int)Lk, (int)dh, scale, s);
+    hipLaunchKernelGGL(attn_delta_kernel<float>, gd, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, gq, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<float>, gk, dim3(256), 0, s, p);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }

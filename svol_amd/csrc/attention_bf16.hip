@@ -1,0 +1,506 @@
+// bf16 fast path of the attention core (gfx950): same "swapped product / accumulator-as-operand"
+// scheme as attention.hip, restructured after profiling the first version (rocprofv3 PMC: VALU issue,
+// not MFMA, bounds these kernels at d_h = 32 — 349 VALU instructions vs 16 MFMAs per 64-key tile):
+//
+//  * MFMA results stay in VGPRs (__launch_bounds__(256, 2) -> the compiler uses the VGPR form of
+//    v_mfma_f32_32x32x16_bf16; the first version spent 40 % of its VALU slots on v_accvgpr_read/write);
+//  * 128-row tiles, two LDS buffers, ONE barrier per tile; the next tile's global loads are issued
+//    before the MFMA/softmax work of the current tile and written to the other buffer afterwards;
+//  * a single row-major LDS image per operand serves both MFMA operand shapes: row reads
+//    (ds_read_b128, XOR-swizzled 16-byte chunks) for the product that contracts over d, and hardware
+//    transposed reads (ds_read_b64_tr_b16) for the product that contracts over the tile rows — no
+//    transposing LDS stores, no second copy;
+//  * softmax statistics in the raw-score domain with a LAZY rescale: O and l are rescaled only when
+//    some query of the wave raises its running maximum by more than 2^4 (exactness is unaffected: P is
+//    formed against the stale maximum and bf16's relative precision is scale free), exp2 arguments come
+//    from one FMA (score * scale*log2e - m), no separate scale or subtract pass;
+//  * backward: the 1/sqrt(d_h) factor of dS is applied once to the dQ / dK accumulators at the end.
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int KT = 128;            // rows per staged tile
+constexpr int IMG = KT * 64;       // bytes per image (32 bf16 per row)
+constexpr float LAZY_THR = 4.0f;   // log2 units
+
+struct Args {
+    const void *q, *k, *v, *o, *d_o;
+    void *out_o, *dq, *dk, *dv;
+    const float* kbias;
+    float *lse2, *delta;
+    int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+    int B, H, Lq, Lk, dh;
+    float scale;
+};
+
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+__device__ __forceinline__ int img_off(int row, int ch) { return row * 64 + ((ch ^ ((row >> 2) & 3)) << 4); }
+
+struct Stage { uint4 v[2]; };
+
+// 128 rows x 4 chunks = 512 chunks, 2 per thread
+__device__ __forceinline__ void load_regs(Stage& s, const bf16_t* g, int64_t ld, int row0, int limit, int dh, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i, row = c >> 2, ch = c & 3;
+        s.v[i] = (row0 + row < limit && ch * 8 < dh) ? *reinterpret_cast<const uint4*>(g + (int64_t)(row0 + row) * ld + ch * 8)
+                                                      : make_uint4(0, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void store_lds(char* img, const Stage& s, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i, row = c >> 2, ch = c & 3;
+        *reinterpret_cast<uint4*>(img + img_off(row, ch)) = s.v[i];
+    }
+}
+
+__device__ __forceinline__ void load_lane_block(uint4 (&out)[2], const bf16_t* g, int64_t ld, int row, bool valid, int dh,
+                                                int h) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int d0 = (2 * s + h) * 8;
+        out[s] = (valid && d0 < dh) ? *reinterpret_cast<const uint4*>(g + (int64_t)row * ld + d0) : make_uint4(0, 0, 0, 0);
+    }
+}
+
+// A operand, contraction over d: tile row `row`, k-step s covers d = 16s + 8h .. +7
+__device__ __forceinline__ void read_rows(uint4 (&a)[2], const char* img, int row, int h) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) a[s] = *reinterpret_cast<const uint4*>(img + img_off(row, 2 * s + h));
+}
+
+// A operand, contraction over the 32 rows of sub-tile `sub` (rows presented in the order of the first
+// product's accumulator registers): lane (r = lane&31 -> column d = r).  ds_read_b64_tr_b16 per 16-lane group:
+// lane 4q+p supplies the address of block row q, columns 4p..4p+3; lane i receives column i of the 4 rows.
+__device__ __forceinline__ void read_tr(uint4 (&a)[2], const char* img, int sub, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, hh = g >> 1;
+    const int ch = 2 * (g & 1) + (p >> 1), inner = 8 * (p & 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int r1 = 32 * sub + 16 * s + 4 * hh + q;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + img_off(r1, ch) + inner));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + img_off(r1 + 8, ch) + inner));
+        a[s] = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+}
+
+// v_max3_f32 without the canonicalising v_max_f32 x,x,x hipcc puts in front of fmaxf() on MFMA results
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+__device__ __forceinline__ f32x16 mma_first(const uint4 (&a)[2], const uint4 (&b)[2]) {
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[s]), __builtin_bit_cast(bf16x8, b[s]), acc, 0, 0,
+                                                      0);
+    return acc;
+}
+
+__device__ __forceinline__ void mma_second(f32x16& acc, const uint4 (&a)[2], const f32x16& x) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        bf16x8 b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = (bf16_t)x[8 * s + j];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[s]), b, acc, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void store_acc(const f32x16& acc, bf16_t* out, int64_t ld, int row, bool valid, int dh, int h,
+                                          float mul) {
+    if (!valid) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int d0 = 8 * g + 4 * h;
+        if (d0 < dh) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(acc[4 * g + e] * mul);
+            *reinterpret_cast<bf16x4*>(out + (int64_t)row * ld + d0) = v;
+        }
+    }
+}
+
+__device__ __forceinline__ void stage_bias(float* sb, const float* kb, int row0, int limit, int tid) {
+    if (tid < KT) {
+        const int key = row0 + tid;
+        sb[tid] = key < limit ? (kb ? kb[key] * LOG2E : 0.f) : -INFINITY;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// forward: lane = queries (32 per wave, 128 per workgroup), tiles over keys
+template <bool MASKED>
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16(Args p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * IMG + 2 * KT * 4];
+    char* sK = smem;                 // [2][IMG]
+    char* sV = smem + 2 * IMG;       // [2][IMG]
+    float* sB = reinterpret_cast<float*>(smem + 4 * IMG);  // [2][KT]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, hh = blockIdx.y;
+    const int qrow = blockIdx.x * 128 + wave * 32 + r;
+    const bool qvalid = qrow < p.Lq;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
+    const float* kb = p.kbias ? p.kbias + (int64_t)b * p.Lk : nullptr;
+    const float c = p.scale * LOG2E;
+
+    uint4 qb[2];
+    load_lane_block(qb, Q, p.ldq, qrow, qvalid, p.dh, h);
+
+    // running max m (raw-score domain when !MASKED, scaled log2 domain when MASKED), partial row sum l
+    float m = -INFINITY, l = 0.f;
+    f32x16 O = zero16();
+
+    const int nt = (p.Lk + KT - 1) / KT;
+    Stage sk, sv;
+    load_regs(sk, K, p.ldk, 0, p.Lk, p.dh, tid);
+    load_regs(sv, V, p.ldv, 0, p.Lk, p.dh, tid);
+    store_lds(sK, sk, tid);
+    store_lds(sV, sv, tid);
+    if (MASKED) stage_bias(sB, kb, 0, p.Lk, tid);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            load_regs(sk, K, p.ldk, (t + 1) * KT, p.Lk, p.dh, tid);
+            load_regs(sv, V, p.ldv, (t + 1) * KT, p.Lk, p.dh, tid);
+        }
+        const char* kimg = sK + cur * IMG;
+        const char* vimg = sV + cur * IMG;
+        const float* bias = sB + cur * KT;
+        // ---- scores of the whole 128-key tile first (8 MFMAs back to back), softmax once per tile:
+        // four independent 32-key chains give the VALU block ILP and amortise the max exchange / rescale
+        f32x16 S[4];
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            uint4 ka[2];
+            read_rows(ka, kimg, sub * 32 + r, h);
+            S[sub] = mma_first(ka, qb);
+        }
+        if (MASKED) {
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + sub * 32 + 8 * g + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) S[sub][4 * g + e] = S[sub][4 * g + e] * c + bb[e];
+                }
+        }
+        float ml[4];
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            float mm = max3(S[sub][0], S[sub][1], S[sub][2]);
+#pragma unroll
+            for (int i = 3; i < 15; i += 2) mm = max3(mm, S[sub][i], S[sub][i + 1]);
+            ml[sub] = max3(mm, S[sub][15], mm);
+        }
+        float mloc = max3(ml[0], ml[1], fmaxf(ml[2], ml[3]));
+        {   // other half-wave's maximum for the same query: v_permlane32_swap (VALU, no LDS round trip)
+            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc),
+                                                             __builtin_bit_cast(unsigned, mloc), false, false);
+            mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+        }
+        const float thr = MASKED ? LAZY_THR : LAZY_THR / c;
+        if (__any(mloc > m + thr)) {  // wave-uniform: rescale only when some query's maximum really moved
+            const float m_new = fmaxf(m, mloc);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(MASKED ? (m - m_use) : (m - m_use) * c);
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) O[i] *= alpha;
+            m = m_new;
+        }
+        const float m_use = (m == -INFINITY) ? 0.f : m;
+        const float mc = MASKED ? -m_use : -m_use * c;
+        float ls[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                S[sub][i] = __builtin_amdgcn_exp2f(MASKED ? S[sub][i] + mc : __builtin_fmaf(S[sub][i], c, mc));
+                ls[sub] += S[sub][i];
+            }
+        l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            uint4 va[2];
+            read_tr(va, vimg, sub, lane);
+            mma_second(O, va, S[sub]);
+        }
+        if (t + 1 < nt) {
+            store_lds(sK + (cur ^ 1) * IMG, sk, tid);
+            store_lds(sV + (cur ^ 1) * IMG, sv, tid);
+            if (MASKED) stage_bias(sB + (cur ^ 1) * KT, kb, (t + 1) * KT, p.Lk, tid);
+        }
+        __syncthreads();
+    }
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    bf16_t* Oo = reinterpret_cast<bf16_t*>(p.out_o) + (int64_t)b * p.Lq * p.ldo + hh * p.dh;
+    store_acc(O, Oo, p.ldo, qrow, qvalid, p.dh, h, inv);
+    if (qvalid && h == 0) {
+        const float m2 = MASKED ? m : m * c;  // scaled log2 domain
+        p.lse2[((int64_t)b * p.H + hh) * p.Lq + qrow] = m2 + __builtin_amdgcn_logf(lt);
+    }
+}
+
+__global__ void attn_delta_bf16(Args p) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)p.B * p.Lq * p.H;
+    if (idx >= total) return;
+    const int hh = (int)(idx % p.H);
+    const int64_t row = idx / p.H;
+    const int b = (int)(row / p.Lq), q = (int)(row % p.Lq);
+    const bf16_t* o = reinterpret_cast<const bf16_t*>(p.o) + row * p.ldo + hh * p.dh;
+    const bf16_t* d = reinterpret_cast<const bf16_t*>(p.d_o) + row * p.lddo + hh * p.dh;
+    float s = 0.f;
+    for (int i = 0; i < p.dh; i += 8) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(o + i), c = *reinterpret_cast<const bf16x8*>(d + i);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)c[e];
+    }
+    p.delta[((int64_t)b * p.H + hh) * p.Lq + q] = s;
+}
+
+// ---------------------------------------------------------------------------
+// dQ: lane = queries, tiles over keys.  dQ^T += K^T (P * (dP - delta)); scaled by 1/sqrt(dh) at the end.
+template <bool MASKED>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(Args p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * IMG + 2 * KT * 4];
+    char* sK = smem;
+    char* sV = smem + 2 * IMG;
+    float* sB = reinterpret_cast<float*>(smem + 4 * IMG);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, hh = blockIdx.y;
+    const int qrow = blockIdx.x * 128 + wave * 32 + r;
+    const bool qvalid = qrow < p.Lq;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
+    const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
+    const float* kb = p.kbias ? p.kbias + (int64_t)b * p.Lk : nullptr;
+    const float c = p.scale * LOG2E;
+
+    uint4 qb[2], dob[2];
+    load_lane_block(qb, Q, p.ldq, qrow, qvalid, p.dh, h);
+    load_lane_block(dob, dO, p.lddo, qrow, qvalid, p.dh, h);
+    const int64_t sidx = ((int64_t)b * p.H + hh) * p.Lq + qrow;
+    const float nlse = qvalid ? -p.lse2[sidx] : -INFINITY;  // exp2(x - inf) = 0 for rows past Lq
+    const float dl = qvalid ? p.delta[sidx] : 0.f;
+
+    f32x16 dQ = zero16();
+    const int nt = (p.Lk + KT - 1) / KT;
+    Stage sk, sv;
+    load_regs(sk, K, p.ldk, 0, p.Lk, p.dh, tid);
+    load_regs(sv, V, p.ldv, 0, p.Lk, p.dh, tid);
+    store_lds(sK, sk, tid);
+    store_lds(sV, sv, tid);
+    if (MASKED) stage_bias(sB, kb, 0, p.Lk, tid);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            load_regs(sk, K, p.ldk, (t + 1) * KT, p.Lk, p.dh, tid);
+            load_regs(sv, V, p.ldv, (t + 1) * KT, p.Lk, p.dh, tid);
+        }
+        const char* kimg = sK + cur * IMG;
+        const char* vimg = sV + cur * IMG;
+        const float* bias = sB + cur * KT;
+#pragma unroll 2
+        for (int sub = 0; sub < 4; ++sub) {
+            uint4 a[2];
+            read_rows(a, kimg, sub * 32 + r, h);
+            f32x16 S = mma_first(a, qb);
+            read_rows(a, vimg, sub * 32 + r, h);
+            const f32x16 dP = mma_first(a, dob);
+            if (MASKED) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + sub * 32 + 8 * g + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(S[4 * g + e], c, bb[e] + nlse));
+                        S[4 * g + e] = pe * (dP[4 * g + e] - dl);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(S[i], c, nlse));
+                    S[i] = pe * (dP[i] - dl);
+                }
+            }
+            read_tr(a, kimg, sub, lane);
+            mma_second(dQ, a, S);
+        }
+        if (t + 1 < nt) {
+            store_lds(sK + (cur ^ 1) * IMG, sk, tid);
+            store_lds(sV + (cur ^ 1) * IMG, sv, tid);
+            if (MASKED) stage_bias(sB + (cur ^ 1) * KT, kb, (t + 1) * KT, p.Lk, tid);
+        }
+        __syncthreads();
+    }
+    bf16_t* dQo = reinterpret_cast<bf16_t*>(p.dq) + (int64_t)b * p.Lq * p.lddq + hh * p.dh;
+    store_acc(dQ, dQo, p.lddq, qrow, qvalid, p.dh, h, p.scale);
+}
+
+// ---------------------------------------------------------------------------
+// dK, dV: lane = keys, tiles over queries.
+template <bool KBIAS>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(Args p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * IMG + 4 * KT * 4];
+    char* sQ = smem;
+    char* sdO = smem + 2 * IMG;
+    float* sL = reinterpret_cast<float*>(smem + 4 * IMG);  // [2][KT] -lse2
+    float* sD = sL + 2 * KT;                               // [2][KT] delta
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, hh = blockIdx.y;
+    const int krow = blockIdx.x * 128 + wave * 32 + r;
+    const bool kvalid = krow < p.Lk;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
+    const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
+    const float c = p.scale * LOG2E;
+    const float kbl = kvalid ? (p.kbias ? p.kbias[(int64_t)b * p.Lk + krow] * LOG2E : 0.f) : -INFINITY;
+    const float* lse_g = p.lse2 + ((int64_t)b * p.H + hh) * p.Lq;
+    const float* dl_g = p.delta + ((int64_t)b * p.H + hh) * p.Lq;
+
+    uint4 kbk[2], vbk[2];
+    load_lane_block(kbk, K, p.ldk, krow, kvalid, p.dh, h);
+    load_lane_block(vbk, V, p.ldv, krow, kvalid, p.dh, h);
+
+    f32x16 dK = zero16(), dV = zero16();
+    const int nt = (p.Lq + KT - 1) / KT;
+    Stage sq, sdo;
+    float rl = 0.f, rd = 0.f;
+    auto load_stats = [&](int row0) {
+        if (tid < KT) {
+            const int qi = row0 + tid;
+            rl = qi < p.Lq ? -lse_g[qi] : -INFINITY;  // exp2(x - inf) = 0 for rows past Lq
+            rd = qi < p.Lq ? dl_g[qi] : 0.f;
+        }
+    };
+    auto store_stats = [&](int buf) {
+        if (tid < KT) { sL[buf * KT + tid] = rl; sD[buf * KT + tid] = rd; }
+    };
+    load_regs(sq, Q, p.ldq, 0, p.Lq, p.dh, tid);
+    load_regs(sdo, dO, p.lddo, 0, p.Lq, p.dh, tid);
+    load_stats(0);
+    store_lds(sQ, sq, tid);
+    store_lds(sdO, sdo, tid);
+    store_stats(0);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            load_regs(sq, Q, p.ldq, (t + 1) * KT, p.Lq, p.dh, tid);
+            load_regs(sdo, dO, p.lddo, (t + 1) * KT, p.Lq, p.dh, tid);
+            load_stats((t + 1) * KT);
+        }
+        const char* qimg = sQ + cur * IMG;
+        const char* doimg = sdO + cur * IMG;
+        const float* nl = sL + cur * KT;
+        const float* dd = sD + cur * KT;
+#pragma unroll 1
+        for (int sub = 0; sub < 4; ++sub) {
+            uint4 a[2];
+            read_rows(a, qimg, sub * 32 + r, h);
+            f32x16 S = mma_first(a, kbk);  // S[q][key]
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 ls = *reinterpret_cast<const f32x4*>(nl + sub * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    S[4 * g + e] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[4 * g + e], c, KBIAS ? kbl + ls[e] : ls[e]));
+            }
+            read_tr(a, doimg, sub, lane);
+            mma_second(dV, a, S);  // dV^T += dO^T P
+            read_rows(a, doimg, sub * 32 + r, h);
+            const f32x16 dP = mma_first(a, vbk);  // dP[q][key] = dO V^T
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 dl = *reinterpret_cast<const f32x4*>(dd + sub * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S[4 * g + e] = S[4 * g + e] * (dP[4 * g + e] - dl[e]);
+            }
+            read_tr(a, qimg, sub, lane);
+            mma_second(dK, a, S);  // dK^T += Q^T dS
+        }
+        if (t + 1 < nt) {
+            store_lds(sQ + (cur ^ 1) * IMG, sq, tid);
+            store_lds(sdO + (cur ^ 1) * IMG, sdo, tid);
+            store_stats(cur ^ 1);
+        }
+        __syncthreads();
+    }
+    bf16_t* dKo = reinterpret_cast<bf16_t*>(p.dk) + (int64_t)b * p.Lk * p.lddk + hh * p.dh;
+    bf16_t* dVo = reinterpret_cast<bf16_t*>(p.dv) + (int64_t)b * p.Lk * p.lddv + hh * p.dh;
+    store_acc(dK, dKo, p.lddk, krow, kvalid, p.dh, h, p.scale);
+    store_acc(dV, dVo, p.lddv, krow, kvalid, p.dh, h, 1.f);
+}
+
+}  // namespace
+
+// entry points used by attention.hip's C-ABI functions
+int svol_attn_fwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
+                              int64_t ldo, float* lse2, const float* kbias, int B, int H, int Lq, int Lk, int dh, float scale,
+                              hipStream_t s) {
+    Args p{};
+    p.q = q; p.k = k; p.v = v; p.out_o = o; p.lse2 = lse2; p.kbias = kbias;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+    p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.dh = dh; p.scale = scale;
+    dim3 grid((unsigned)((Lq + 127) / 128), (unsigned)H, (unsigned)B);
+    const bool masked = kbias != nullptr || (Lk % KT) != 0;
+    if (masked) hipLaunchKernelGGL(attn_fwd_bf16<true>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(attn_fwd_bf16<false>, grid, dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
+}
+
+int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                              const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta,
+                              const float* kbias, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int B,
+                              int H, int Lq, int Lk, int dh, float scale, hipStream_t s) {
+    Args p{};
+    p.q = q; p.k = k; p.v = v; p.o = o; p.d_o = d_o; p.lse2 = const_cast<float*>(lse2); p.delta = delta; p.kbias = kbias;
+    p.dq = dq; p.dk = dk; p.dv = dv;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
+    p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.dh = dh; p.scale = scale;
+    const int64_t total = (int64_t)B * Lq * H;
+    dim3 gd((unsigned)((total + 255) / 256));
+    dim3 gq((unsigned)((Lq + 127) / 128), (unsigned)H, (unsigned)B);
+    dim3 gk((unsigned)((Lk + 127) / 128), (unsigned)H, (unsigned)B);
+    const bool masked = kbias != nullptr || (Lk % KT) != 0;
+    hipLaunchKernelGGL(attn_delta_bf16, gd, dim3(256), 0, s, p);
+    if (masked) hipLaunchKernelGGL(attn_bwd_dq_bf16<true>, gq, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(attn_bwd_dq_bf16<false>, gq, dim3(256), 0, s, p);
+    if (masked) hipLaunchKernelGGL(attn_bwd_dkdv_bf16<true>, gk, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(attn_bwd_dkdv_bf16<false>, gk, dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
+}

@@ -39,7 +39,7 @@ struct NtArgs {
 
 // TC = element type of C and of the residual (T, or float for the fp32 residual stream)
 template <typename T, typename TC>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs p) {
     constexpr int EPC = Tr<T>::EPC;
     constexpr int BK = 8 * EPC;
     __shared__ __attribute__((aligned(16))) char smem[2 * 128 * 128];
@@ -156,7 +156,7 @@ template <> struct TnCfg<bf16_t> { static constexpr int CT = 64, STRIDE = 288, C
 template <> struct TnCfg<float> { static constexpr int CT = 32, STRIDE = 576, CPR = 32; };
 
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
     constexpr int EPC = Tr<T>::EPC;
     constexpr int CT = TnCfg<T>::CT, S = TnCfg<T>::STRIDE, CPR = TnCfg<T>::CPR;
     __shared__ __attribute__((aligned(16))) char smem[2 * CT * S];

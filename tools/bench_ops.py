@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the hot kernels at the benchmark (cfg2) shapes, timed with HIP events.
+    python tools/bench_ops.py [attn] [gemm] [ln] [--iters N]
+"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from svol_amd import ops
+
+DEV = 'cuda'
+B, H, L, DH, D, F, NQ = 8, 8, 6272, 32, 256, 2048, 100
+ITERS = 10
+for i, a in enumerate(sys.argv):
+    if a == '--iters':
+        ITERS = int(sys.argv[i + 1])
+which = [a for a in sys.argv[1:] if not a.startswith('--') and not a.isdigit()] or ['attn', 'gemm', 'ln']
+
+
+def timeit(fn, iters=ITERS, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def rnd(*shape, dt=torch.bfloat16, scale=1.0):
+    return (torch.randn(*shape, device=DEV) * scale).to(dt)
+
+
+if 'attn' in which:
+    for dt in (torch.bfloat16,):
+        qkv = rnd(B * L, 3 * D, dt=dt)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        o, lse = ops.attn_fwd(q, k, v, B, H, L, L, DH)
+        do = rnd(B * L, D, dt=dt)
+        dqkv = torch.empty_like(qkv)
+        t = timeit(lambda: ops.attn_fwd(q, k, v, B, H, L, L, DH))
+        fl = 4.0 * L * L * D * B
+        print(f'attn_fwd  {dt}: {t:.3f} ms  {fl / t / 1e9:.1f} TFLOP/s (algorithmic 4L^2dB)')
+        t = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, B, H, L, L, DH, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]))
+        print(f'attn_bwd  {dt}: {t:.3f} ms  {2 * fl / t / 1e9:.1f} TFLOP/s (algorithmic 2x fwd)')
+        # cross attention shape
+        qc = rnd(B * NQ, D, dt=dt)
+        kb = torch.zeros(B, L, device=DEV)
+        t = timeit(lambda: ops.attn_fwd(qc, k, v, B, H, NQ, L, DH, kb))
+        print(f'cross_attn_fwd (Lq=100): {t:.3f} ms')
+
+if 'gemm' in which:
+    M = B * L
+    for (n, kk, name) in [(2 * D, D, 'qk proj'), (D, D, 'v/out proj'), (F, D, 'fc1'), (D, F, 'fc2'), (D, 512, 'in proj0')]:
+        A = rnd(M, kk)
+        W = rnd(n, kk, scale=0.05)
+        bias = torch.zeros(n, device=DEV)
+        t = timeit(lambda: ops.gemm_nt(A, W, bias))
+        print(f'gemm_nt {name:12s} M={M} N={n} K={kk}: {t:.3f} ms  {2.0 * M * n * kk / t / 1e9:.1f} TFLOP/s')
+        dY = rnd(M, n)
+        t = timeit(lambda: ops.gemm_tn(dY, A))
+        print(f'gemm_tn {name:12s} Mc={M} N={n} K={kk}: {t:.3f} ms  {2.0 * M * n * kk / t / 1e9:.1f} TFLOP/s')
+    X = rnd(M, F)
+    t = timeit(lambda: ops.colsum(X))
+    print(f'colsum [{M},{F}]: {t:.3f} ms  {X.numel() * 2 / t / 1e6:.0f} GB/s')
+    t = timeit(lambda: ops.act_bwd(X, X, ops.ACT_GELU))
+    print(f'act_bwd gelu [{M},{F}]: {t:.3f} ms  {X.numel() * 6 / t / 1e6:.0f} GB/s')
+
+if 'ln' in which:
+    M = B * L
+    x = torch.randn(M, D, device=DEV)
+    g, b_ = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
+    pos = rnd(M, D)
+    t = timeit(lambda: ops.layernorm_fwd(x, g, b_, torch.bfloat16, pos, want32=True))
+    print(f'ln_fwd [{M},{D}] fp32->fp32+2bf16: {t:.3f} ms  {M * D * (4 + 4 + 2 + 2 + 2) / t / 1e6:.0f} GB/s')
+    y32, y, yp, mean, rstd = ops.layernorm_fwd(x, g, b_, torch.bfloat16, pos, want32=True)
+    t = timeit(lambda: ops.layernorm_bwd(x, y, yp, x, g, mean, rstd, torch.bfloat16, want32=True))
+    print(f'ln_bwd [{M},{D}]: {t:.3f} ms  {M * D * (4 + 2 + 2 + 4 + 4 + 2) / t / 1e6:.0f} GB/s')
