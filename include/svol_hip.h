@@ -65,6 +65,12 @@ int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, co
                  void* C, int64_t ldc, const float* bias, int act, void* pre_act_out, int64_t ldp,
                  const void* residual, int64_t ldr, int out_f32, int64_t M, int64_t N, int64_t K, int dtype,
                  void* stream);
+/* Fused MLP backward step: C[M,N] = (A[M,K] * B[N,K]^T) .* gelu'(pre[M,N]);  colsum[N] (fp32, may be NULL,
+ * caller zeroes) += column sums of C (= the fc1 bias gradient).  Replaces dh = ds W2, dpre = dh *
+ * gelu'(pre), db1 = sum(dpre) of the MLP backward (cross_modal_transformer.py:163-179). */
+int svol_gemm_nt_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                       const void* pre, int64_t ldp, float* colsum, int64_t M, int64_t N, int64_t K, int dtype,
+                       void* stream);
 /* dW[N,K] (fp32, ld = ldc) (+)= A[Mc,N]^T * B[Mc,K]   (contraction over the Mc rows; weight gradient).
  * The output is accumulated with fp32 atomics: the caller zeroes C first unless it wants accumulation. */
 int svol_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t Mc,
@@ -86,11 +92,12 @@ int svol_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float
                        void* ypos, const void* pos, int64_t pos_rows, float* mean, float* rstd, int64_t M, int64_t D,
                        float dropout_p, uint64_t seed, int dtype, void* stream);
 /* dx = LN'(dy32 + dy + dy2) (each may be NULL, not all); outputs dx32 (fp32) and/or dx (dtype);
- * dgamma/dbeta (fp32) accumulated with atomics (caller zeroes). */
+ * dgamma/dbeta (fp32) accumulated with atomics (caller zeroes).  dx_colsum (fp32 [D], may be NULL,
+ * caller zeroes) += column sums of dx — the bias gradient of the Linear that produced LN's input. */
 int svol_layernorm_bwd(const float* dy32, const void* dy, const void* dy2, const void* x, int x_f32,
                        const float* gamma, const float* mean, const float* rstd, float* dx32, void* dx,
-                       float* dgamma, float* dbeta, int64_t M, int64_t D, float dropout_p, uint64_t seed, int dtype,
-                       void* stream);
+                       float* dgamma, float* dbeta, float* dx_colsum, int64_t M, int64_t D, float dropout_p,
+                       uint64_t seed, int dtype, void* stream);
 
 /* ---- sine positional encoding (position_encoding.py:51-71) -------------- */
 /* mask [B,L] float (1 = valid) -> pos [B,L,D] (dtype). */

@@ -327,6 +327,11 @@ inline int grid_1d(int64_t n, int block) {
 
 }  // namespace
 
+// bf16 fast path (gemm_bf16.hip)
+int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
+                           int act, void* pre, int64_t ldp, const void* res, int64_t ldr, int out_f32, const void* aux,
+                           int64_t ldaux, float* colsum, int epi, int64_t M, int64_t N, int64_t K, hipStream_t s);
+
 extern "C" {
 
 int svol_abi_version(void) { return 1; }
@@ -356,6 +361,11 @@ int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, co
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
     if (grid.y > 65535u) return SVOL_E_UNSUPPORTED;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == SVOL_BF16 && !A2) {
+        const int rc = svol_gemm_nt_bf16_fast(A, lda, B, ldb, C, ldc, bias, act, pre_act_out, ldp, residual, ldr, out_f32, nullptr,
+                                              0, nullptr, 0, M, N, K, s);
+        if (rc != SVOL_E_UNSUPPORTED) return rc;
+    }
     if (dtype == SVOL_BF16) {
         if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, p);
@@ -364,6 +374,27 @@ int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, co
     }
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
+}
+
+int svol_gemm_nt_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* pre,
+                       int64_t ldp, float* colsum, int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
+    if (!A || !B || !C || !pre || M < 0 || N < 0 || K <= 0) return SVOL_E_INVALID;
+    if (M == 0 || N == 0) return SVOL_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == SVOL_BF16) {
+        const int rc = svol_gemm_nt_bf16_fast(A, lda, B, ldb, C, ldc, nullptr, SVOL_ACT_NONE, nullptr, 0, nullptr, 0, 0, pre, ldp,
+                                              colsum, 1, M, N, K, s);
+        if (rc != SVOL_E_UNSUPPORTED) return rc;
+    }
+    // generic composition (f32 / odd shapes): GEMM, then dpre = dh * gelu'(pre) in place, then column sums
+    if (ldc != N || ldp != N) return SVOL_E_UNSUPPORTED;
+    int rc = svol_gemm_nt(A, lda, nullptr, 0, B, ldb, C, ldc, nullptr, SVOL_ACT_NONE, nullptr, 0, nullptr, 0, 0, M, N, K, dtype,
+                          stream);
+    if (rc) return rc;
+    rc = svol_act_bwd(C, pre, C, SVOL_ACT_GELU, M * N, dtype, stream);
+    if (rc) return rc;
+    if (colsum) rc = svol_colsum(C, ldc, colsum, M, N, dtype, stream);
+    return rc;
 }
 
 int svol_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t Mc, int64_t N,

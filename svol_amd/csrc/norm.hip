@@ -75,16 +75,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx32,
                                                      T* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int64_t M, int D, float p,
-                                                     float inv_keep, uint64_t seed, int rows_per_wave) {
+                                                     float* __restrict__ dbeta, float* __restrict__ dxsum, int64_t M, int D,
+                                                     float p, float inv_keep, uint64_t seed, int rows_per_wave) {
     const int lane = threadIdx.x & 63;
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t r0 = wave_id * rows_per_wave;
-    float dg[LN_MAX_PASSES][4], db[LN_MAX_PASSES][4];
+    float dg[LN_MAX_PASSES][4], db[LN_MAX_PASSES][4], dxs[LN_MAX_PASSES][4];
 #pragma unroll
     for (int j = 0; j < LN_MAX_PASSES; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { dg[j][e] = 0.f; db[j][e] = 0.f; }
+        for (int e = 0; e < 4; ++e) { dg[j][e] = 0.f; db[j][e] = 0.f; dxs[j][e] = 0.f; }
 
     for (int64_t row = r0; row < r0 + rows_per_wave && row < M; ++row) {
         const float mu = mean[row], rs = rstd[row];
@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float r = rs * (g[j][e] - s1 - xh[j][e] * s2);
+                    dxs[j][e] += r;
                     o.set(e, r);
                     o32.set(e, r);
                 }
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
     // one set of atomics per WORKGROUP: the 4 waves' partial sums are combined in LDS first (every wave
     // of every workgroup adding to the same D addresses is the contended-atomic worst case)
-    __shared__ float red[2][LN_MAX_PASSES * 256];
+    __shared__ float red[3][LN_MAX_PASSES * 256];
     const int wave = threadIdx.x >> 6;
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
@@ -147,8 +148,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 if (c < D) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (w == 0) { red[0][c + e] = dg[j][e]; red[1][c + e] = db[j][e]; }
-                        else { red[0][c + e] += dg[j][e]; red[1][c + e] += db[j][e]; }
+                        if (w == 0) { red[0][c + e] = dg[j][e]; red[1][c + e] = db[j][e]; red[2][c + e] = dxs[j][e]; }
+                        else { red[0][c + e] += dg[j][e]; red[1][c + e] += db[j][e]; red[2][c + e] += dxs[j][e]; }
                     }
                 }
             }
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int c = threadIdx.x; c < D; c += 256) {
         atomicAdd(dgamma + c, red[0][c]);
         atomicAdd(dbeta + c, red[1][c]);
+        if (dxsum) atomicAdd(dxsum + c, red[2][c]);
     }
 }
 
@@ -230,8 +232,8 @@ int svol_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float
 }
 
 int svol_layernorm_bwd(const float* dy32, const void* dy, const void* dy2, const void* x, int x_f32, const float* gamma,
-                       const float* mean, const float* rstd, float* dx32, void* dx, float* dgamma, float* dbeta, int64_t M,
-                       int64_t D, float dropout_p, uint64_t seed, int dtype, void* stream) {
+                       const float* mean, const float* rstd, float* dx32, void* dx, float* dgamma, float* dbeta,
+                       float* dx_colsum, int64_t M, int64_t D, float dropout_p, uint64_t seed, int dtype, void* stream) {
     if ((!dy32 && !dy && !dy2) || !x || !gamma || !mean || !rstd || (!dx && !dx32) || !dgamma || !dbeta || M < 0 || D <= 0)
         return SVOL_E_INVALID;
     if (D % 4 || D > LN_MAX_PASSES * 256) return SVOL_E_UNSUPPORTED;
@@ -247,13 +249,13 @@ int svol_layernorm_bwd(const float* dy32, const void* dy, const void* dy2, const
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SVOL_BF16 && x_f32)
         hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, dy32, (const bf16_t*)dy, (const bf16_t*)dy2,
-                           (const float*)x, gamma, mean, rstd, dx32, (bf16_t*)dx, dgamma, dbeta, M, (int)D, dropout_p, inv_keep, seed, (int)rpw);
+                           (const float*)x, gamma, mean, rstd, dx32, (bf16_t*)dx, dgamma, dbeta, dx_colsum, M, (int)D, dropout_p, inv_keep, seed, (int)rpw);
     else if (dtype == SVOL_BF16)
         hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, dy32, (const bf16_t*)dy, (const bf16_t*)dy2,
-                           (const bf16_t*)x, gamma, mean, rstd, dx32, (bf16_t*)dx, dgamma, dbeta, M, (int)D, dropout_p, inv_keep, seed, (int)rpw);
+                           (const bf16_t*)x, gamma, mean, rstd, dx32, (bf16_t*)dx, dgamma, dbeta, dx_colsum, M, (int)D, dropout_p, inv_keep, seed, (int)rpw);
     else
         hipLaunchKernelGGL((ln_bwd_kernel<float, float>), dim3(grid), dim3(256), 0, s, dy32, (const float*)dy, (const float*)dy2,
-                           (const float*)x, gamma, mean, rstd, dx32, (float*)dx, dgamma, dbeta, M, (int)D, dropout_p, inv_keep, seed, (int)rpw);
+                           (const float*)x, gamma, mean, rstd, dx32, (float*)dx, dgamma, dbeta, dx_colsum, M, (int)D, dropout_p, inv_keep, seed, (int)rpw);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }

@@ -142,6 +142,18 @@ def gemm_tn(A, B, out=None):
     return out
 
 
+def gemm_nt_dgelu(A, B, pre, want_colsum=True):
+    """(A @ B^T) * gelu'(pre), and its column sums (fp32) — fused MLP backward step."""
+    M, K = A.shape
+    N = B.shape[0]
+    out = torch.empty((M, N), dtype=A.dtype, device=A.device)
+    cs = torch.zeros((N,), dtype=torch.float32, device=A.device) if want_colsum else None
+    rc = _lib.lib().svol_gemm_nt_dgelu(_ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), out.stride(0), _ptr(pre),
+                                       pre.stride(0), _ptr(cs), M, N, K, _dt(A), _stream())
+    _lib.check(rc, 'svol_gemm_nt_dgelu')
+    return out, cs
+
+
 def colsum(X, out=None):
     assert X.dim() == 2 and X.stride(1) == 1
     M, N = X.shape
@@ -181,8 +193,10 @@ def layernorm_fwd(x, gamma, beta, dtype, pos=None, p=0.0, seed=0, want32=False, 
     return y32, y, ypos, mean, rstd
 
 
-def layernorm_bwd(dy32, dy, dy2, x, gamma, mean, rstd, dtype, p=0.0, seed=0, want32=False, want_t=True):
-    """LN backward; any of dy32 (fp32) / dy / dy2 (`dtype`) may be None.  Returns (dx32|None, dx|None, dg, db)."""
+def layernorm_bwd(dy32, dy, dy2, x, gamma, mean, rstd, dtype, p=0.0, seed=0, want32=False, want_t=True,
+                  want_colsum=False):
+    """LN backward; any of dy32 (fp32) / dy / dy2 (`dtype`) may be None.  Returns (dx32|None, dx|None, dg, db)
+    (+ the column sums of dx when want_colsum: the bias gradient of the Linear feeding this LN)."""
     M, D = x.shape
     x_f32 = 1 if (x.dtype == torch.float32 and dtype != torch.float32) else 0
     cont = lambda t: None if t is None else t.reshape(M, D).contiguous()
@@ -191,12 +205,14 @@ def layernorm_bwd(dy32, dy, dy2, x, gamma, mean, rstd, dtype, p=0.0, seed=0, wan
     assert (dy is None or dy.dtype == dtype) and (dy2 is None or dy2.dtype == dtype)
     dx32 = torch.empty((M, D), dtype=torch.float32, device=x.device) if want32 else None
     dx = torch.empty((M, D), dtype=dtype, device=x.device) if want_t else None
-    dg = torch.zeros((D,), dtype=torch.float32, device=x.device)
-    db = torch.zeros((D,), dtype=torch.float32, device=x.device)
+    red = torch.zeros((3, D), dtype=torch.float32, device=x.device)  # one memset for dgamma | dbeta | colsum(dx)
+    dg, db, cs = red[0], red[1], (red[2] if want_colsum else None)
     rc = _lib.lib().svol_layernorm_bwd(_ptr(dy32), _ptr(dy), _ptr(dy2), _ptr(x), x_f32, _ptr(gamma), _ptr(mean),
-                                       _ptr(rstd), _ptr(dx32), _ptr(dx), _ptr(dg), _ptr(db), M, D, float(p), int(seed),
-                                       _DT[dtype], _stream())
+                                       _ptr(rstd), _ptr(dx32), _ptr(dx), _ptr(dg), _ptr(db), _ptr(cs), M, D, float(p),
+                                       int(seed), _DT[dtype], _stream())
     _lib.check(rc, 'svol_layernorm_bwd')
+    if want_colsum:
+        return dx32, dx, dg, db, cs
     return dx32, dx, dg, db
 
 
@@ -404,14 +420,11 @@ class MLPLNFn(torch.autograd.Function):
         dpos = None
         if ctx.pos_shape is not None and ctx.needs_input_grad[8] and dypos is not None:
             dpos = _pos_grad(dypos, ctx.pos_shape, D)
-        ds32, ds, dg, dbt = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True)
+        ds32, ds, dg, dbt, db2 = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True,
+                                               want_colsum=True)
         dW2 = gemm_tn(ds, hid)
-        db2 = colsum(ds)
-        dh = gemm_nt(ds, ctx.W2T)
-        dpre = act_bwd(dh, pre, ACT_GELU)
-        del dh
+        dpre, db1 = gemm_nt_dgelu(ds, ctx.W2T, pre)  # (ds W2) * gelu'(pre) and its column sums, one kernel
         dW1 = gemm_tn(dpre, x2)
-        db1 = colsum(dpre)
         dx = gemm_nt(dpre, ctx.W1T)
         return ds32.view(ctx.shp), dx.view(ctx.shp), dW1, db1, dW2, db2, dg, dbt, dpos
 
@@ -465,9 +478,9 @@ class AttnLNFn(torch.autograd.Function):
         dpos = None
         if ctx.pos_shape is not None and ctx.needs_input_grad[11] and dypos is not None:
             dpos = _pos_grad(dypos, ctx.pos_shape, d)
-        ds32, g, dg, dbt = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True)
+        ds32, g, dg, dbt, dbo = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True,
+                                              want_colsum=True)
         dWo = gemm_tn(g, o)
-        dbo = colsum(g)
         do = gemm_nt(g, WoT)
         dW_in = torch.zeros((3 * d, d), dtype=torch.float32, device=g.device)
         db_in = torch.zeros((3 * d,), dtype=torch.float32, device=g.device)

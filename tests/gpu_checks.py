@@ -83,6 +83,21 @@ def check_gemm_nt():
     return res
 
 
+def check_gemm_dgelu():
+    res = {}
+    for dt in DTYPES:
+        for (M, N, K) in [(300, 256, 64), (1000, 2048, 256), (130, 64, 128), (77, 96, 32)]:
+            A, W = _rnd((M, K), dt, 50), _rnd((N, K), dt, 51, 1.0 / math.sqrt(K))
+            pre = _rnd((M, N), dt, 52)
+            out, cs = ops.gemm_nt_dgelu(A.to(DEV), W.to(DEV), pre.to(DEV))
+            p64 = pre.double().requires_grad_(True)
+            O.gelu_erf(p64).sum().backward()
+            ref = (A.double() @ W.double().t()) * p64.grad
+            res[f'gemm_dgelu/{dt}/{M}x{N}x{K}/out'] = (rel_err(out, ref), TOL[dt])
+            res[f'gemm_dgelu/{dt}/{M}x{N}x{K}/colsum'] = (rel_err(cs, ref.sum(0)), 1e-4 if dt == torch.float32 else 1e-2)
+    return res
+
+
 def check_gemm_tn():
     res = {}
     for dt in DTYPES:
@@ -155,8 +170,10 @@ def check_layernorm():
                 res[f'ln_fwd/{tag}/y'] = (rel_err(y, yr), TOL[dt])
                 res[f'ln_fwd/{tag}/ypos'] = (rel_err(ypos, ypr), TOL[dt])
                 (yr * (dy.double() + dy32.double()) + ypr * dyp.double()).sum().backward()
-                dx32, dx, dg, db = ops.layernorm_bwd(dy32.to(DEV), dy.to(DEV), dyp.to(DEV), x.to(DEV), g.to(DEV), mean,
-                                                     rstd, dt, want32=True)
+                dx32, dx, dg, db, cs = ops.layernorm_bwd(dy32.to(DEV), dy.to(DEV), dyp.to(DEV), x.to(DEV), g.to(DEV), mean,
+                                                         rstd, dt, want32=True, want_colsum=True)
+                res[f'ln_bwd/{tag}/dx_colsum'] = (float((cs.cpu().double() - x64.grad.sum(0)).abs().max()) /
+                                                  float(x64.grad.abs().max() * math.sqrt(M)), 2e-5 if dt == torch.float32 else 1e-2)
                 res[f'ln_bwd/{tag}/dx32'] = (rel_err(dx32, x64.grad), TOL[dt] if not x_f32 else 2e-5 + (0 if dt == torch.float32 else 1e-2))
                 res[f'ln_bwd/{tag}/dx'] = (rel_err(dx, x64.grad), TOL[dt])
                 res[f'ln_bwd/{tag}/dgamma'] = (rel_err(dg, g64.grad), 1e-4 if dt == torch.float32 else 1e-2)

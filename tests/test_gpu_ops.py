@@ -27,6 +27,10 @@ def test_gemm_nt(G):
     _assert(G.check_gemm_nt())
 
 
+def test_gemm_nt_dgelu_fused(G):
+    _assert(G.check_gemm_dgelu())
+
+
 def test_gemm_tn(G):
     _assert(G.check_gemm_tn())
 

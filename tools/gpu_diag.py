@@ -17,7 +17,7 @@ from tests.helpers import load_golden  # noqa: E402
 def main():
     filt = sys.argv[1:]
     groups = [
-        ('gemm_nt', G.check_gemm_nt), ('gemm_tn', G.check_gemm_tn), ('small', G.check_small_ops),
+        ('gemm_nt', G.check_gemm_nt), ('gemm_dgelu', G.check_gemm_dgelu), ('gemm_tn', G.check_gemm_tn), ('small', G.check_small_ops),
         ('layernorm', G.check_layernorm), ('posenc', G.check_posenc), ('attention', G.check_attention),
         ('gate', G.check_gate), ('lsap', G.check_lsap_vs_scipy),
     ]
