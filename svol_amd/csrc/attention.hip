@@ -29,9 +29,6 @@ namespace {
 constexpr float LOG2E = 1.4426950408889634f;
 
 template <typename T> struct AT;
-template <> struct AT<bf16_t> {
-    static constexpr int EPC = 8, NA = 2, CPR = 4, NAT_ROW = 64, TR_STRIDE = 64 * 2 + 8;
-};
 template <> struct AT<float> {
     static constexpr int EPC = 4, NA = 4, CPR = 8, NAT_ROW = 128, TR_STRIDE = 64 * 4 + 16;
 };

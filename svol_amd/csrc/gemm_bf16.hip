@@ -16,6 +16,8 @@
 //    coalesced side;
 //  * fused backward epilogue: out = acc * gelu'(pre) plus per-column sums (the bias gradient), which
 //    removes a 205 MB read-modify-write pass and a column-sum pass per MLP.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -27,8 +29,18 @@ struct FastArgs {
     int M, N, K, act, epi;
 };
 
-constexpr int STAGE = 16384;         // one 128 x 64 bf16 operand tile
 constexpr int EP_STRIDE = 272;       // bytes per staged accumulator row (64 floats + 16 pad)
+
+// LDS operand image: 128 rows of BK bf16 (BK*2 bytes), 16-byte chunks permuted so that the ds_read_b128
+// fragment reads of a 16x16x32 MFMA (lanes: row = lane&15, chunk = lane>>4) are bank-conflict free.
+template <int BK> __device__ __forceinline__ int slot_of(int row, int ch) {
+    if constexpr (BK == 64) {
+        return ch ^ (row & 7);
+    } else {
+        const int rh = (row >> 2) & 3;
+        return ch ^ ((0x78 >> (2 * rh)) & 3);  // g(rh) = {0,2,3,1}: the 16 lanes of every ds_read_b128 group hit 16 distinct slots
+    }
+}
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 template <typename TC> struct Out4;
@@ -49,9 +61,16 @@ template <> struct Out4<bf16_t> {
     }
 };
 
-template <typename TC>
-__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(FastArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * STAGE];
+template <typename TC, int BK>
+__device__ __forceinline__ void gemm_nt_bf16_body(const FastArgs& p) {
+    constexpr int RB = BK * 2;                 // bytes per image row
+    constexpr int CPR = RB / 16;               // chunks per row
+    constexpr int STAGE = 128 * RB;            // one operand tile
+    constexpr int RPI = 1024 / RB;             // rows per 1-KiB wave DMA instruction
+    constexpr int NI = STAGE / 1024 / 4;       // DMA instructions per wave per operand per stage
+    constexpr int EPB = 4 * 16 * EP_STRIDE;    // epilogue staging bytes (4 waves x 16 rows)
+    constexpr int SMEM = (4 * STAGE > EPB) ? 4 * STAGE : EPB;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -63,12 +82,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(FastArgs p) {
         (void*)(p.A + (int64_t)bm * p.lda), 0, (int)(((int64_t)rowsA * p.lda) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.B + (int64_t)bn * p.ldb), 0, (int)(((int64_t)rowsB * p.ldb) * 2), 0x00020000);
-    // lane -> (row within an 8-row group, source chunk): LDS slot (lane&7) of row (lane>>3) holds chunk slot^row
-    const int lrow = lane >> 3, lch = (lane & 7) ^ lrow;
-    int voffA[4], voffB[4];
+    // the LDS side of an LDS-DMA is lane-linear (slot lane%CPR of row lane/CPR): permute the SOURCE chunk instead.
+    // slot_of is an involution in ch for a fixed row, so the chunk stored in slot s is slot_of(row, s).
+    int voffA[NI], voffB[NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + lrow;
+    for (int i = 0; i < NI; ++i) {
+        const int row = (wave * NI + i) * RPI + lane / CPR;
+        const int lch = slot_of<BK>(row, lane % CPR);
         voffA[i] = (int)(((int64_t)row * p.lda + lch * 8) * 2);
         voffB[i] = (int)(((int64_t)row * p.ldb + lch * 8) * 2);
     }
@@ -76,9 +96,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(FastArgs p) {
         char* sa = smem + stage * STAGE;
         char* sb = smem + (2 + stage) * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(sa + (wave * 4 + i) * 1024), 16, voffA[i], k0 * 2, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_ptr)(sb + (wave * 4 + i) * 1024), 16, voffB[i], k0 * 2, 0, 0);
+        for (int i = 0; i < NI; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(sa + (wave * NI + i) * 1024), 16, voffA[i], k0 * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_ptr)(sb + (wave * NI + i) * 1024), 16, voffB[i], k0 * 2, 0, 0);
         }
     };
 
@@ -89,22 +109,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(FastArgs p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fq = lane >> 4;
-    const int nk = p.K / 64;
+    const int nk = p.K / BK;
     issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();  // waits for this stage's DMA (vmcnt(0)) and for everyone to be done with the other stage
-        if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * 64);
+        if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * BK);
         const char* sa = smem + (kt & 1) * STAGE;
         const char* sb = smem + (2 + (kt & 1)) * STAGE;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < BK / 32; ++g) {
             uint4 mf[4], nf[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int rowM = wm * 64 + t * 16 + fr;
-                mf[t] = *reinterpret_cast<const uint4*>(sa + rowM * 128 + (((4 * g + fq) ^ (rowM & 7)) << 4));
+                mf[t] = *reinterpret_cast<const uint4*>(sa + rowM * RB + (slot_of<BK>(rowM, 4 * g + fq) << 4));
                 const int rowN = wn * 64 + t * 16 + fr;
-                nf[t] = *reinterpret_cast<const uint4*>(sb + rowN * 128 + (((4 * g + fq) ^ (rowN & 7)) << 4));
+                nf[t] = *reinterpret_cast<const uint4*>(sb + rowN * RB + (slot_of<BK>(rowN, 4 * g + fq) << 4));
             }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
@@ -115,9 +135,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(FastArgs p) {
         }
     }
 
-    // ---- epilogue through LDS: two passes of 32 rows per wave --------------------------------------
+    // ---- epilogue through LDS: four passes of 16 rows per wave -------------------------------------
     __syncthreads();
-    char* st = smem + wave * (32 * EP_STRIDE);
+    char* st = smem + wave * (16 * EP_STRIDE);
     const int cq = lane & 15, rq = lane >> 4;           // coalesced side: 4 columns cq*4.., rows rq, rq+4, ...
     const int ncol = bn + wn * 64 + cq * 4;
     const bool colv = ncol + 4 <= p.N;                  // fast vector path for this lane's 4 columns
@@ -130,19 +150,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(FastArgs p) {
     TC* C = reinterpret_cast<TC*>(p.C);
     const TC* R = reinterpret_cast<const TC*>(p.res);
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < 4; ++pass) {
 #pragma unroll
-        for (int ml = 0; ml < 2; ++ml) {
-            const int mt = pass * 2 + ml;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                *reinterpret_cast<f32x4*>(st + (ml * 16 + fr) * EP_STRIDE + (nt * 16 + fq * 4) * 4) = acc[nt][mt];
-        }
+        for (int nt = 0; nt < 4; ++nt)
+            *reinterpret_cast<f32x4*>(st + fr * EP_STRIDE + (nt * 16 + fq * 4) * 4) = acc[nt][pass];
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < 4; ++it) {
             const int rl = it * 4 + rq;
-            const int m = bm + wm * 64 + pass * 32 + rl;
+            const int m = bm + wm * 64 + pass * 16 + rl;
             f32x4 v = *reinterpret_cast<const f32x4*>(st + rl * EP_STRIDE + cq * 16);
             if (m < p.M) {
                 if (p.epi == 0) {
@@ -211,6 +227,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(FastArgs p) {
     }
 }
 
+// concrete kernels (one per output type x K-step)
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_f32_k64(FastArgs p) { gemm_nt_bf16_body<float, 64>(p); }
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_b16_k64(FastArgs p) { gemm_nt_bf16_body<bf16_t, 64>(p); }
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_f32_k32(FastArgs p) { gemm_nt_bf16_body<float, 32>(p); }
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_b16_k32(FastArgs p) { gemm_nt_bf16_body<bf16_t, 32>(p); }
+
 }  // namespace
 
 // launcher used by gemm.hip's C-ABI entry points.  Returns SVOL_E_UNSUPPORTED when the shape does not
@@ -218,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(FastArgs p) {
 int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
                            int act, void* pre, int64_t ldp, const void* res, int64_t ldr, int out_f32, const void* aux,
                            int64_t ldaux, float* colsum, int epi, int64_t M, int64_t N, int64_t K, hipStream_t s) {
-    if (K % 64 || lda % 8 || ldb % 8 || !aligned16(A) || !aligned16(B)) return SVOL_E_UNSUPPORTED;
+    if (K % 32 || lda % 8 || ldb % 8 || !aligned16(A) || !aligned16(B)) return SVOL_E_UNSUPPORTED;
     // vector epilogue needs 8-byte (bf16) / 16-byte (f32) aligned rows; otherwise the scalar tail path is used per lane
     if ((int64_t)128 * lda * 2 >= (1ll << 31) || (int64_t)128 * ldb * 2 >= (1ll << 31)) return SVOL_E_UNSUPPORTED;
     const int celt = out_f32 ? 4 : 2;
@@ -230,7 +252,16 @@ int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ld
                lda, ldb, ldc, ldp, ldr, ldaux, (int)M, (int)N, (int)K, act, epi};
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
     if (grid.y > 65535u) return SVOL_E_UNSUPPORTED;
-    if (out_f32) hipLaunchKernelGGL(gemm_nt_bf16_kernel<float>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(gemm_nt_bf16_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+    // K-step 32 keeps the two-stage ring at 32 KiB per workgroup (4-5 workgroups per CU hide the DMA latency of the
+    // short K = 256 loops); deep-K launches use 64-deep steps (half the barriers)
+    static const int force_bk = getenv("SVOL_GEMM_BK") ? atoi(getenv("SVOL_GEMM_BK")) : 0;
+    const bool bk64 = force_bk ? (force_bk == 64) : (K % 64 == 0 && K >= 1024);
+    if (bk64 && K % 64 == 0) {
+        if (out_f32) hipLaunchKernelGGL(gemm_nt_bf16_f32_k64, grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(gemm_nt_bf16_b16_k64, grid, dim3(256), 0, s, p);
+    } else {
+        if (out_f32) hipLaunchKernelGGL(gemm_nt_bf16_f32_k32, grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(gemm_nt_bf16_b16_k32, grid, dim3(256), 0, s, p);
+    }
     return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
 }
