@@ -73,6 +73,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the captured hipGraph (N=1)')
     ap.add_argument('--batch', type=int, default=8, help='videos per GPU')
     a = ap.parse_args()
 
@@ -102,7 +103,8 @@ def main():
     crit = build_loss(args).to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
     reducer = parallel.BucketedGradAllReduce(params, skip=parallel.unused_parameters(model))
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, fused=True)  # train.py:98-99
+    use_graph = world == 1 and not a.no_graph
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, fused=True, capturable=use_graph)  # train.py:98-99
     # weak scaling: every rank gets its own B videos (different seeds = a properly sharded global batch)
     inp = {k: v.to(dev) for k, v in syn.synth_inputs(args, B, T, P, seed=1 + rank).items()}
     tg = syn.synth_targets(B, T, seed=1 + rank)
@@ -118,9 +120,20 @@ def main():
         opt.step()
         return loss
 
+    if use_graph:
+        # N = 1: the whole step is captured once in a hipGraph (svol_amd/graph.py); every timed step still
+        # re-stages the inputs and re-flattens the targets on the host, then replays
+        from svol_amd.graph import GraphedTrainStep
+        gstep = GraphedTrainStep(model, crit, opt, reducer, inp, tg)
+        eager_step = step
+
+        def step():  # noqa: F811
+            return gstep(inp, tg)[0]
+
     for _ in range(a.warmup):
         loss = step()
-    ops.timer.enable(['attn_fwd', 'attn_bwd'])
+    if not use_graph:
+        ops.timer.enable(['attn_fwd', 'attn_bwd'])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -133,6 +146,16 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.timer.disable()
+    if use_graph:
+        # per-kernel durations cannot be bracketed inside a graph replay: time the SAME kernels with HIP events on
+        # the launch stream over eager steps run right after the timed region (same process, same shapes, same data)
+        crit.static_packed = None
+        model.step_dev = None
+        ops.timer.enable(['attn_fwd', 'attn_bwd'])
+        for _ in range(max(3, min(a.steps, 10))):
+            eager_step()
+        torch.cuda.synchronize()
+        ops.timer.disable()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -176,6 +199,7 @@ def main():
                                    'criterion + bwd (+RCCL grad all-reduce) + AdamW' % B,
                        'global_batch': B * world, 'parallelism': f'dp{world}'},
             'final_loss': final_loss,
+            'launch_mode': 'hipGraph replay (whole step captured)' if use_graph else 'eager',
         }
         if roof:
             res['roofline'] = roof

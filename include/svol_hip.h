@@ -85,19 +85,21 @@ int svol_act_bwd(const void* dy, const void* aux, void* dpre, int act, int64_t n
  * the kernel emits the fp32 value (y32, feeds the next residual add) and the compute-dtype copies the
  * GEMMs consume (y, and ypos = y + pos).  Any of y32 / y may be NULL (not both); ypos/pos go together.
  * pos has `pos_rows` rows and is indexed row % pos_rows so a [N,d] query embedding broadcasts over
- * the batch.  Dropout (p, seed) is a stateless counter-based mask applied to LN's output.  mean/rstd
+ * the batch.  Dropout (p, seed) is a stateless counter-based mask applied to LN's output; the effective
+ * seed is seed + *seed_offset_dev (device int64, may be NULL) so that a captured hipGraph draws a fresh
+ * mask on every replay.  mean/rstd
  * fp32 [M] are saved for backward.  nn.LayerNorm + nn.Dropout of svanet.py:168-178; post-norms
  * cross_modal_transformer.py:127-158. */
 int svol_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float* beta, float* y32, void* y,
                        void* ypos, const void* pos, int64_t pos_rows, float* mean, float* rstd, int64_t M, int64_t D,
-                       float dropout_p, uint64_t seed, int dtype, void* stream);
+                       float dropout_p, uint64_t seed, const int64_t* seed_offset_dev, int dtype, void* stream);
 /* dx = LN'(dy32 + dy + dy2) (each may be NULL, not all); outputs dx32 (fp32) and/or dx (dtype);
  * dgamma/dbeta (fp32) accumulated with atomics (caller zeroes).  dx_colsum (fp32 [D], may be NULL,
  * caller zeroes) += column sums of dx — the bias gradient of the Linear that produced LN's input. */
 int svol_layernorm_bwd(const float* dy32, const void* dy, const void* dy2, const void* x, int x_f32,
                        const float* gamma, const float* mean, const float* rstd, float* dx32, void* dx,
                        float* dgamma, float* dbeta, float* dx_colsum, int64_t M, int64_t D, float dropout_p,
-                       uint64_t seed, int dtype, void* stream);
+                       uint64_t seed, const int64_t* seed_offset_dev, int dtype, void* stream);
 
 /* ---- sine positional encoding (position_encoding.py:51-71) -------------- */
 /* mask [B,L] float (1 = valid) -> pos [B,L,D] (dtype). */

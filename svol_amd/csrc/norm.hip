@@ -14,7 +14,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
                                                      const float* __restrict__ beta, float* __restrict__ y32,
                                                      T* __restrict__ y, T* __restrict__ ypos, const T* __restrict__ pos,
                                                      int64_t pos_rows, float* __restrict__ mean, float* __restrict__ rstd,
-                                                     int64_t M, int D, float p, float inv_keep, uint64_t seed) {
+                                                     int64_t M, int D, float p, float inv_keep, uint64_t seed0,
+                                                     const int64_t* __restrict__ soff) {
+    const uint64_t seed = seed0 + (soff ? ((uint64_t)soff[0] << 8) : 0ull);  // device-side step counter (same stride as the host-side one): graph replays draw fresh masks
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -76,7 +78,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ rstd, float* __restrict__ dx32,
                                                      T* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, float* __restrict__ dxsum, int64_t M, int D,
-                                                     float p, float inv_keep, uint64_t seed, int rows_per_wave) {
+                                                     float p, float inv_keep, uint64_t seed0, const int64_t* __restrict__ soff, int rows_per_wave) {
+    const uint64_t seed = seed0 + (soff ? ((uint64_t)soff[0] << 8) : 0ull);
     const int lane = threadIdx.x & 63;
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t r0 = wave_id * rows_per_wave;
@@ -207,7 +210,7 @@ extern "C" {
 
 int svol_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float* beta, float* y32, void* y,
                        void* ypos, const void* pos, int64_t pos_rows, float* mean, float* rstd, int64_t M, int64_t D,
-                       float dropout_p, uint64_t seed, int dtype, void* stream) {
+                       float dropout_p, uint64_t seed, const int64_t* seed_offset_dev, int dtype, void* stream) {
     if (!x || !gamma || !beta || (!y && !y32) || !mean || !rstd || M < 0 || D <= 0) return SVOL_E_INVALID;
     if ((ypos != nullptr) != (pos != nullptr)) return SVOL_E_INVALID;
     if (pos && pos_rows <= 0) return SVOL_E_INVALID;
@@ -220,20 +223,21 @@ int svol_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SVOL_BF16 && x_f32)
         hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, (const float*)x, gamma, beta, y32,
-                           (bf16_t*)y, (bf16_t*)ypos, (const bf16_t*)pos, pos_rows, mean, rstd, M, (int)D, dropout_p, inv_keep, seed);
+                           (bf16_t*)y, (bf16_t*)ypos, (const bf16_t*)pos, pos_rows, mean, rstd, M, (int)D, dropout_p, inv_keep, seed, seed_offset_dev);
     else if (dtype == SVOL_BF16)
         hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, y32,
-                           (bf16_t*)y, (bf16_t*)ypos, (const bf16_t*)pos, pos_rows, mean, rstd, M, (int)D, dropout_p, inv_keep, seed);
+                           (bf16_t*)y, (bf16_t*)ypos, (const bf16_t*)pos, pos_rows, mean, rstd, M, (int)D, dropout_p, inv_keep, seed, seed_offset_dev);
     else
         hipLaunchKernelGGL((ln_fwd_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)x, gamma, beta, y32,
-                           (float*)y, (float*)ypos, (const float*)pos, pos_rows, mean, rstd, M, (int)D, dropout_p, inv_keep, seed);
+                           (float*)y, (float*)ypos, (const float*)pos, pos_rows, mean, rstd, M, (int)D, dropout_p, inv_keep, seed, seed_offset_dev);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }
 
 int svol_layernorm_bwd(const float* dy32, const void* dy, const void* dy2, const void* x, int x_f32, const float* gamma,
                        const float* mean, const float* rstd, float* dx32, void* dx, float* dgamma, float* dbeta,
-                       float* dx_colsum, int64_t M, int64_t D, float dropout_p, uint64_t seed, int dtype, void* stream) {
+                       float* dx_colsum, int64_t M, int64_t D, float dropout_p, uint64_t seed, const int64_t* seed_offset_dev,
+                       int dtype, void* stream) {
     if ((!dy32 && !dy && !dy2) || !x || !gamma || !mean || !rstd || (!dx && !dx32) || !dgamma || !dbeta || M < 0 || D <= 0)
         return SVOL_E_INVALID;
     if (D % 4 || D > LN_MAX_PASSES * 256) return SVOL_E_UNSUPPORTED;
@@ -249,13 +253,13 @@ int svol_layernorm_bwd(const float* dy32, const void* dy, const void* dy2, const
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SVOL_BF16 && x_f32)
         hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, dy32, (const bf16_t*)dy, (const bf16_t*)dy2,
-                           (const float*)x, gamma, mean, rstd, dx32, (bf16_t*)dx, dgamma, dbeta, dx_colsum, M, (int)D, dropout_p, inv_keep, seed, (int)rpw);
+                           (const float*)x, gamma, mean, rstd, dx32, (bf16_t*)dx, dgamma, dbeta, dx_colsum, M, (int)D, dropout_p, inv_keep, seed, seed_offset_dev, (int)rpw);
     else if (dtype == SVOL_BF16)
         hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, dy32, (const bf16_t*)dy, (const bf16_t*)dy2,
-                           (const bf16_t*)x, gamma, mean, rstd, dx32, (bf16_t*)dx, dgamma, dbeta, dx_colsum, M, (int)D, dropout_p, inv_keep, seed, (int)rpw);
+                           (const bf16_t*)x, gamma, mean, rstd, dx32, (bf16_t*)dx, dgamma, dbeta, dx_colsum, M, (int)D, dropout_p, inv_keep, seed, seed_offset_dev, (int)rpw);
     else
         hipLaunchKernelGGL((ln_bwd_kernel<float, float>), dim3(grid), dim3(256), 0, s, dy32, (const float*)dy, (const float*)dy2,
-                           (const float*)x, gamma, mean, rstd, dx32, (float*)dx, dgamma, dbeta, dx_colsum, M, (int)D, dropout_p, inv_keep, seed, (int)rpw);
+                           (const float*)x, gamma, mean, rstd, dx32, (float*)dx, dgamma, dbeta, dx_colsum, M, (int)D, dropout_p, inv_keep, seed, seed_offset_dev, (int)rpw);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }

@@ -34,6 +34,9 @@ class SetCriterion(nn.Module):
                 raise AssertionError(f'do you really want to compute {l_} loss?')
         self.last_match = None
         self.last_packed = None
+        # optional StaticPackedTargets (svol_amd.graph): when set, `targets` passed to forward() are ignored and
+        # the pre-loaded static buffers are used (hipGraph capture / replay)
+        self.static_packed = None
 
     def forward(self, outputs, targets):
         if self.sketch_head == 'sketch_detr':
@@ -49,7 +52,7 @@ class SetCriterion(nn.Module):
             raise RuntimeError('svol_amd.SetCriterion runs on the MI355X only (no CPU fallback)')
         NL, B, N = logits_all.shape[:3]
         m = self.matcher
-        packed = m.pack(targets, NL, B, N, logits_all.device)
+        packed = self.static_packed if self.static_packed is not None else m.pack(targets, NL, B, N, logits_all.device)
         losses, match = ops.SetCriterionFn.apply(logits_all, boxes_all, packed, m.cost_bbox, m.cost_giou,
                                                  m.cost_class, self.eos_coef)
         self.last_match, self.last_packed = match, packed

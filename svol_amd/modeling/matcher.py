@@ -108,6 +108,55 @@ class PackedTargets:
         return out
 
 
+class StaticPackedTargets:
+    """PackedTargets with FIXED-CAPACITY device buffers that are refilled in place (``load``), so that the
+    matcher / criterion kernels can be captured in a hipGraph: the launch geometry (number of LSAP problems,
+    LDS size, cost-buffer size) depends only on (matcher, layers, B, N, frames) and the capacity, while the
+    per-batch box counts / offsets / coordinates live in device memory the kernels read at run time."""
+
+    def __init__(self, matcher: str, n_layers: int, B: int, N: int, num_frames: int, q_per_frame: int, device,
+                 max_boxes_per_video: int = 128):
+        self.matcher, self.n_layers, self.B, self.N, self.T, self.q = matcher, n_layers, B, N, num_frames, q_per_frame
+        self.device = device
+        self.cap_video = int(max_boxes_per_video)
+        P1 = B if matcher == 'video_matcher' else B * num_frames
+        self.problems_per_layer = P1
+        self.n_problems = P1 * n_layers
+        if matcher == 'video_matcher':
+            self.max_dim = max(N, self.cap_video)
+            self.cost_numel = self.n_problems * N * self.cap_video
+        else:
+            self.max_dim = max(q_per_frame, self.cap_video)
+            self.cost_numel = n_layers * B * N * self.cap_video  # sum over frames of q * m_t <= N * boxes per video
+        self._i32 = torch.zeros((4, self.n_problems), dtype=torch.int32, device=device)
+        self.pred_off, self.pred_cnt, self.tgt_off, self.tgt_cnt = self._i32[0], self._i32[1], self._i32[2], self._i32[3]
+        self.cost_off = torch.zeros((self.n_problems,), dtype=torch.int64, device=device)
+        self.tgt_boxes = torch.zeros((B * self.cap_video, 4), dtype=torch.float32, device=device)
+        self.status = torch.zeros((self.n_problems,), dtype=torch.int32, device=device)
+        self.rebase_vid_off = (torch.zeros((B,), dtype=torch.int32, device=device)
+                               if matcher == 'per_frame_matcher' else None)
+        self.vid_off = np.zeros(B, np.int64)
+        self.last_cost = None
+
+    def load(self, targets):
+        """Flatten `targets` on the host (same traversal as PackedTargets) and refill the device buffers."""
+        tmp = PackedTargets(targets, self.matcher, self.n_layers, self.B, self.N, self.T, self.q, 'cpu')
+        if max(tmp.per_video) > self.cap_video:
+            raise ValueError(f'a video has {max(tmp.per_video)} boxes, capacity is {self.cap_video}')
+        assert tmp.n_problems == self.n_problems and tmp.cost_numel <= self.cost_numel
+        self._i32.copy_(torch.stack([tmp.pred_off, tmp.pred_cnt, tmp.tgt_off, tmp.tgt_cnt]), non_blocking=True)
+        self.cost_off.copy_(tmp.cost_off, non_blocking=True)
+        nb = tmp.tgt_boxes.shape[0]
+        self.tgt_boxes[:nb].copy_(tmp.tgt_boxes, non_blocking=True)
+        if self.rebase_vid_off is not None:
+            self.rebase_vid_off.copy_(tmp.rebase_vid_off, non_blocking=True)
+        self.vid_off = tmp.vid_off
+        self.per_video, self.per_frame, self.total_boxes = tmp.per_video, tmp.per_frame, tmp.total_boxes
+
+    check_status = PackedTargets.check_status
+    indices_from_match = PackedTargets.indices_from_match
+
+
 class _DeviceMatcher(nn.Module):
     kind = None
 

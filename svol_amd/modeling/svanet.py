@@ -44,10 +44,10 @@ class LinearLayer(nn.Module):
             self.LayerNorm = nn.LayerNorm(in_hsz)
         self.net = nn.Sequential(nn.Dropout(dropout), nn.Linear(in_hsz, out_hsz))
 
-    def forward(self, x, seed=0, out_f32=False):
+    def forward(self, x, seed=0, out_f32=False, seed_dev=None):
         p = self.p if self.training else 0.0
         if self.layer_norm:
-            x = ops.layer_norm(x, self.LayerNorm.weight, self.LayerNorm.bias, p, seed)
+            x = ops.layer_norm(x, self.LayerNorm.weight, self.LayerNorm.bias, p, seed, seed_dev)
         elif p > 0.0:
             raise NotImplementedError('dropout without LayerNorm is not on the reference path')
         lin = self.net[1]
@@ -87,12 +87,16 @@ class SVANet(nn.Module):
         self.compute_dtype = _DTYPES[compute_dtype]
         self._step = 0
         self.base_seed = 1
+        # device-side step counter added to the dropout seed (svol_amd.graph advances it inside a captured
+        # hipGraph so that every replay draws a fresh mask); None = host-side counter only
+        self.step_dev = None
 
     def _proj(self, seq, x, salt):
         """input projection; the last layer emits fp32 (start of the fp32 residual stream)."""
         n = len(seq)
         for j, layer in enumerate(seq):
-            x = layer(x, seed=(self.base_seed << 32) + (self._step << 8) + salt * 16 + j, out_f32=(j == n - 1))
+            x = layer(x, seed=(self.base_seed << 32) + (self._step << 8) + salt * 16 + j, out_f32=(j == n - 1),
+                      seed_dev=self.step_dev)
         return x
 
     def forward(self, src_sketch, src_sketch_mask, src_video, src_video_mask):

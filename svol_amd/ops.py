@@ -172,7 +172,7 @@ def act_bwd(dy, aux, act):
     return out
 
 
-def layernorm_fwd(x, gamma, beta, dtype, pos=None, p=0.0, seed=0, want32=False, want_t=True):
+def layernorm_fwd(x, gamma, beta, dtype, pos=None, p=0.0, seed=0, want32=False, want_t=True, seed_dev=None):
     """x [M,D] (fp32 residual stream or `dtype`) -> (y32 | None, y | None, ypos | None, mean, rstd)."""
     x = x.contiguous()
     M, D = x.shape
@@ -188,13 +188,13 @@ def layernorm_fwd(x, gamma, beta, dtype, pos=None, p=0.0, seed=0, want32=False, 
         assert pos.dtype == dtype and pos.shape[-1] == D
     rc = _lib.lib().svol_layernorm_fwd(_ptr(x), x_f32, _ptr(gamma), _ptr(beta), _ptr(y32), _ptr(y), _ptr(ypos),
                                        _ptr(pos), pos.numel() // D if pos is not None else 0, _ptr(mean), _ptr(rstd),
-                                       M, D, float(p), int(seed), _DT[dtype], _stream())
+                                       M, D, float(p), int(seed), _ptr(seed_dev), _DT[dtype], _stream())
     _lib.check(rc, 'svol_layernorm_fwd')
     return y32, y, ypos, mean, rstd
 
 
 def layernorm_bwd(dy32, dy, dy2, x, gamma, mean, rstd, dtype, p=0.0, seed=0, want32=False, want_t=True,
-                  want_colsum=False):
+                  want_colsum=False, seed_dev=None):
     """LN backward; any of dy32 (fp32) / dy / dy2 (`dtype`) may be None.  Returns (dx32|None, dx|None, dg, db)
     (+ the column sums of dx when want_colsum: the bias gradient of the Linear feeding this LN)."""
     M, D = x.shape
@@ -209,7 +209,7 @@ def layernorm_bwd(dy32, dy, dy2, x, gamma, mean, rstd, dtype, p=0.0, seed=0, wan
     dg, db, cs = red[0], red[1], (red[2] if want_colsum else None)
     rc = _lib.lib().svol_layernorm_bwd(_ptr(dy32), _ptr(dy), _ptr(dy2), _ptr(x), x_f32, _ptr(gamma), _ptr(mean),
                                        _ptr(rstd), _ptr(dx32), _ptr(dx), _ptr(dg), _ptr(db), _ptr(cs), M, D, float(p),
-                                       int(seed), _DT[dtype], _stream())
+                                       int(seed), _ptr(seed_dev), _DT[dtype], _stream())
     _lib.check(rc, 'svol_layernorm_bwd')
     if want_colsum:
         return dx32, dx, dg, db, cs
@@ -314,23 +314,23 @@ class LayerNormFn(torch.autograd.Function):
     """y = dropout(LN(x)), compute dtype in / out (input projections, svanet.py:168-178)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, p, seed):
+    def forward(ctx, x, gamma, beta, p, seed, seed_dev):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
-        _, y, _, mean, rstd = layernorm_fwd(x2, gamma, beta, x.dtype, None, p, seed)
-        ctx.save_for_backward(x2, gamma, mean, rstd)
+        _, y, _, mean, rstd = layernorm_fwd(x2, gamma, beta, x.dtype, None, p, seed, seed_dev=seed_dev)
+        ctx.save_for_backward(x2, gamma, mean, rstd, seed_dev)
         ctx.p, ctx.seed, ctx.shp = p, seed, shp
         return y.view(shp)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, gamma, mean, rstd = ctx.saved_tensors
-        _, dx, dg, db = layernorm_bwd(None, dy, None, x2, gamma, mean, rstd, x2.dtype, ctx.p, ctx.seed)
-        return dx.view(ctx.shp), dg, db, None, None
+        x2, gamma, mean, rstd, seed_dev = ctx.saved_tensors
+        _, dx, dg, db = layernorm_bwd(None, dy, None, x2, gamma, mean, rstd, x2.dtype, ctx.p, ctx.seed, seed_dev=seed_dev)
+        return dx.view(ctx.shp), dg, db, None, None, None
 
 
-def layer_norm(x, gamma, beta, p=0.0, seed=0):
-    return LayerNormFn.apply(x, gamma, beta, p, seed)
+def layer_norm(x, gamma, beta, p=0.0, seed=0, seed_dev=None):
+    return LayerNormFn.apply(x, gamma, beta, p, seed, seed_dev)
 
 
 class LinearFn(torch.autograd.Function):
