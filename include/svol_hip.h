@@ -53,18 +53,20 @@ int svol_cast(const void* src, int dtype_src, void* dst, int dtype_dst, int64_t 
 int svol_cast_transpose(const float* src, void* dst, void* dstT, int dtype, int64_t R, int64_t C, void* stream);
 
 /* ---- GEMMs (nn.Linear and its backward) --------------------------------- */
-/* C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]) + residual[M,N]
+/* C[M,N] = act((A[M,K] * B[N,K]^T + bias[N]) * colscale[N]) + residual[M,N]
  *   A2/n_split: output columns n >= n_split read their A operand from A2 instead of A
  *               (fused q/k-with-pos vs v-without-pos projection, cross_modal_transformer.py:137-138);
  *               pass A2=NULL, n_split=0 when unused.  n_split must be a multiple of 128.
- *   bias fp32 or NULL; pre_act_out (dtype, ld = ldp) or NULL receives the pre-activation (saved
+ *   bias fp32 or NULL; colscale fp32 or NULL (per-output-column factor: the attention query columns are
+ *   emitted pre-multiplied by d_h^-1/2 * log2(e) so the attention kernels exponentiate raw MFMA results);
+ *   pre_act_out (dtype, ld = ldp) or NULL receives the pre-activation (saved
  *   for backward); residual (ld = ldr) or NULL.  out_f32 != 0: C and residual are fp32 regardless of
  *   dtype (the fp32 residual stream that feeds the post-norms).  Replaces nn.Linear/F.relu/F.gelu:
  *   svanet.py:174-181, cross_modal_transformer.py:163-179, svanet.py:144-156. */
 int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, const void* B, int64_t ldb,
-                 void* C, int64_t ldc, const float* bias, int act, void* pre_act_out, int64_t ldp,
-                 const void* residual, int64_t ldr, int out_f32, int64_t M, int64_t N, int64_t K, int dtype,
-                 void* stream);
+                 void* C, int64_t ldc, const float* bias, const float* colscale, int act, void* pre_act_out,
+                 int64_t ldp, const void* residual, int64_t ldr, int out_f32, int64_t M, int64_t N, int64_t K,
+                 int dtype, void* stream);
 /* Fused MLP backward step: C[M,N] = (A[M,K] * B[N,K]^T) .* gelu'(pre[M,N]);  colsum[N] (fp32, may be NULL,
  * caller zeroes) += column sums of C (= the fc1 bias gradient).  Replaces dh = ds W2, dpre = dh *
  * gelu'(pre), db1 = sum(dpre) of the MLP backward (cross_modal_transformer.py:163-179). */
@@ -109,15 +111,18 @@ int svol_posenc_sine(const float* mask, void* pos, int64_t B, int64_t L, int64_t
  * q/k/v/o are [B*L, ld] row-major, head h occupies columns [h*dh, (h+1)*dh).  softmax(q k^T * scale
  * + kbias) v; kbias [B,Lk] fp32 additive (0 / -inf = key_padding_mask, cross_modal_transformer.py:154)
  * or NULL.  lse2 [B,H,Lq] fp32 = log2-domain log-sum-exp saved for backward.  dh <= 32, dh % 8 == 0.
+ * q_premul != 0: the caller already multiplied q by q_premul = scale*log2(e) (fused into the projection
+ * GEMM epilogue); the kernels then exponentiate the raw MFMA results and dq is still the gradient with
+ * respect to the UNscaled q.  Pass 0 for plain q.
  * Replaces the core of nn.MultiheadAttention (cross_modal_transformer.py:139,147,154). */
 int svol_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                   int64_t ldo, float* lse2, const float* kbias, int64_t B, int64_t H, int64_t Lq, int64_t Lk,
-                  int64_t dh, float scale, int dtype, void* stream);
+                  int64_t dh, float scale, float q_premul, int dtype, void* stream);
 /* delta[B,H,Lq] = rowsum(dO * O) ; then dq / dk / dv (same layouts as q/k/v). */
 int svol_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
                   int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta, const float* kbias,
                   void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int64_t B, int64_t H,
-                  int64_t Lq, int64_t Lk, int64_t dh, float scale, int dtype, void* stream);
+                  int64_t Lq, int64_t Lk, int64_t dh, float scale, float q_premul, int dtype, void* stream);
 
 /* ---- sketch->video gate (cross_modal_transformer.py:122-127) ------------
  * Only the head-averaged attention weights of the 1-query MHA are used by the reference, so the

@@ -23,7 +23,7 @@ _u64 = ctypes.c_uint64
 SIGNATURES = {
     'svol_cast': [_p, _int, _p, _int, _i64, _p],
     'svol_cast_transpose': [_p, _p, _p, _int, _i64, _i64, _p],
-    'svol_gemm_nt': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _int, _p, _i64, _p, _i64, _int, _i64, _i64, _i64,
+    'svol_gemm_nt': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _int, _p, _i64, _p, _i64, _int, _i64, _i64, _i64,
                      _int, _p],
     'svol_gemm_nt_dgelu': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p],
     'svol_gemm_tn': [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _int, _p],
@@ -32,9 +32,10 @@ SIGNATURES = {
     'svol_layernorm_fwd': [_p, _int, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _f32, _u64, _p, _int, _p],
     'svol_layernorm_bwd': [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f32, _u64, _p, _int, _p],
     'svol_posenc_sine': [_p, _p, _i64, _i64, _i64, _int, _p],
-    'svol_attn_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _int, _p],
+    'svol_attn_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _int,
+                      _p],
     'svol_attn_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64,
-                      _i64, _i64, _i64, _i64, _i64, _f32, _int, _p],
+                      _i64, _i64, _i64, _i64, _i64, _f32, _f32, _int, _p],
     'svol_gate_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p],
     'svol_gate_bwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _int,
                       _p],

@@ -175,6 +175,7 @@ struct AttnArgs {
     int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
     int B, H, Lq, Lk, dh;
     float scale;
+    float premul;
 };
 
 template <typename T> struct Smem {
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
     const T* V = reinterpret_cast<const T*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
     const float* kb = p.kbias ? p.kbias + (int64_t)b * p.Lk : nullptr;
-    const float sc = p.scale * LOG2E;
+    const float sc = p.premul != 0.f ? 1.f : p.scale * LOG2E;
 
     uint4 qb[AT<T>::NA];
     load_lane_block<T>(qb, Q, p.ldq, qrow, qvalid, p.dh, h);
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
     const T* V = reinterpret_cast<const T*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
     const float* kb = p.kbias ? p.kbias + (int64_t)b * p.Lk : nullptr;
-    const float sc = p.scale * LOG2E;
+    const float sc = p.premul != 0.f ? 1.f : p.scale * LOG2E;
 
     uint4 qb[AT<T>::NA], dob[AT<T>::NA];
     load_lane_block<T>(qb, Q, p.ldq, qrow, qvalid, p.dh, h);
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
     const T* dO = reinterpret_cast<const T*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
     const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
     const T* V = reinterpret_cast<const T*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
-    const float sc = p.scale * LOG2E;
+    const float sc = p.premul != 0.f ? 1.f : p.scale * LOG2E;
     const float kbl = kvalid ? (p.kbias ? p.kbias[(int64_t)b * p.Lk + krow] * LOG2E : 0.f) : -INFINITY;
     const float* lse_g = p.lse2 + ((int64_t)b * p.H + hh) * p.Lq;
     const float* dl_g = p.delta + ((int64_t)b * p.H + hh) * p.Lq;
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
     }
     T* dKo = reinterpret_cast<T*>(p.dk) + (int64_t)b * p.Lk * p.lddk + hh * p.dh;
     T* dVo = reinterpret_cast<T*>(p.dv) + (int64_t)b * p.Lk * p.lddv + hh * p.dh;
-    store_acc_T<T>(dK, dKo, p.lddk, krow, kvalid, p.dh, h, 1.f);
+    store_acc_T<T>(dK, dKo, p.lddk, krow, kvalid, p.dh, h, p.premul != 0.f ? 1.f / p.premul : 1.f);
     store_acc_T<T>(dV, dVo, p.lddv, krow, kvalid, p.dh, h, 1.f);
 }
 
@@ -443,17 +444,17 @@ bool ld_ok(int64_t ld, int dtype) { return ld % (dtype == SVOL_BF16 ? 8 : 4) == 
 // bf16 fast path (attention_bf16.hip)
 int svol_attn_fwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                               int64_t ldo, float* lse2, const float* kbias, int B, int H, int Lq, int Lk, int dh, float scale,
-                              hipStream_t s);
+                              float premul, hipStream_t s);
 int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                               const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta,
                               const float* kbias, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int B,
-                              int H, int Lq, int Lk, int dh, float scale, hipStream_t s);
+                              int H, int Lq, int Lk, int dh, float scale, float premul, hipStream_t s);
 
 extern "C" {
 
 int svol_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                   int64_t ldo, float* lse2, const float* kbias, int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t dh,
-                  float scale, int dtype, void* stream) {
+                  float scale, float q_premul, int dtype, void* stream) {
     if (!q || !k || !v || !o || !lse2) return SVOL_E_INVALID;
     int rc = check_common(B, H, Lq, Lk, dh, dtype);
     if (rc) return rc;
@@ -462,12 +463,12 @@ int svol_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const 
     AttnArgs p{};
     p.q = q; p.k = k; p.v = v; p.out_o = o; p.lse2 = lse2; p.kbias = kbias;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
-    p.B = (int)B; p.H = (int)H; p.Lq = (int)Lq; p.Lk = (int)Lk; p.dh = (int)dh; p.scale = scale;
+    p.B = (int)B; p.H = (int)H; p.Lq = (int)Lq; p.Lk = (int)Lk; p.dh = (int)dh; p.scale = scale; p.premul = q_premul;
     dim3 grid((unsigned)((Lq + 127) / 128), (unsigned)H, (unsigned)B);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SVOL_BF16)
         return svol_attn_fwd_bf16_launch(q, ldq, k, ldk, v, ldv, o, ldo, lse2, kbias, (int)B, (int)H, (int)Lq, (int)Lk, (int)dh,
-                                         scale, s);
+                                         scale, q_premul, s);
     hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), 0, s, p);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
@@ -476,7 +477,7 @@ int svol_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const 
 int svol_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
                   int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta, const float* kbias, void* dq,
                   int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int64_t B, int64_t H, int64_t Lq, int64_t Lk,
-                  int64_t dh, float scale, int dtype, void* stream) {
+                  int64_t dh, float scale, float q_premul, int dtype, void* stream) {
     if (!q || !k || !v || !o || !d_o || !lse2 || !delta || !dq || !dk || !dv) return SVOL_E_INVALID;
     int rc = check_common(B, H, Lq, Lk, dh, dtype);
     if (rc) return rc;
@@ -490,7 +491,7 @@ int svol_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const 
     p.q = q; p.k = k; p.v = v; p.o = o; p.d_o = d_o; p.lse2 = const_cast<float*>(lse2); p.delta = delta; p.kbias = kbias;
     p.dq = dq; p.dk = dk; p.dv = dv;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
-    p.B = (int)B; p.H = (int)H; p.Lq = (int)Lq; p.Lk = (int)Lk; p.dh = (int)dh; p.scale = scale;
+    p.B = (int)B; p.H = (int)H; p.Lq = (int)Lq; p.Lk = (int)Lk; p.dh = (int)dh; p.scale = scale; p.premul = q_premul;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t total = B * Lq * H;
     dim3 gd((unsigned)((total + 255) / 256));
@@ -498,7 +499,7 @@ int svol_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const 
     dim3 gk((unsigned)((Lk + 127) / 128), (unsigned)H, (unsigned)B);
     if (dtype == SVOL_BF16)
         return svol_attn_bwd_bf16_launch(q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse2, delta, kbias, dq, lddq, dk, lddk, dv,
-                                         lddv, (int)B, (int)H, (int)Lq, (int)Lk, (int)dh, scale, s);
+                                         lddv, (int)B, (int)H, (int)Lq, (int)Lk, (int)dh, scale, q_premul, s);
     hipLaunchKernelGGL(attn_delta_kernel<float>, gd, dim3(256), 0, s, p);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, gq, dim3(256), 0, s, p);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<float>, gk, dim3(256), 0, s, p);

@@ -32,6 +32,7 @@ struct Args {
     int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
     int B, H, Lq, Lk, dh;
     float scale;
+    float premul;  // != 0: q was pre-multiplied by premul = scale*log2(e) (fused into the projection GEMM epilogue)
 };
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(Args p) {
     const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
     const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
     const float* kb = p.kbias ? p.kbias + (int64_t)b * p.Lk : nullptr;
-    const float c = p.scale * LOG2E;
+    const float c = p.premul != 0.f ? 1.f : p.scale * LOG2E;
 
     uint4 qb[2];
     load_lane_block(qb, Q, p.ldq, qrow, qvalid, p.dh, h);
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(Args p) {
     const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
     const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
     const float* kb = p.kbias ? p.kbias + (int64_t)b * p.Lk : nullptr;
-    const float c = p.scale * LOG2E;
+    const float c = p.premul != 0.f ? 1.f : p.scale * LOG2E;
 
     uint4 qb[2], dob[2];
     load_lane_block(qb, Q, p.ldq, qrow, qvalid, p.dh, h);
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(Args p) {
     const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
     const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
-    const float c = p.scale * LOG2E;
+    const float c = p.premul != 0.f ? 1.f : p.scale * LOG2E;
     const float kbl = kvalid ? (p.kbias ? p.kbias[(int64_t)b * p.Lk + krow] * LOG2E : 0.f) : -INFINITY;
     const float* lse_g = p.lse2 + ((int64_t)b * p.H + hh) * p.Lq;
     const float* dl_g = p.delta + ((int64_t)b * p.H + hh) * p.Lq;
@@ -462,7 +463,285 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(Args p) {
     }
     bf16_t* dKo = reinterpret_cast<bf16_t*>(p.dk) + (int64_t)b * p.Lk * p.lddk + hh * p.dh;
     bf16_t* dVo = reinterpret_cast<bf16_t*>(p.dv) + (int64_t)b * p.Lk * p.lddv + hh * p.dh;
-    store_acc(dK, dKo, p.lddk, krow, kvalid, p.dh, h, p.scale);
+    store_acc(dK, dKo, p.lddk, krow, kvalid, p.dh, h, p.premul != 0.f ? p.scale / p.premul : p.scale);
+    store_acc(dV, dVo, p.lddv, krow, kvalid, p.dh, h, 1.f);
+}
+
+// ===========================================================================================
+// "PRE" kernels: the big unmasked self-attention with q pre-multiplied by scale*log2(e) (fused into
+// the projection GEMM epilogue, so it costs no extra rounding).  Every per-score VALU operation that
+// is not an exp, a product or a conversion is moved into the MFMA: the row constants (-running max,
+// -lse, -delta) are the INITIAL ACCUMULATORS of the score / dP products (guide: "row constants as the
+// initial accumulator"), so   p = exp2(acc)   and   dS = p * acc2   come straight out of the matrix pipe.
+// Per 32x32 block: forward 8 max3 + 16 exp + 16 add + 8 cvt (was + 16 fma); dQ 16 exp + 16 mul + 8 cvt
+// (was + 16 fma + 16 sub); dK/dV 16 exp + 16 mul + 16 cvt (was + 16 fma + 16 sub).
+__device__ __forceinline__ f32x16 splat16(float x) {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = x;
+    return z;
+}
+// D = A*B + C with D and C in DIFFERENT registers, so a loop-invariant C (the row constants) is never copied:
+// through the builtin hipcc picks the tied ("mac") form and re-materialises C with 16 v_mov per product.
+// s_nop 1: VALU-written operand -> MFMA read wait states (nothing inside an asm statement is padded for us);
+// the result feeds only the next MFMA's C (accumulate chain, no wait states needed).
+__device__ __forceinline__ f32x16 mma_first_c(const uint4 (&a)[2], const uint4 (&b)[2], const f32x16& c0) {
+    f32x16 acc;
+    asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3"
+        : "=&v"(acc)
+        : "v"(__builtin_bit_cast(bf16x8, a[0])), "v"(__builtin_bit_cast(bf16x8, b[0])), "v"(c0));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, b[1]), acc, 0, 0,
+                                                   0);
+}
+// accumulator initialised from a per-ROW vector in LDS (row constants of the reg-side tile)
+__device__ __forceinline__ f32x16 rows16(const float* v, int sub, int h) {
+    f32x16 z;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(v + sub * 32 + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[4 * g + e] = t[e];
+    }
+    return z;
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_pre(Args p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * IMG];
+    char* sK = smem;
+    char* sV = smem + 2 * IMG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, hh = blockIdx.y;
+    const int qrow = blockIdx.x * 128 + wave * 32 + r;
+    const bool qvalid = qrow < p.Lq;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
+
+    uint4 qb[2];
+    load_lane_block(qb, Q, p.ldq, qrow, qvalid, p.dh, h);
+    float m = 0.f, l = 0.f;       // m: running reference (log2 domain), scores enter the softmax as s - m
+    f32x16 O = zero16();
+    f32x16 Cm = zero16();         // -m in every accumulator register of this lane's query
+
+    const int nt = p.Lk / KT;     // launcher guarantees Lk % KT == 0
+    Stage sk, sv;
+    load_regs(sk, K, p.ldk, 0, p.Lk, p.dh, tid);
+    load_regs(sv, V, p.ldv, 0, p.Lk, p.dh, tid);
+    store_lds(sK, sk, tid);
+    store_lds(sV, sv, tid);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            load_regs(sk, K, p.ldk, (t + 1) * KT, p.Lk, p.dh, tid);
+            load_regs(sv, V, p.ldv, (t + 1) * KT, p.Lk, p.dh, tid);
+        }
+        const char* kimg = sK + cur * IMG;
+        const char* vimg = sV + cur * IMG;
+        f32x16 S[4];
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            uint4 ka[2];
+            read_rows(ka, kimg, sub * 32 + r, h);
+            S[sub] = mma_first_c(ka, qb, Cm);  // = score - m
+        }
+        float ml[4];
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            float mm = max3(S[sub][0], S[sub][1], S[sub][2]);
+#pragma unroll
+            for (int i = 3; i < 15; i += 2) mm = max3(mm, S[sub][i], S[sub][i + 1]);
+            ml[sub] = max3(mm, S[sub][15], mm);
+        }
+        float mloc = max3(ml[0], ml[1], fmaxf(ml[2], ml[3]));
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc),
+                                                             __builtin_bit_cast(unsigned, mloc), false, false);
+            mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+        }
+        if (t == 0 || __any(mloc > LAZY_THR)) {  // wave-uniform
+            // first tile: anchor the reference at this tile's maximum (may move down); later: only upward moves
+            const float dm = (t == 0) ? mloc : fmaxf(mloc, 0.f);
+            if (t != 0) {
+                const float alpha = __builtin_amdgcn_exp2f(-dm);
+                l *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) O[i] *= alpha;
+            }
+            m += dm;
+            Cm = splat16(-m);
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) S[sub][i] -= dm;
+        }
+        float ls[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                S[sub][i] = __builtin_amdgcn_exp2f(S[sub][i]);
+                ls[sub] += S[sub][i];
+            }
+        l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            uint4 va[2];
+            read_tr(va, vimg, sub, lane);
+            mma_second(O, va, S[sub]);
+        }
+        if (t + 1 < nt) {
+            store_lds(sK + (cur ^ 1) * IMG, sk, tid);
+            store_lds(sV + (cur ^ 1) * IMG, sv, tid);
+        }
+        __syncthreads();
+    }
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    bf16_t* Oo = reinterpret_cast<bf16_t*>(p.out_o) + (int64_t)b * p.Lq * p.ldo + hh * p.dh;
+    store_acc(O, Oo, p.ldo, qrow, qvalid, p.dh, h, inv);
+    if (qvalid && h == 0) p.lse2[((int64_t)b * p.H + hh) * p.Lq + qrow] = m + __builtin_amdgcn_logf(lt);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_pre(Args p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * IMG];
+    char* sK = smem;
+    char* sV = smem + 2 * IMG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, hh = blockIdx.y;
+    const int qrow = blockIdx.x * 128 + wave * 32 + r;
+    const bool qvalid = qrow < p.Lq;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
+    const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
+
+    uint4 qb[2], dob[2];
+    load_lane_block(qb, Q, p.ldq, qrow, qvalid, p.dh, h);
+    load_lane_block(dob, dO, p.lddo, qrow, qvalid, p.dh, h);
+    const int64_t sidx = ((int64_t)b * p.H + hh) * p.Lq + qrow;
+    const f32x16 Cl = splat16(qvalid ? -p.lse2[sidx] : -INFINITY);  // score - lse  (rows past Lq -> p = 0)
+    const f32x16 Cd = splat16(qvalid ? -p.delta[sidx] : 0.f);       // dP - delta
+
+    f32x16 dQ = zero16();
+    const int nt = p.Lk / KT;
+    Stage sk, sv;
+    load_regs(sk, K, p.ldk, 0, p.Lk, p.dh, tid);
+    load_regs(sv, V, p.ldv, 0, p.Lk, p.dh, tid);
+    store_lds(sK, sk, tid);
+    store_lds(sV, sv, tid);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            load_regs(sk, K, p.ldk, (t + 1) * KT, p.Lk, p.dh, tid);
+            load_regs(sv, V, p.ldv, (t + 1) * KT, p.Lk, p.dh, tid);
+        }
+        const char* kimg = sK + cur * IMG;
+        const char* vimg = sV + cur * IMG;
+#pragma unroll 2
+        for (int sub = 0; sub < 4; ++sub) {
+            uint4 a[2];
+            read_rows(a, kimg, sub * 32 + r, h);
+            f32x16 S = mma_first_c(a, qb, Cl);
+            read_rows(a, vimg, sub * 32 + r, h);
+            const f32x16 dP = mma_first_c(a, dob, Cd);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[i] = __builtin_amdgcn_exp2f(S[i]) * dP[i];
+            read_tr(a, kimg, sub, lane);
+            mma_second(dQ, a, S);
+        }
+        if (t + 1 < nt) {
+            store_lds(sK + (cur ^ 1) * IMG, sk, tid);
+            store_lds(sV + (cur ^ 1) * IMG, sv, tid);
+        }
+        __syncthreads();
+    }
+    bf16_t* dQo = reinterpret_cast<bf16_t*>(p.dq) + (int64_t)b * p.Lq * p.lddq + hh * p.dh;
+    store_acc(dQ, dQo, p.lddq, qrow, qvalid, p.dh, h, p.scale);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_pre(Args p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * IMG + 4 * KT * 4];
+    char* sQ = smem;
+    char* sdO = smem + 2 * IMG;
+    float* sL = reinterpret_cast<float*>(smem + 4 * IMG);  // [2][KT] -lse2
+    float* sD = sL + 2 * KT;                               // [2][KT] -delta
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, hh = blockIdx.y;
+    const int krow = blockIdx.x * 128 + wave * 32 + r;
+    const bool kvalid = krow < p.Lk;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
+    const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
+    const float* lse_g = p.lse2 + ((int64_t)b * p.H + hh) * p.Lq;
+    const float* dl_g = p.delta + ((int64_t)b * p.H + hh) * p.Lq;
+
+    uint4 kbk[2], vbk[2];
+    load_lane_block(kbk, K, p.ldk, krow, kvalid, p.dh, h);
+    load_lane_block(vbk, V, p.ldv, krow, kvalid, p.dh, h);
+    f32x16 dK = zero16(), dV = zero16();
+    const int nt = (p.Lq + KT - 1) / KT;
+    Stage sq, sdo;
+    float rl = 0.f, rd = 0.f;
+    auto load_stats = [&](int row0) {
+        if (tid < KT) {
+            const int qi = row0 + tid;
+            rl = qi < p.Lq ? -lse_g[qi] : -INFINITY;
+            rd = qi < p.Lq ? -dl_g[qi] : 0.f;
+        }
+    };
+    auto store_stats = [&](int buf) {
+        if (tid < KT) { sL[buf * KT + tid] = rl; sD[buf * KT + tid] = rd; }
+    };
+    load_regs(sq, Q, p.ldq, 0, p.Lq, p.dh, tid);
+    load_regs(sdo, dO, p.lddo, 0, p.Lq, p.dh, tid);
+    load_stats(0);
+    store_lds(sQ, sq, tid);
+    store_lds(sdO, sdo, tid);
+    store_stats(0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            load_regs(sq, Q, p.ldq, (t + 1) * KT, p.Lq, p.dh, tid);
+            load_regs(sdo, dO, p.lddo, (t + 1) * KT, p.Lq, p.dh, tid);
+            load_stats((t + 1) * KT);
+        }
+        const char* qimg = sQ + cur * IMG;
+        const char* doimg = sdO + cur * IMG;
+        const float* nl = sL + cur * KT;
+        const float* nd = sD + cur * KT;
+#pragma unroll 1
+        for (int sub = 0; sub < 4; ++sub) {
+            uint4 a[2];
+            read_rows(a, qimg, sub * 32 + r, h);
+            f32x16 S = mma_first_c(a, kbk, rows16(nl, sub, h));  // score - lse[q]
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[i] = __builtin_amdgcn_exp2f(S[i]);
+            read_tr(a, doimg, sub, lane);
+            mma_second(dV, a, S);
+            read_rows(a, doimg, sub * 32 + r, h);
+            const f32x16 dP = mma_first_c(a, vbk, rows16(nd, sub, h));  // dO V^T - delta[q]
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[i] *= dP[i];
+            read_tr(a, qimg, sub, lane);
+            mma_second(dK, a, S);
+        }
+        if (t + 1 < nt) {
+            store_lds(sQ + (cur ^ 1) * IMG, sq, tid);
+            store_lds(sdO + (cur ^ 1) * IMG, sdo, tid);
+            store_stats(cur ^ 1);
+        }
+        __syncthreads();
+    }
+    bf16_t* dKo = reinterpret_cast<bf16_t*>(p.dk) + (int64_t)b * p.Lk * p.lddk + hh * p.dh;
+    bf16_t* dVo = reinterpret_cast<bf16_t*>(p.dv) + (int64_t)b * p.Lk * p.lddv + hh * p.dh;
+    store_acc(dK, dKo, p.lddk, krow, kvalid, p.dh, h, p.scale / p.premul);
     store_acc(dV, dVo, p.lddv, krow, kvalid, p.dh, h, 1.f);
 }
 
@@ -471,14 +750,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(Args p) {
 // entry points used by attention.hip's C-ABI functions
 int svol_attn_fwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                               int64_t ldo, float* lse2, const float* kbias, int B, int H, int Lq, int Lk, int dh, float scale,
-                              hipStream_t s) {
+                              float premul, hipStream_t s) {
     Args p{};
     p.q = q; p.k = k; p.v = v; p.out_o = o; p.lse2 = lse2; p.kbias = kbias;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
-    p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.dh = dh; p.scale = scale;
+    p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.dh = dh; p.scale = scale; p.premul = premul;
     dim3 grid((unsigned)((Lq + 127) / 128), (unsigned)H, (unsigned)B);
     const bool masked = kbias != nullptr || (Lk % KT) != 0;
-    if (masked) hipLaunchKernelGGL(attn_fwd_bf16<true>, grid, dim3(256), 0, s, p);
+    if (!masked && premul != 0.f) hipLaunchKernelGGL(attn_fwd_bf16_pre, grid, dim3(256), 0, s, p);
+    else if (masked) hipLaunchKernelGGL(attn_fwd_bf16<true>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(attn_fwd_bf16<false>, grid, dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
 }
@@ -486,21 +766,27 @@ int svol_attn_fwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
 int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                               const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta,
                               const float* kbias, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int B,
-                              int H, int Lq, int Lk, int dh, float scale, hipStream_t s) {
+                              int H, int Lq, int Lk, int dh, float scale, float premul, hipStream_t s) {
     Args p{};
     p.q = q; p.k = k; p.v = v; p.o = o; p.d_o = d_o; p.lse2 = const_cast<float*>(lse2); p.delta = delta; p.kbias = kbias;
     p.dq = dq; p.dk = dk; p.dv = dv;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
-    p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.dh = dh; p.scale = scale;
+    p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.dh = dh; p.scale = scale; p.premul = premul;
     const int64_t total = (int64_t)B * Lq * H;
     dim3 gd((unsigned)((total + 255) / 256));
     dim3 gq((unsigned)((Lq + 127) / 128), (unsigned)H, (unsigned)B);
     dim3 gk((unsigned)((Lk + 127) / 128), (unsigned)H, (unsigned)B);
     const bool masked = kbias != nullptr || (Lk % KT) != 0;
     hipLaunchKernelGGL(attn_delta_bf16, gd, dim3(256), 0, s, p);
-    if (masked) hipLaunchKernelGGL(attn_bwd_dq_bf16<true>, gq, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(attn_bwd_dq_bf16<false>, gq, dim3(256), 0, s, p);
-    if (masked) hipLaunchKernelGGL(attn_bwd_dkdv_bf16<true>, gk, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(attn_bwd_dkdv_bf16<false>, gk, dim3(256), 0, s, p);
+    if (!masked && premul != 0.f) {
+        hipLaunchKernelGGL(attn_bwd_dq_bf16_pre, gq, dim3(256), 0, s, p);
+        hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre, gk, dim3(256), 0, s, p);
+    } else if (masked) {
+        hipLaunchKernelGGL(attn_bwd_dq_bf16<true>, gq, dim3(256), 0, s, p);
+        hipLaunchKernelGGL(attn_bwd_dkdv_bf16<true>, gk, dim3(256), 0, s, p);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dq_bf16<false>, gq, dim3(256), 0, s, p);
+        hipLaunchKernelGGL(attn_bwd_dkdv_bf16<false>, gk, dim3(256), 0, s, p);
+    }
     return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
 }

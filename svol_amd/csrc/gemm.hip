@@ -32,7 +32,7 @@ __device__ __forceinline__ void mma_chunk(f32x4& acc, const uint4& a, const uint
 
 struct NtArgs {
     const void* A; const void* A2; const void* B; void* C;
-    const float* bias; void* pre; const void* res;
+    const float* bias; const float* colscale; void* pre; const void* res;
     int64_t lda, ldb, ldc, ldr, ldp, n_split;
     int M, N, K, act;
 };
@@ -116,11 +116,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs p) {
             const int n = bn + wn * 64 + nt * 16 + fr;
             if (n >= p.N) continue;
             const float bv = p.bias ? p.bias[n] : 0.f;
+            const float cs = p.colscale ? p.colscale[n] : 1.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = bm + wm * 64 + mt * 16 + fq * 4 + r;
                 if (m >= p.M) continue;
-                float v = acc[mt][nt][r] + bv;
+                float v = (acc[mt][nt][r] + bv) * cs;
                 if (pre) pre[(int64_t)m * p.ldp + n] = from_f32<T>(v);
                 if (p.act == SVOL_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (p.act == SVOL_ACT_GELU) v = gelu_f(v);
@@ -330,7 +331,8 @@ inline int grid_1d(int64_t n, int block) {
 // bf16 fast path (gemm_bf16.hip)
 int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
                            int act, void* pre, int64_t ldp, const void* res, int64_t ldr, int out_f32, const void* aux,
-                           int64_t ldaux, float* colsum, int epi, int64_t M, int64_t N, int64_t K, hipStream_t s);
+                           int64_t ldaux, float* colsum, int epi, const float* colscale, int64_t M, int64_t N, int64_t K,
+                           hipStream_t s);
 
 extern "C" {
 
@@ -347,8 +349,8 @@ const char* svol_strerror(int code) {
 }
 
 int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, const void* B, int64_t ldb, void* C,
-                 int64_t ldc, const float* bias, int act, void* pre_act_out, int64_t ldp, const void* residual,
-                 int64_t ldr, int out_f32, int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
+                 int64_t ldc, const float* bias, const float* colscale, int act, void* pre_act_out, int64_t ldp,
+                 const void* residual, int64_t ldr, int out_f32, int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
     if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return SVOL_E_INVALID;
     if (M == 0 || N == 0) return SVOL_OK;
     const int epc = dtype == SVOL_BF16 ? 8 : 4;
@@ -357,13 +359,13 @@ int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, co
     if (!aligned16(A) || !aligned16(B) || (A2 && !aligned16(A2))) return SVOL_E_INVALID;
     if (A2 && (n_split % 128)) return SVOL_E_UNSUPPORTED;
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return SVOL_E_UNSUPPORTED;
-    NtArgs p{A, A2, B, C, bias, pre_act_out, residual, lda, ldb, ldc, ldr, ldp, n_split, (int)M, (int)N, (int)K, act};
+    NtArgs p{A, A2, B, C, bias, colscale, pre_act_out, residual, lda, ldb, ldc, ldr, ldp, n_split, (int)M, (int)N, (int)K, act};
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
     if (grid.y > 65535u) return SVOL_E_UNSUPPORTED;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SVOL_BF16 && !A2) {
         const int rc = svol_gemm_nt_bf16_fast(A, lda, B, ldb, C, ldc, bias, act, pre_act_out, ldp, residual, ldr, out_f32, nullptr,
-                                              0, nullptr, 0, M, N, K, s);
+                                              0, nullptr, 0, colscale, M, N, K, s);
         if (rc != SVOL_E_UNSUPPORTED) return rc;
     }
     if (dtype == SVOL_BF16) {
@@ -383,13 +385,13 @@ int svol_gemm_nt_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, v
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SVOL_BF16) {
         const int rc = svol_gemm_nt_bf16_fast(A, lda, B, ldb, C, ldc, nullptr, SVOL_ACT_NONE, nullptr, 0, nullptr, 0, 0, pre, ldp,
-                                              colsum, 1, M, N, K, s);
+                                              colsum, 1, nullptr, M, N, K, s);
         if (rc != SVOL_E_UNSUPPORTED) return rc;
     }
     // generic composition (f32 / odd shapes): GEMM, then dpre = dh * gelu'(pre) in place, then column sums
     if (ldc != N || ldp != N) return SVOL_E_UNSUPPORTED;
-    int rc = svol_gemm_nt(A, lda, nullptr, 0, B, ldb, C, ldc, nullptr, SVOL_ACT_NONE, nullptr, 0, nullptr, 0, 0, M, N, K, dtype,
-                          stream);
+    int rc = svol_gemm_nt(A, lda, nullptr, 0, B, ldb, C, ldc, nullptr, nullptr, SVOL_ACT_NONE, nullptr, 0, nullptr, 0, 0, M, N, K,
+                          dtype, stream);
     if (rc) return rc;
     rc = svol_act_bwd(C, pre, C, SVOL_ACT_GELU, M * N, dtype, stream);
     if (rc) return rc;

@@ -24,7 +24,7 @@ namespace {
 
 struct FastArgs {
     const bf16_t* A; const bf16_t* B; void* C;
-    const float* bias; bf16_t* pre; const void* res; const bf16_t* aux; float* colsum;
+    const float* bias; const float* colscale; bf16_t* pre; const void* res; const bf16_t* aux; float* colsum;
     int64_t lda, ldb, ldc, ldp, ldr, ldaux;
     int M, N, K, act, epi;
 };
@@ -146,6 +146,11 @@ __device__ __forceinline__ void gemm_nt_bf16_body(const FastArgs& p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) bias4[e] = (ncol + e < p.N) ? p.bias[ncol + e] : 0.f;
     }
+    f32x4 scale4 = {1.f, 1.f, 1.f, 1.f};
+    if (p.colscale) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) scale4[e] = (ncol + e < p.N) ? p.colscale[ncol + e] : 1.f;
+    }
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
     TC* C = reinterpret_cast<TC*>(p.C);
     const TC* R = reinterpret_cast<const TC*>(p.res);
@@ -163,7 +168,7 @@ __device__ __forceinline__ void gemm_nt_bf16_body(const FastArgs& p) {
             if (m < p.M) {
                 if (p.epi == 0) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += bias4[e];
+                    for (int e = 0; e < 4; ++e) v[e] = (v[e] + bias4[e]) * scale4[e];
                     if (p.pre) {
                         if (colv) Out4<bf16_t>::store(p.pre + (int64_t)m * p.ldp + ncol, v);
                         else
@@ -239,7 +244,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_b16_k32(FastArgs p) { gem
 // qualify (the caller then uses the generic kernel).
 int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
                            int act, void* pre, int64_t ldp, const void* res, int64_t ldr, int out_f32, const void* aux,
-                           int64_t ldaux, float* colsum, int epi, int64_t M, int64_t N, int64_t K, hipStream_t s) {
+                           int64_t ldaux, float* colsum, int epi, const float* colscale, int64_t M, int64_t N, int64_t K,
+                           hipStream_t s) {
     if (K % 32 || lda % 8 || ldb % 8 || !aligned16(A) || !aligned16(B)) return SVOL_E_UNSUPPORTED;
     // vector epilogue needs 8-byte (bf16) / 16-byte (f32) aligned rows; otherwise the scalar tail path is used per lane
     if ((int64_t)128 * lda * 2 >= (1ll << 31) || (int64_t)128 * ldb * 2 >= (1ll << 31)) return SVOL_E_UNSUPPORTED;
@@ -248,7 +254,7 @@ int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ld
     if (res && ((ldr * celt) % (4 * celt) || (reinterpret_cast<uintptr_t>(res) % (4 * celt)))) return SVOL_E_UNSUPPORTED;
     if (pre && (ldp % 4 || (reinterpret_cast<uintptr_t>(pre) % 8))) return SVOL_E_UNSUPPORTED;
     if (aux && (ldaux % 4 || (reinterpret_cast<uintptr_t>(aux) % 8))) return SVOL_E_UNSUPPORTED;
-    FastArgs p{(const bf16_t*)A, (const bf16_t*)B, C, bias, (bf16_t*)pre, res, (const bf16_t*)aux, colsum,
+    FastArgs p{(const bf16_t*)A, (const bf16_t*)B, C, bias, colscale, (bf16_t*)pre, res, (const bf16_t*)aux, colsum,
                lda, ldb, ldc, ldp, ldr, ldaux, (int)M, (int)N, (int)K, act, epi};
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
     if (grid.y > 65535u) return SVOL_E_UNSUPPORTED;

@@ -108,7 +108,7 @@ def cast_transpose(w: torch.Tensor, dtype: torch.dtype, want: bool = True, want_
     return d, dT
 
 
-def gemm_nt(A, B, bias=None, act=ACT_NONE, residual=None, want_pre=False, out=None, out_f32=False):
+def gemm_nt(A, B, bias=None, act=ACT_NONE, residual=None, want_pre=False, out=None, out_f32=False, colscale=None):
     """out[M,N] = act(A[M,K] @ B[N,K]^T + bias) + residual.  A/B/out/residual may be column slices
     of wider row-major buffers (stride(0) is the leading dimension).  out_f32: `out` and `residual`
     are fp32 (the fp32 residual stream) whatever the operand dtype."""
@@ -121,7 +121,8 @@ def gemm_nt(A, B, bias=None, act=ACT_NONE, residual=None, want_pre=False, out=No
     assert out.dtype == cdt and (residual is None or residual.dtype == cdt)
     pre = torch.empty((M, N), dtype=A.dtype, device=A.device) if want_pre else None
     rc = _lib.lib().svol_gemm_nt(_ptr(A), A.stride(0), 0, 0, _ptr(B), B.stride(0), _ptr(out), out.stride(0),
-                                 _ptr(bias), act, _ptr(pre), pre.stride(0) if pre is not None else 0, _ptr(residual),
+                                 _ptr(bias), _ptr(colscale), act, _ptr(pre), pre.stride(0) if pre is not None else 0,
+                                 _ptr(residual),
                                  residual.stride(0) if residual is not None else 0, 1 if out_f32 else 0, M, N, K,
                                  _dt(A), _stream())
     _lib.check(rc, 'svol_gemm_nt')
@@ -225,20 +226,20 @@ def posenc_sine(mask_f32: torch.Tensor, D: int, dtype: torch.dtype) -> torch.Ten
     return pos
 
 
-def attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias=None):
+def attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias=None, premul=0.0):
     """q/k/v: 2-D [B*L, >=H*dh] views (column slices allowed). Returns o [B*Lq, H*dh], lse2 [B,H,Lq]."""
     o = torch.empty((B * Lq, H * dh), dtype=q.dtype, device=q.device)
     lse2 = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
     tok = timer.start('attn_fwd', (B, H, Lq, Lk, dh))
     rc = _lib.lib().svol_attn_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o),
                                   o.stride(0), _ptr(lse2), _ptr(kbias), B, H, Lq, Lk, dh, 1.0 / math.sqrt(dh),
-                                  _dt(q), _stream())
+                                  float(premul), _dt(q), _stream())
     timer.stop(tok)
     _lib.check(rc, 'svol_attn_fwd')
     return o, lse2
 
 
-def attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias=None):
+def attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias=None, premul=0.0):
     """Writes dq/dk/dv (2-D views, column slices allowed)."""
     do = do if do.stride(1) == 1 else do.contiguous()
     delta = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
@@ -246,7 +247,7 @@ def attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias=None):
     rc = _lib.lib().svol_attn_bwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o),
                                   o.stride(0), _ptr(do), do.stride(0), _ptr(lse2), _ptr(delta), _ptr(kbias),
                                   _ptr(dq), dq.stride(0), _ptr(dk), dk.stride(0), _ptr(dv), dv.stride(0), B, H, Lq,
-                                  Lk, dh, 1.0 / math.sqrt(dh), _dt(q), _stream())
+                                  Lk, dh, 1.0 / math.sqrt(dh), float(premul), _dt(q), _stream())
     timer.stop(tok)
     _lib.check(rc, 'svol_attn_bwd')
 
@@ -443,26 +444,30 @@ class AttnLNFn(torch.autograd.Function):
         dh = d // H
         Wc, WcT = weights.get(W_in, dt)
         Woc, WoT = weights.get(W_o, dt)
+        # bf16: the projection GEMM emits q already multiplied by d_h^-1/2 * log2(e) (rounded once, in the fp32
+        # epilogue), which lets the attention kernels exponentiate raw MFMA results
+        premul = (LOG2E / math.sqrt(dh)) if dt == torch.bfloat16 else 0.0
+        qscale = _qscale(d, premul, xq.device) if premul else None
         a_qp = xq_pos.reshape(B * Lq, d)
         a_q = xq.reshape(B * Lq, d)
         a_kp = a_qp if self_attn else xk_pos.reshape(B * Lk, d)
         a_v = a_q if self_attn else xv.reshape(B * Lk, d)
         if self_attn:
             qkv = torch.empty((B * Lq, 3 * d), dtype=dt, device=xq.device)
-            gemm_nt(a_qp, Wc[:2 * d], b_in[:2 * d], out=qkv[:, :2 * d])
+            gemm_nt(a_qp, Wc[:2 * d], b_in[:2 * d], out=qkv[:, :2 * d], colscale=qscale)
             gemm_nt(a_q, Wc[2 * d:], b_in[2 * d:], out=qkv[:, 2 * d:])
             q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         else:
-            q = gemm_nt(a_qp, Wc[:d], b_in[:d])
+            q = gemm_nt(a_qp, Wc[:d], b_in[:d], colscale=qscale[:d] if qscale is not None else None)
             kv = torch.empty((B * Lk, 2 * d), dtype=dt, device=xq.device)
             gemm_nt(a_kp, Wc[d:2 * d], b_in[d:2 * d], out=kv[:, :d])
             gemm_nt(a_v, Wc[2 * d:], b_in[2 * d:], out=kv[:, d:])
             k, v = kv[:, :d], kv[:, d:]
-        o, lse2 = attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias)
+        o, lse2 = attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias, premul)
         s32 = gemm_nt(o, Woc, b_o, residual=xq32.reshape(B * Lq, d), out_f32=True)
         y32, y, ypos, mean, rstd = _ln_out(s32, gamma, beta, pos_out, dt)
         ctx.save_for_backward(a_qp, a_q, a_kp, a_v, q, k, v, o, lse2, kbias, s32, gamma, mean, rstd)
-        ctx.WcT, ctx.WoT, ctx.dims, ctx.self_attn = WcT, WoT, (B, H, Lq, Lk, dh, d), self_attn
+        ctx.WcT, ctx.WoT, ctx.dims, ctx.self_attn, ctx.premul = WcT, WoT, (B, H, Lq, Lk, dh, d), self_attn, premul
         ctx.pos_shape = pos_out.shape if pos_out is not None else None
         shp = (B, Lq, d)
         if pos_out is not None:
@@ -488,7 +493,7 @@ class AttnLNFn(torch.autograd.Function):
         if ctx.self_attn:
             dqkv = torch.empty((B * Lq, 3 * d), dtype=dt, device=g.device)
             dq, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
-            attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias)
+            attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias, ctx.premul)
             gemm_tn(dqkv[:, :2 * d], a_qp, out=dW_in[:2 * d])
             gemm_tn(dv, a_q, out=dW_in[2 * d:])
             colsum(dqkv, out=db_in)
@@ -499,7 +504,7 @@ class AttnLNFn(torch.autograd.Function):
         dq = torch.empty((B * Lq, d), dtype=dt, device=g.device)
         dkv = torch.empty((B * Lk, 2 * d), dtype=dt, device=g.device)
         dk, dv = dkv[:, :d], dkv[:, d:]
-        attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias)
+        attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias, ctx.premul)
         gemm_tn(dq, a_qp, out=dW_in[:d])
         gemm_tn(dk, a_kp, out=dW_in[d:2 * d])
         gemm_tn(dv, a_v, out=dW_in[2 * d:])
@@ -511,6 +516,21 @@ class AttnLNFn(torch.autograd.Function):
         shk = (B, Lk, d)
         return (ds32.view(shq), None, dxq_pos.view(shq), dxk_pos.view(shk), dxv.view(shk), dW_in, db_in, dWo, dbo, dg,
                 dbt, dpos, None, None, None)
+
+
+LOG2E = 1.4426950408889634
+_QSCALE = {}
+
+
+def _qscale(d, premul, device):
+    """per-column epilogue factor of the packed q|k projection: premul on the q columns, 1 on the k columns."""
+    key = (d, premul, str(device))
+    t = _QSCALE.get(key)
+    if t is None:
+        t = torch.ones((2 * d,), dtype=torch.float32, device=device)
+        t[:d] = premul
+        _QSCALE[key] = t
+    return t
 
 
 def mlp_ln(x32, x, W1, b1, W2, b2, gamma, beta, pos_out=None):

@@ -241,7 +241,7 @@ def _attn_ref(q, k, v, B, H, Lq, Lk, dh, kbias):
 def check_attention():
     res = {}
     cases = [(2, 4, 70, 150, 8, True), (1, 8, 200, 200, 32, False), (2, 8, 100, 333, 32, True), (1, 2, 129, 64, 16, False),
-             (1, 8, 384, 384, 32, False)]
+             (1, 8, 384, 384, 32, False), (2, 4, 200, 256, 32, False), (1, 2, 100, 128, 8, False)]
     for dt in DTYPES:
         for (B, H, Lq, Lk, dh, masked) in cases:
             d = H * dh
@@ -265,6 +265,22 @@ def check_attention():
             res[tag + '/dq'] = (rel_err(dq, q64.grad), TOL[dt] * 2)
             res[tag + '/dk'] = (rel_err(dk, k64.grad), TOL[dt] * 2)
             res[tag + '/dv'] = (rel_err(dv, v64.grad), TOL[dt] * 2)
+            # q pre-multiplied by scale*log2(e) (what the projection GEMM epilogue emits in the model): same
+            # mathematical result, dq still w.r.t. the unscaled q
+            pm = 1.4426950408889634 / math.sqrt(dh)
+            qp = (q.double() * pm).to(dt)
+            qref = (qp.double() / pm).requires_grad_(True)  # the unscaled q the kernel effectively sees
+            k64b, v64b = k.double().requires_grad_(True), v.double().requires_grad_(True)
+            o_ref2, _ = _attn_ref(qref, k64b, v64b, B, H, Lq, Lk, dh, kb)
+            (o_ref2 * do.double()).sum().backward()
+            o2, lse22 = ops.attn_fwd(qp.to(DEV), kd, vd, B, H, Lq, Lk, dh, kb.to(DEV) if masked else None, pm)
+            res[tag + '/premul/o'] = (rel_err(o2, o_ref2), TOL[dt])
+            dq2, dk2, dv2 = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+            ops.attn_bwd(qp.to(DEV), kd, vd, o2, do.to(DEV), lse22, B, H, Lq, Lk, dh, dq2, dk2, dv2,
+                         kb.to(DEV) if masked else None, pm)
+            res[tag + '/premul/dq'] = (rel_err(dq2, qref.grad), TOL[dt] * 2)
+            res[tag + '/premul/dk'] = (rel_err(dk2, k64b.grad), TOL[dt] * 2)
+            res[tag + '/premul/dv'] = (rel_err(dv2, v64b.grad), TOL[dt] * 2)
         # packed [M,3d] buffer with column slices (the layout the model uses)
         B, H, L, dh = 2, 4, 96, 8
         d = H * dh

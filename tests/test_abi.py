@@ -33,8 +33,8 @@ def test_argument_validation_without_gpu():
     """Null pointers / bad shapes are rejected before any launch (safe to call without a device)."""
     from svol_amd import _lib
     L = _lib.lib()
-    assert L.svol_gemm_nt(0, 8, 0, 0, 0, 8, 0, 8, 0, 0, 0, 0, 0, 0, 0, 4, 4, 8, 1, 0) == -1
-    assert L.svol_attn_fwd(0, 8, 0, 8, 0, 8, 0, 8, 0, 0, 1, 1, 1, 1, 8, 1.0, 1, 0) == -1
+    assert L.svol_gemm_nt(0, 8, 0, 0, 0, 8, 0, 8, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 8, 1, 0) == -1
+    assert L.svol_attn_fwd(0, 8, 0, 8, 0, 8, 0, 8, 0, 0, 1, 1, 1, 1, 8, 1.0, 0.0, 1, 0) == -1
     assert L.svol_cast(0, 0, 0, 1, 10, 0) == -1
 
 

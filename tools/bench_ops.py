@@ -41,11 +41,13 @@ if 'attn' in which:
         o, lse = ops.attn_fwd(q, k, v, B, H, L, L, DH)
         do = rnd(B * L, D, dt=dt)
         dqkv = torch.empty_like(qkv)
-        t = timeit(lambda: ops.attn_fwd(q, k, v, B, H, L, L, DH))
         fl = 4.0 * L * L * D * B
-        print(f'attn_fwd  {dt}: {t:.3f} ms  {fl / t / 1e9:.1f} TFLOP/s (algorithmic 4L^2dB)')
-        t = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, B, H, L, L, DH, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]))
-        print(f'attn_bwd  {dt}: {t:.3f} ms  {2 * fl / t / 1e9:.1f} TFLOP/s (algorithmic 2x fwd)')
+        for pm in (0.0, 1.4426950408889634 / DH ** 0.5):
+            o, lse = ops.attn_fwd(q, k, v, B, H, L, L, DH, None, pm)
+            t = timeit(lambda: ops.attn_fwd(q, k, v, B, H, L, L, DH, None, pm))
+            print(f'attn_fwd  premul={pm:.3f}: {t:.3f} ms  {fl / t / 1e9:.1f} TFLOP/s (algorithmic 4L^2dB)')
+            t = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, B, H, L, L, DH, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], None, pm))
+            print(f'attn_bwd  premul={pm:.3f}: {t:.3f} ms  {2 * fl / t / 1e9:.1f} TFLOP/s (algorithmic 2x fwd)')
         # cross attention shape
         qc = rnd(B * NQ, D, dt=dt)
         kb = torch.zeros(B, L, device=DEV)
