@@ -74,9 +74,11 @@ int svol_gemm_nt_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, v
                        const void* pre, int64_t ldp, float* colsum, int64_t M, int64_t N, int64_t K, int dtype,
                        void* stream);
 /* dW[N,K] (fp32, ld = ldc) (+)= A[Mc,N]^T * B[Mc,K]   (contraction over the Mc rows; weight gradient).
- * The output is accumulated with fp32 atomics: the caller zeroes C first unless it wants accumulation. */
-int svol_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t Mc,
-                 int64_t N, int64_t K, int dtype, void* stream);
+ * The output is accumulated with fp32 atomics: the caller zeroes C first unless it wants accumulation.
+ * colsum (fp32 [N], may be NULL, caller zeroes) += column sums of A — the bias gradient, computed on the
+ * matrix pipe (A^T * ones) by the workgroups that already hold the A tiles. */
+int svol_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
+                 int64_t Mc, int64_t N, int64_t K, int dtype, void* stream);
 /* out[N] (fp32) += sum_m X[m,n]   (bias gradient).  Caller zeroes `out`. */
 int svol_colsum(const void* X, int64_t ldx, float* out, int64_t M, int64_t N, int dtype, void* stream);
 /* dpre[i] = dy[i] * act'(aux[i]); aux = post-activation for RELU/SIGMOID, pre-activation for GELU. */

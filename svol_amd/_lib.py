@@ -26,7 +26,7 @@ SIGNATURES = {
     'svol_gemm_nt': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _int, _p, _i64, _p, _i64, _int, _i64, _i64, _i64,
                      _int, _p],
     'svol_gemm_nt_dgelu': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p],
-    'svol_gemm_tn': [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _int, _p],
+    'svol_gemm_tn': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p],
     'svol_colsum': [_p, _i64, _p, _i64, _i64, _int, _p],
     'svol_act_bwd': [_p, _p, _p, _int, _i64, _int, _p],
     'svol_layernorm_fwd': [_p, _int, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _f32, _u64, _p, _int, _p],

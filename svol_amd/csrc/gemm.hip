@@ -12,6 +12,8 @@
 // element types: bf16 feeds v_mfma_f32_16x16x32_bf16 (one MFMA per chunk-group of 4 chunks), f32
 // feeds v_mfma_f32_16x16x4_f32 (four MFMAs per chunk group, element e of every lane's chunk) —
 // the contraction index permutation is identical for A and B so the sum is unchanged.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs p) {
 //         by 16 banks.
 // ---------------------------------------------------------------------------
 struct TnArgs {
-    const void* A; const void* B; float* C;
+    const void* A; const void* B; float* C; float* colsum;
     int64_t lda, ldb, ldc;
     int Mc, N, K, m_chunk;
 };
@@ -201,6 +203,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fq = lane >> 4;
+    // optional column sums of A (= bias gradient) on the matrix pipe: A^T * ones, only in the k-tile-0 workgroups'
+    // wk == 0 waves (every output column of the extra tile holds the same sum)
+    const bool do_cs = p.colsum != nullptr && blockIdx.x == 0 && wk == 0;
+    f32x4 cs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     load_tile(m_begin);
     for (int m0 = m_begin; m0 < m_end; m0 += CT) {
         store_tile();
@@ -230,6 +238,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
 #pragma unroll
                     for (int kt = 0; kt < 4; ++kt)
                         acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
+                if (do_cs) {
+                    bf16x8 ones;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) cs[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], ones, cs[nt], 0, 0, 0);
+                }
             }
         } else {
 #pragma unroll 2
@@ -246,6 +261,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
 #pragma unroll
                     for (int kt = 0; kt < 4; ++kt)
                         acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
+                if (do_cs) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) cs[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[nt], 1.0f, cs[nt], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -263,6 +282,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
                 if (n < p.N) atomicAdd(p.C + (int64_t)n * p.ldc + k, acc[nt][kt][r]);
             }
         }
+    if (do_cs && fr == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + nt * 16 + fq * 4 + r;
+                if (n < p.N) atomicAdd(p.colsum + n, cs[nt][r]);
+            }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -399,8 +427,8 @@ int svol_gemm_nt_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, v
     return rc;
 }
 
-int svol_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t Mc, int64_t N,
-                 int64_t K, int dtype, void* stream) {
+int svol_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum, int64_t Mc,
+                 int64_t N, int64_t K, int dtype, void* stream) {
     if (!A || !B || !C || Mc < 0 || N <= 0 || K <= 0) return SVOL_E_INVALID;
     if (Mc == 0) return SVOL_OK;
     if (dtype != SVOL_BF16 && dtype != SVOL_F32) return SVOL_E_INVALID;
@@ -410,14 +438,18 @@ int svol_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* 
     if (Mc > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return SVOL_E_UNSUPPORTED;
     const int ct = dtype == SVOL_BF16 ? 64 : 32;
     const int64_t tiles = ((N + 127) / 128) * ((K + 127) / 128);
-    // split the contraction so that ~1024 workgroups exist (256 CUs x 4), chunk a multiple of CT
-    int64_t want = (1024 + tiles - 1) / tiles;
+    // split the contraction so that ~TARGET workgroups exist, chunk a multiple of CT
+    // (measured on MI355X: the fp32 atomics of the final accumulation dominate small outputs, so few, long-running
+    //  workgroups win there: 256x256 outputs 0.065 ms at 1024 workgroups vs 0.032 ms at 256)
+    static const int force_wgs = getenv("SVOL_TN_WGS") ? atoi(getenv("SVOL_TN_WGS")) : 0;
+    const int target_wgs = force_wgs ? force_wgs : (tiles <= 8 ? 256 : 512);
+    int64_t want = (target_wgs + tiles - 1) / tiles;
     int64_t chunk = (Mc + want - 1) / want;
     chunk = ((chunk + ct - 1) / ct) * ct;
     if (chunk < 4 * ct) chunk = 4 * ct;
     const int64_t splits = (Mc + chunk - 1) / chunk;
     if (splits > 65535) return SVOL_E_UNSUPPORTED;
-    TnArgs p{A, B, C, lda, ldb, ldc, (int)Mc, (int)N, (int)K, (int)chunk};
+    TnArgs p{A, B, C, colsum, lda, ldb, ldc, (int)Mc, (int)N, (int)K, (int)chunk};
     dim3 grid((unsigned)((K + 127) / 128), (unsigned)((N + 127) / 128), (unsigned)splits);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SVOL_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, dim3(256), 0, s, p);

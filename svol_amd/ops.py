@@ -129,16 +129,17 @@ def gemm_nt(A, B, bias=None, act=ACT_NONE, residual=None, want_pre=False, out=No
     return (out, pre) if want_pre else out
 
 
-def gemm_tn(A, B, out=None):
-    """out[N,K] (fp32) += A[Mc,N]^T @ B[Mc,K]; a fresh zeroed `out` is allocated when not given."""
+def gemm_tn(A, B, out=None, colsum=None):
+    """out[N,K] (fp32) += A[Mc,N]^T @ B[Mc,K]; a fresh zeroed `out` is allocated when not given.
+    colsum (fp32 [N], zeroed by the caller) += column sums of A (bias gradient, fused)."""
     assert A.dim() == 2 and B.dim() == 2 and A.shape[0] == B.shape[0]
     assert A.stride(1) == 1 and B.stride(1) == 1
     Mc, N = A.shape
     K = B.shape[1]
     if out is None:
         out = torch.zeros((N, K), dtype=torch.float32, device=A.device)
-    rc = _lib.lib().svol_gemm_tn(_ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), out.stride(0), Mc, N, K,
-                                 _dt(A), _stream())
+    rc = _lib.lib().svol_gemm_tn(_ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), out.stride(0), _ptr(colsum),
+                                 Mc, N, K, _dt(A), _stream())
     _lib.check(rc, 'svol_gemm_tn')
     return out
 
@@ -362,19 +363,24 @@ class LinearFn(torch.autograd.Function):
             d = cast(d, x2.dtype)
         if ctx.act != ACT_NONE:
             d = act_bwd(d, y, ctx.act)
-        db = colsum(d) if ctx.has_b else None
         # out-features that are not a multiple of the 16-byte chunk (2-class / 4-coordinate heads):
         # zero-pad the contraction / column dimension
         epc = 8 if d.dtype == torch.bfloat16 else 4
         WcT = ctx.WcT
+        Np = (N + epc - 1) // epc * epc
         if N % epc:
-            Np = (N + epc - 1) // epc * epc
             dp = torch.zeros((d.shape[0], Np), dtype=d.dtype, device=d.device)
             dp[:, :N] = d
             wp = torch.zeros((WcT.shape[0], Np), dtype=WcT.dtype, device=WcT.device)
             wp[:, :N] = WcT
             d, WcT = dp, wp
-        dW = gemm_tn(d, x2)[:N]
+        # dW and db share one zeroed buffer (one memset) ; db = column sums of d, fused into the dW GEMM
+        K_ = x2.shape[1]
+        buf = torch.zeros((Np * K_ + Np,), dtype=torch.float32, device=d.device)
+        dWp, dbp = buf[:Np * K_].view(Np, K_), buf[Np * K_:]
+        gemm_tn(d, x2, out=dWp, colsum=dbp if ctx.has_b else None)
+        dW = dWp[:N]
+        db = dbp[:N] if ctx.has_b else None
         dx = gemm_nt(d, WcT).view(ctx.shp) if ctx.need_dx else None
         return dx, dW, db, None, None
 
@@ -423,9 +429,11 @@ class MLPLNFn(torch.autograd.Function):
             dpos = _pos_grad(dypos, ctx.pos_shape, D)
         ds32, ds, dg, dbt, db2 = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True,
                                                want_colsum=True)
-        dW2 = gemm_tn(ds, hid)
+        F_ = hid.shape[1]
+        wbuf = torch.zeros((2 * D * F_,), dtype=torch.float32, device=ds.device)  # one memset for dW1 | dW2
+        dW2 = gemm_tn(ds, hid, out=wbuf[D * F_:].view(D, F_))
         dpre, db1 = gemm_nt_dgelu(ds, ctx.W2T, pre)  # (ds W2) * gelu'(pre) and its column sums, one kernel
-        dW1 = gemm_tn(dpre, x2)
+        dW1 = gemm_tn(dpre, x2, out=wbuf[:D * F_].view(F_, D))
         dx = gemm_nt(dpre, ctx.W1T)
         return ds32.view(ctx.shp), dx.view(ctx.shp), dW1, db1, dW2, db2, dg, dbt, dpos
 
@@ -485,18 +493,18 @@ class AttnLNFn(torch.autograd.Function):
             dpos = _pos_grad(dypos, ctx.pos_shape, d)
         ds32, g, dg, dbt, dbo = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True,
                                               want_colsum=True)
-        dWo = gemm_tn(g, o)
+        gbuf = torch.zeros((3 * d * d + 3 * d + d * d,), dtype=torch.float32, device=g.device)  # one memset for all
+        dW_in, db_in = gbuf[:3 * d * d].view(3 * d, d), gbuf[3 * d * d:3 * d * d + 3 * d]
+        dWo = gbuf[3 * d * d + 3 * d:].view(d, d)
+        gemm_tn(g, o, out=dWo)
         do = gemm_nt(g, WoT)
-        dW_in = torch.zeros((3 * d, d), dtype=torch.float32, device=g.device)
-        db_in = torch.zeros((3 * d,), dtype=torch.float32, device=g.device)
         shq = (B, Lq, d)
         if ctx.self_attn:
             dqkv = torch.empty((B * Lq, 3 * d), dtype=dt, device=g.device)
             dq, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
             attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias, ctx.premul)
-            gemm_tn(dqkv[:, :2 * d], a_qp, out=dW_in[:2 * d])
-            gemm_tn(dv, a_q, out=dW_in[2 * d:])
-            colsum(dqkv, out=db_in)
+            gemm_tn(dqkv[:, :2 * d], a_qp, out=dW_in[:2 * d], colsum=db_in[:2 * d])
+            gemm_tn(dv, a_q, out=dW_in[2 * d:], colsum=db_in[2 * d:])
             dxq_pos = gemm_nt(dqkv[:, :2 * d], WcT[:, :2 * d])  # d(x + pos) = [dq dk] W_qk
             dxq = gemm_nt(dv, WcT[:, 2 * d:])                    # d(x) through V
             return (ds32.view(shq), dxq.view(shq), dxq_pos.view(shq), None, None, dW_in, db_in, dWo, dbo, dg, dbt,
@@ -505,11 +513,9 @@ class AttnLNFn(torch.autograd.Function):
         dkv = torch.empty((B * Lk, 2 * d), dtype=dt, device=g.device)
         dk, dv = dkv[:, :d], dkv[:, d:]
         attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias, ctx.premul)
-        gemm_tn(dq, a_qp, out=dW_in[:d])
-        gemm_tn(dk, a_kp, out=dW_in[d:2 * d])
-        gemm_tn(dv, a_v, out=dW_in[2 * d:])
-        colsum(dq, out=db_in[:d])
-        colsum(dkv, out=db_in[d:])
+        gemm_tn(dq, a_qp, out=dW_in[:d], colsum=db_in[:d])
+        gemm_tn(dk, a_kp, out=dW_in[d:2 * d], colsum=db_in[d:2 * d])
+        gemm_tn(dv, a_v, out=dW_in[2 * d:], colsum=db_in[2 * d:])
         dxq_pos = gemm_nt(dq, WcT[:, :d])
         dxk_pos = gemm_nt(dk, WcT[:, d:2 * d])
         dxv = gemm_nt(dv, WcT[:, 2 * d:])
