@@ -144,12 +144,15 @@ def gemm_tn(A, B, out=None, colsum=None):
     return out
 
 
-def gemm_nt_dgelu(A, B, pre, want_colsum=True):
-    """(A @ B^T) * gelu'(pre), and its column sums (fp32) — fused MLP backward step."""
+def gemm_nt_dgelu(A, B, pre, want_colsum=True, colsum_out=None):
+    """(A @ B^T) * gelu'(pre), and its column sums (fp32, accumulated into colsum_out when given) — fused MLP
+    backward step."""
     M, K = A.shape
     N = B.shape[0]
     out = torch.empty((M, N), dtype=A.dtype, device=A.device)
-    cs = torch.zeros((N,), dtype=torch.float32, device=A.device) if want_colsum else None
+    cs = colsum_out
+    if cs is None and want_colsum:
+        cs = torch.zeros((N,), dtype=torch.float32, device=A.device)
     rc = _lib.lib().svol_gemm_nt_dgelu(_ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), out.stride(0), _ptr(pre),
                                        pre.stride(0), _ptr(cs), M, N, K, _dt(A), _stream())
     _lib.check(rc, 'svol_gemm_nt_dgelu')
@@ -196,7 +199,7 @@ def layernorm_fwd(x, gamma, beta, dtype, pos=None, p=0.0, seed=0, want32=False, 
 
 
 def layernorm_bwd(dy32, dy, dy2, x, gamma, mean, rstd, dtype, p=0.0, seed=0, want32=False, want_t=True,
-                  want_colsum=False, seed_dev=None):
+                  want_colsum=False, seed_dev=None, dg_out=None, db_out=None, cs_out=None):
     """LN backward; any of dy32 (fp32) / dy / dy2 (`dtype`) may be None.  Returns (dx32|None, dx|None, dg, db)
     (+ the column sums of dx when want_colsum: the bias gradient of the Linear feeding this LN)."""
     M, D = x.shape
@@ -207,8 +210,12 @@ def layernorm_bwd(dy32, dy, dy2, x, gamma, mean, rstd, dtype, p=0.0, seed=0, wan
     assert (dy is None or dy.dtype == dtype) and (dy2 is None or dy2.dtype == dtype)
     dx32 = torch.empty((M, D), dtype=torch.float32, device=x.device) if want32 else None
     dx = torch.empty((M, D), dtype=dtype, device=x.device) if want_t else None
-    red = torch.zeros((3, D), dtype=torch.float32, device=x.device)  # one memset for dgamma | dbeta | colsum(dx)
-    dg, db, cs = red[0], red[1], (red[2] if want_colsum else None)
+    dg, db, cs = dg_out, db_out, (cs_out if want_colsum else None)  # accumulated into (gradient sinks) when given
+    if dg is None or db is None or (want_colsum and cs is None):
+        red = torch.zeros((3, D), dtype=torch.float32, device=x.device)  # one memset for dgamma | dbeta | colsum(dx)
+        dg = red[0] if dg is None else dg
+        db = red[1] if db is None else db
+        cs = (red[2] if cs is None else cs) if want_colsum else None
     rc = _lib.lib().svol_layernorm_bwd(_ptr(dy32), _ptr(dy), _ptr(dy2), _ptr(x), x_f32, _ptr(gamma), _ptr(mean),
                                        _ptr(rstd), _ptr(dx32), _ptr(dx), _ptr(dg), _ptr(db), _ptr(cs), M, D, float(p),
                                        int(seed), _ptr(seed_dev), _DT[dtype], _stream())
@@ -301,6 +308,33 @@ weights = _WeightCache()
 
 
 # ----------------------------------------------------------------------------
+# gradient sinks: when svol_amd.parallel.BucketedGradAllReduce owns the gradients (param.grad is a view into
+# a flat fp32 bucket that is zeroed once per step), the weight-/bias-/LayerNorm-gradient kernels accumulate
+# STRAIGHT into that view and the Function returns None for the parameter — no per-parameter memset, no
+# AccumulateGrad add.  The parameter's post-accumulate-grad hook (the reducer's bucket countdown) still fires:
+# autograd runs the AccumulateGrad node with an undefined gradient after the producing Function has finished.
+# ----------------------------------------------------------------------------
+class GradSink:
+    __slots__ = ('view',)
+
+    def __init__(self, view):
+        self.view = view
+
+
+def _claim(p, needed=True):
+    """forward: the sink of parameter `p` if its gradient can be written in place, else None."""
+    s = getattr(p, '_svol_sink', None) if (needed and p is not None) else None
+    g = p.grad if s is not None else None
+    if g is None or g.data_ptr() != s.view.data_ptr():
+        return None
+    return s
+
+
+def _tgt(sink, shape, device):
+    return sink.view if sink is not None else torch.zeros(shape, dtype=torch.float32, device=device)
+
+
+# ----------------------------------------------------------------------------
 # autograd Functions
 # ----------------------------------------------------------------------------
 def _pos_grad(dypos, pos_shape, D):
@@ -322,13 +356,16 @@ class LayerNormFn(torch.autograd.Function):
         _, y, _, mean, rstd = layernorm_fwd(x2, gamma, beta, x.dtype, None, p, seed, seed_dev=seed_dev)
         ctx.save_for_backward(x2, gamma, mean, rstd, seed_dev)
         ctx.p, ctx.seed, ctx.shp = p, seed, shp
+        ctx.sinks = (_claim(gamma, ctx.needs_input_grad[1]), _claim(beta, ctx.needs_input_grad[2]))
         return y.view(shp)
 
     @staticmethod
     def backward(ctx, dy):
         x2, gamma, mean, rstd, seed_dev = ctx.saved_tensors
-        _, dx, dg, db = layernorm_bwd(None, dy, None, x2, gamma, mean, rstd, x2.dtype, ctx.p, ctx.seed, seed_dev=seed_dev)
-        return dx.view(ctx.shp), dg, db, None, None, None
+        sg, sb = ctx.sinks
+        _, dx, dg, db = layernorm_bwd(None, dy, None, x2, gamma, mean, rstd, x2.dtype, ctx.p, ctx.seed, seed_dev=seed_dev,
+                                      dg_out=sg.view if sg else None, db_out=sb.view if sb else None)
+        return dx.view(ctx.shp), None if sg else dg, None if sb else db, None, None, None
 
 
 def layer_norm(x, gamma, beta, p=0.0, seed=0, seed_dev=None):
@@ -350,6 +387,9 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x2, y if act != ACT_NONE else None)
         ctx.WcT, ctx.act, ctx.shp, ctx.has_b = WcT, act, shp, b is not None
         ctx.need_dx = ctx.needs_input_grad[0]
+        epc = 8 if x.dtype == torch.bfloat16 else 4
+        ok = W.shape[0] % epc == 0
+        ctx.sinks = (_claim(W, ok and ctx.needs_input_grad[1]), _claim(b, ok and ctx.needs_input_grad[2]))
         return y.view(*shp[:-1], W.shape[0])
 
     @staticmethod
@@ -374,13 +414,24 @@ class LinearFn(torch.autograd.Function):
             wp = torch.zeros((WcT.shape[0], Np), dtype=WcT.dtype, device=WcT.device)
             wp[:, :N] = WcT
             d, WcT = dp, wp
-        # dW and db share one zeroed buffer (one memset) ; db = column sums of d, fused into the dW GEMM
+        # db = column sums of d, fused into the dW GEMM; without gradient sinks dW and db share one zeroed buffer
         K_ = x2.shape[1]
-        buf = torch.zeros((Np * K_ + Np,), dtype=torch.float32, device=d.device)
-        dWp, dbp = buf[:Np * K_].view(Np, K_), buf[Np * K_:]
-        gemm_tn(d, x2, out=dWp, colsum=dbp if ctx.has_b else None)
-        dW = dWp[:N]
-        db = dbp[:N] if ctx.has_b else None
+        sW, sb = ctx.sinks
+        if sW is not None and (sb is not None or not ctx.has_b):
+            gemm_tn(d, x2, out=sW.view, colsum=sb.view if sb else None)
+            dW = db = None
+        else:
+            buf = torch.zeros((Np * K_ + Np,), dtype=torch.float32, device=d.device)
+            dWp, dbp = buf[:Np * K_].view(Np, K_), buf[Np * K_:]
+            gemm_tn(d, x2, out=dWp, colsum=dbp if ctx.has_b else None)
+            dW = dWp[:N]
+            db = dbp[:N] if ctx.has_b else None
+            if sW is not None:
+                sW.view.add_(dW)
+                dW = None
+            if sb is not None:
+                sb.view.add_(db)
+                db = None
         dx = gemm_nt(d, WcT).view(ctx.shp) if ctx.need_dx else None
         return dx, dW, db, None, None
 
@@ -415,6 +466,8 @@ class MLPLNFn(torch.autograd.Function):
         ctx.save_for_backward(x2, pre, hid, s32, gamma, mean, rstd)
         ctx.W1T, ctx.W2T, ctx.shp = W1T, W2T, shp
         ctx.pos_shape = pos_out.shape if pos_out is not None else None
+        nig = ctx.needs_input_grad
+        ctx.sinks = tuple(_claim(p_, nig[i]) for i, p_ in ((2, W1), (3, b1), (4, W2), (5, b2), (6, gamma), (7, beta)))
         if pos_out is not None:
             return y32.view(shp), y.view(shp), ypos.view(shp)
         return y32.view(shp), y.view(shp)
@@ -427,15 +480,28 @@ class MLPLNFn(torch.autograd.Function):
         dpos = None
         if ctx.pos_shape is not None and ctx.needs_input_grad[8] and dypos is not None:
             dpos = _pos_grad(dypos, ctx.pos_shape, D)
+        sW1, sb1, sW2, sb2, sg, sbt = ctx.sinks
+        vw = lambda s_: s_.view if s_ is not None else None
         ds32, ds, dg, dbt, db2 = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True,
-                                               want_colsum=True)
+                                               want_colsum=True, dg_out=vw(sg), db_out=vw(sbt), cs_out=vw(sb2))
         F_ = hid.shape[1]
-        wbuf = torch.zeros((2 * D * F_,), dtype=torch.float32, device=ds.device)  # one memset for dW1 | dW2
-        dW2 = gemm_tn(ds, hid, out=wbuf[D * F_:].view(D, F_))
-        dpre, db1 = gemm_nt_dgelu(ds, ctx.W2T, pre)  # (ds W2) * gelu'(pre) and its column sums, one kernel
-        dW1 = gemm_tn(dpre, x2, out=wbuf[:D * F_].view(F_, D))
+        if sW1 is not None and sW2 is not None:
+            dW1, dW2 = sW1.view, sW2.view
+        else:
+            wbuf = torch.zeros((2 * D * F_,), dtype=torch.float32, device=ds.device)  # one memset for dW1 | dW2
+            dW1, dW2 = wbuf[:D * F_].view(F_, D), wbuf[D * F_:].view(D, F_)
+        gemm_tn(ds, hid, out=dW2)
+        # (ds W2) * gelu'(pre) and its column sums, one kernel
+        dpre, db1 = gemm_nt_dgelu(ds, ctx.W2T, pre, colsum_out=vw(sb1))
+        gemm_tn(dpre, x2, out=dW1)
         dx = gemm_nt(dpre, ctx.W1T)
-        return ds32.view(ctx.shp), dx.view(ctx.shp), dW1, db1, dW2, db2, dg, dbt, dpos
+        if (sW1 is None) != (sW2 is None):  # only one of the two has a sink: add the other by hand
+            for s_, g_ in ((sW1, dW1), (sW2, dW2)):
+                if s_ is not None:
+                    s_.view.add_(g_)
+        n_ = lambda s_, g_: None if s_ is not None else g_
+        return (ds32.view(ctx.shp), dx.view(ctx.shp), n_(sW1, dW1), n_(sb1, db1), n_(sW2, dW2), n_(sb2, db2), n_(sg, dg),
+                n_(sbt, dbt), dpos)
 
 
 class AttnLNFn(torch.autograd.Function):
@@ -477,6 +543,11 @@ class AttnLNFn(torch.autograd.Function):
         ctx.save_for_backward(a_qp, a_q, a_kp, a_v, q, k, v, o, lse2, kbias, s32, gamma, mean, rstd)
         ctx.WcT, ctx.WoT, ctx.dims, ctx.self_attn, ctx.premul = WcT, WoT, (B, H, Lq, Lk, dh, d), self_attn, premul
         ctx.pos_shape = pos_out.shape if pos_out is not None else None
+        nig = ctx.needs_input_grad
+        ctx.sinks = tuple(_claim(p_, nig[i]) for i, p_ in ((5, W_in), (6, b_in), (7, W_o), (8, b_o), (9, gamma),
+                                                           (10, beta)))
+        if any(s_ is None for s_ in ctx.sinks):  # all or nothing
+            ctx.sinks = None
         shp = (B, Lq, d)
         if pos_out is not None:
             return y32.view(shp), y.view(shp), ypos.view(shp)
@@ -491,11 +562,18 @@ class AttnLNFn(torch.autograd.Function):
         dpos = None
         if ctx.pos_shape is not None and ctx.needs_input_grad[11] and dypos is not None:
             dpos = _pos_grad(dypos, ctx.pos_shape, d)
-        ds32, g, dg, dbt, dbo = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True,
-                                              want_colsum=True)
-        gbuf = torch.zeros((3 * d * d + 3 * d + d * d,), dtype=torch.float32, device=g.device)  # one memset for all
-        dW_in, db_in = gbuf[:3 * d * d].view(3 * d, d), gbuf[3 * d * d:3 * d * d + 3 * d]
-        dWo = gbuf[3 * d * d + 3 * d:].view(d, d)
+        sk = ctx.sinks
+        if sk is not None:
+            dW_in, db_in, dWo = sk[0].view, sk[1].view, sk[2].view
+            ds32, g, dg, dbt, dbo = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True,
+                                                  want_colsum=True, dg_out=sk[4].view, db_out=sk[5].view,
+                                                  cs_out=sk[3].view)
+        else:
+            ds32, g, dg, dbt, dbo = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True,
+                                                  want_colsum=True)
+            gbuf = torch.zeros((3 * d * d + 3 * d + d * d,), dtype=torch.float32, device=g.device)  # one memset
+            dW_in, db_in = gbuf[:3 * d * d].view(3 * d, d), gbuf[3 * d * d:3 * d * d + 3 * d]
+            dWo = gbuf[3 * d * d + 3 * d:].view(d, d)
         gemm_tn(g, o, out=dWo)
         do = gemm_nt(g, WoT)
         shq = (B, Lq, d)
@@ -507,6 +585,8 @@ class AttnLNFn(torch.autograd.Function):
             gemm_tn(dv, a_q, out=dW_in[2 * d:], colsum=db_in[2 * d:])
             dxq_pos = gemm_nt(dqkv[:, :2 * d], WcT[:, :2 * d])  # d(x + pos) = [dq dk] W_qk
             dxq = gemm_nt(dv, WcT[:, 2 * d:])                    # d(x) through V
+            if sk is not None:
+                dW_in = db_in = dWo = dbo = dg = dbt = None
             return (ds32.view(shq), dxq.view(shq), dxq_pos.view(shq), None, None, dW_in, db_in, dWo, dbo, dg, dbt,
                     dpos, None, None, None)
         dq = torch.empty((B * Lq, d), dtype=dt, device=g.device)
@@ -520,6 +600,8 @@ class AttnLNFn(torch.autograd.Function):
         dxk_pos = gemm_nt(dk, WcT[:, d:2 * d])
         dxv = gemm_nt(dv, WcT[:, 2 * d:])
         shk = (B, Lk, d)
+        if sk is not None:
+            dW_in = db_in = dWo = dbo = dg = dbt = None
         return (ds32.view(shq), None, dxq_pos.view(shq), dxk_pos.view(shk), dxv.view(shk), dW_in, db_in, dWo, dbo, dg,
                 dbt, dpos, None, None, None)
 
@@ -578,6 +660,7 @@ class GateFn(torch.autograd.Function):
         _lib.check(rc, 'svol_gate_fwd')
         ctx.save_for_backward(x2, pos2, u, gamma, a, mean, rstd, ws)
         ctx.dims = (B, L, D, H)
+        ctx.sinks = (_claim(gamma, ctx.needs_input_grad[3]), _claim(beta, ctx.needs_input_grad[4]))
         return y32.view(B, L, D), y.view(B, L, D), ypos.view(B, L, D)
 
     @staticmethod
@@ -587,15 +670,17 @@ class GateFn(torch.autograd.Function):
         cont = lambda t: None if t is None else t.reshape(B * L, D).contiguous()
         dy32, dy, dypos = cont(dy32), cont(dy), cont(dypos)
         dx32 = torch.empty_like(x2)
-        du = torch.zeros((B, H, D), dtype=torch.float32, device=x2.device)
-        dg = torch.zeros((D,), dtype=torch.float32, device=x2.device)
-        db = torch.zeros((D,), dtype=torch.float32, device=x2.device)
+        sg, sb = ctx.sinks
+        zb = torch.zeros((B * H * D + 2 * D,), dtype=torch.float32, device=x2.device)  # one memset: du | dgamma | dbeta
+        du = zb[:B * H * D].view(B, H, D)
+        dg = sg.view if sg else zb[B * H * D:B * H * D + D]
+        db = sb.view if sb else zb[B * H * D + D:]
         ws2 = torch.empty((B * L + B * H,), dtype=torch.float32, device=x2.device)
         rc = _lib.lib().svol_gate_bwd(_ptr(dy32), _ptr(dy), _ptr(dypos), _ptr(x2), _ptr(pos2), _ptr(u), _ptr(gamma),
                                       _ptr(a), _ptr(mean), _ptr(rstd), _ptr(ws), _ptr(ws2), _ptr(dx32), _ptr(du),
                                       _ptr(dg), _ptr(db), B, L, D, H, _DT[pos2.dtype], _stream())
         _lib.check(rc, 'svol_gate_bwd')
-        return dx32.view(B, L, D), None, du, dg, db, None
+        return dx32.view(B, L, D), None, du, None if sg else dg, None if sb else db, None
 
 
 def gate(x32, pos, u, gamma, beta, H):

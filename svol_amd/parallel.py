@@ -54,9 +54,13 @@ class BucketedGradAllReduce:
         self._handles = []
         self._hooks = []
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        from .ops import GradSink
         for bi, b in enumerate(self.buckets):
             for p in b['params']:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+                # the svol kernels accumulate weight / bias / LayerNorm gradients straight into the bucket view
+                # (svol_amd.ops "gradient sinks"); the hook above still fires for them
+                p._svol_sink = GradSink(p.grad)
 
     def _make_bucket(self, params):
         n = sum(p.numel() for p in params)
@@ -120,6 +124,10 @@ class BucketedGradAllReduce:
         for h in self._hooks:
             h.remove()
         self._hooks.clear()
+        for b in self.buckets:
+            for p in b['params']:
+                if hasattr(p, '_svol_sink'):
+                    del p._svol_sink
 
 
 def unused_parameters(model: torch.nn.Module):

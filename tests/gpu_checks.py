@@ -414,9 +414,10 @@ def check_lsap_vs_scipy(n_cases=60):
 
 
 # ---------------------------------------------------------------------------
-def run_head_case(name, dtype):
+def run_head_case(name, dtype, sinks=False):
     """Full head + criterion forward/backward through the product modules; returns
-    (outputs dict, loss dict, total, model, criterion)."""
+    (outputs dict, loss dict, total, model, criterion).  sinks: gradients owned by BucketedGradAllReduce
+    (the kernels accumulate straight into the flat buckets, svol_amd.ops "gradient sinks")."""
     from svol_amd.modeling.loss import build_loss
     from svol_amd.modeling.svanet import build_svanet
     from tests.helpers import head_case
@@ -426,16 +427,24 @@ def run_head_case(name, dtype):
     model.load_state_dict(sd, strict=True)
     model = model.to(DEV).eval()
     crit = build_loss(args).to(DEV).eval()
+    if sinks:
+        from svol_amd import parallel
+        red = parallel.BucketedGradAllReduce([p for p in model.parameters()], bucket_bytes=1 << 20,
+                                             skip=parallel.unused_parameters(model))
+        red.zero_grad()
+        model._test_reducer = red
     out = model(inp['src_sketch'].to(DEV), inp['src_sketch_mask'].to(DEV), inp['src_video'].to(DEV),
                 inp['src_video_mask'].to(DEV))
     ld = crit(out, tg)
     wd = crit.weight_dict
     tot = sum(ld[k] * wd[k] for k in ld.keys() if k in wd)
     tot.backward()
+    if sinks:
+        red.finish()
     return z, meta, args, out, ld, tot, model, crit
 
 
-def check_head_case(name, dtype):
+def check_head_case(name, dtype, sinks=False):
     """Whole hot path through the product modules vs the reference's golden vectors.
 
     * final-layer outputs (pred_logits / pred_boxes — the outputs north_star names): |diff| <= 1e-3 fp32 /
@@ -458,8 +467,10 @@ def check_head_case(name, dtype):
     fp32 = dtype == torch.float32
     tol = 1e-3 if fp32 else (1.5e-2 if name.startswith('tiny') else 1e-2)
     res = {}
-    z, meta, args, out, ld, tot, model, crit = run_head_case(name, dtype)
-    tag = f'head/{name}/{"fp32" if fp32 else "bf16"}'
+    z, meta, args, out, ld, tot, model, crit = run_head_case(name, dtype, sinks)
+    tag = f'head/{name}/{"fp32" if fp32 else "bf16"}' + ('/sinks' if sinks else '')
+    if sinks:  # every bucket saw all of its parameters complete exactly once
+        res[tag + '/buckets_incomplete'] = (float(sum(b['pending'] != 0 for b in model._test_reducer.buckets)), 0.0)
     res[tag + '/pred_logits_abs'] = (float((out['pred_logits'].cpu() - torch.from_numpy(z['pred_logits'])).abs().max()), tol)
     res[tag + '/pred_boxes_abs'] = (float((out['pred_boxes'].cpu() - torch.from_numpy(z['pred_boxes'])).abs().max()), tol)
     if 'aux_logits' in z.files:
