@@ -69,6 +69,31 @@ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, floa
     return u < p ? 0.0f : inv_keep;
 }
 
+// erf-GELU for the bf16 GEMM epilogues: Phi(x) from the Abramowitz-Stegun 7.1.26 rational form of erfc
+// (|abs error| < 1.5e-7 on Phi, no cancellation for x < 0), 2 transcendental + ~10 plain VALU ops instead of the
+// branchy library erff.  The Gaussian exp(-x^2/2) it needs is the same one gelu'(x) needs.
+__device__ __forceinline__ void gelu_parts(float x, float& Phi, float& E) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    E = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);  // exp(-x^2/2)
+    float q = fmaf(1.061405429f, t, -1.453152027f);
+    q = fmaf(q, t, 1.421413741f);
+    q = fmaf(q, t, -0.284496736f);
+    q = fmaf(q, t, 0.254829592f);
+    const float h = 0.5f * q * t * E;  // = 0.5 erfc(|x|/sqrt2)
+    Phi = x >= 0.f ? 1.0f - h : h;
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+    float Phi, E;
+    gelu_parts(x, Phi, E);
+    return x * Phi;
+}
+__device__ __forceinline__ float dgelu_fast(float x) {
+    float Phi, E;
+    gelu_parts(x, Phi, E);
+    return fmaf(x * 0.39894228040143267794f, E, Phi);
+}
+
 // exact (erf) GELU and derivative
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float dgelu_f(float x) {

@@ -6,6 +6,8 @@
 // u[b,h,:] = d_h^-1/2 * W_k,h^T q[b,h,:] (the k-bias adds a per-(b,h) constant that cancels in the
 // softmax), so the [L,d]x[d,d] K projection, the V projection, P.V and out_proj of the reference are
 // never computed.  Forward = 3 passes over x (scores, per-(b,h) max/sum, apply+LN1); backward = 3.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -316,21 +318,42 @@ __global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const float* __rest
             }
         }
     }
+    // du: fold the workgroup's four waves in LDS first (every wave of a batch element hits the same H*D addresses)
+    __shared__ float red[GH * NP * 256];
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
 #pragma unroll
-    for (int hh = 0; hh < GH; ++hh)
+            for (int hh = 0; hh < GH; ++hh)
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int c = (lane + 64 * j) * 4;
-            if (hh < H && c < D) {
+                for (int j = 0; j < NP; ++j) {
+                    const int c = (lane + 64 * j) * 4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) atomicAdd(du + ((int64_t)b * H + hh) * D + c + e, dur[hh][j][e]);
-            }
+                    for (int e = 0; e < 4; ++e) {
+                        float* r = red + hh * NP * 256 + c + e;
+                        if (w == 0) *r = dur[hh][j][e];
+                        else *r += dur[hh][j][e];
+                    }
+                }
         }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < GH * NP * 256; i += 256) {
+        const int hh = i / (NP * 256), c = i % (NP * 256);
+        if (hh < H && c < D) atomicAdd(du + ((int64_t)b * H + hh) * D + c, red[i]);
+    }
 }
 
 int rows_per_wave(int64_t rows, int64_t target_waves) {
     int64_t r = (rows + target_waves - 1) / target_waves;
     return (int)(r < 1 ? 1 : r);
+}
+// total waves of the row-loop kernels: enough resident waves per SIMD to cover HBM latency (each wave walks its rows
+// one after the other), few enough that the per-wave u registers / LDS reductions stay amortised
+int64_t gate_waves(int which) {
+    static const char* names[3] = {"SVOL_GATE_WAVES_SC", "SVOL_GATE_WAVES_LN", "SVOL_GATE_WAVES_AP"};
+    static int64_t w[3] = {0, 0, 0};
+    if (!w[which]) w[which] = getenv(names[which]) ? atoll(getenv(names[which])) : 4096;
+    return w[which] < 64 ? 64 : w[which];
 }
 
 }  // namespace
@@ -349,7 +372,7 @@ int svol_gate_fwd(const float* x32, const void* pos, const float* u, const float
     float* scores = ws;
     float* mx = ws + B * H * L;
     float* sm = mx + B * H;
-    const int rpw = rows_per_wave(L, 2048 / (B > 2048 ? 2048 : B) + 1);
+    const int rpw = rows_per_wave(L, gate_waves(0) / B + 1);
     dim3 g1((unsigned)((L + 4 * rpw - 1) / (4 * rpw)), (unsigned)B);
     const int64_t M = B * L;
     const unsigned g3 = (unsigned)((M + 3) / 4);
@@ -387,9 +410,9 @@ int svol_gate_bwd(const float* dy32, const void* dy, const void* dy2, const floa
     float* da = ws2;
     float* cc = ws2 + B * L;
     const int64_t M = B * L;
-    const int rpw1 = rows_per_wave(M, 2048);
+    const int rpw1 = rows_per_wave(M, gate_waves(1));
     const unsigned g1 = (unsigned)(((M + rpw1 - 1) / rpw1 + 3) / 4);
-    const int rpw3 = rows_per_wave(L, 2048 / (B > 2048 ? 2048 : B) + 1);
+    const int rpw3 = rows_per_wave(L, gate_waves(2) / B + 1);
     dim3 g3((unsigned)((L + 4 * rpw3 - 1) / (4 * rpw3)), (unsigned)B);
 #define SVOL_GATE_BWD(TT)                                                                                                   \
     do {                                                                                                                    \

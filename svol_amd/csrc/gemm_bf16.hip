@@ -180,7 +180,7 @@ __device__ __forceinline__ void gemm_nt_bf16_body(const FastArgs& p) {
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                     } else if (p.act == SVOL_ACT_GELU) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
                     } else if (p.act == SVOL_ACT_SIGMOID) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
@@ -199,10 +199,10 @@ __device__ __forceinline__ void gemm_nt_bf16_body(const FastArgs& p) {
                     if (colv) {
                         const f32x4 a = Out4<bf16_t>::load(p.aux + (int64_t)m * p.ldaux + ncol);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(a[e]);
+                        for (int e = 0; e < 4; ++e) v[e] *= dgelu_fast(a[e]);
                     } else {
                         for (int e = 0; e < 4; ++e)
-                            v[e] = (ncol + e < p.N) ? v[e] * dgelu_f((float)p.aux[(int64_t)m * p.ldaux + ncol + e]) : 0.f;
+                            v[e] = (ncol + e < p.N) ? v[e] * dgelu_fast((float)p.aux[(int64_t)m * p.ldaux + ncol + e]) : 0.f;
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) csum[e] += v[e];

@@ -71,6 +71,40 @@ if 'gemm' in which:
     t = timeit(lambda: ops.act_bwd(X, X, ops.ACT_GELU))
     print(f'act_bwd gelu [{M},{F}]: {t:.3f} ms  {X.numel() * 6 / t / 1e6:.0f} GB/s')
 
+if 'gemm2' in which:  # the step's GEMM variants with their real epilogues; GB/s over algorithmic HBM bytes
+    M = B * L
+    x = rnd(M, D)
+    x32 = torch.randn(M, D, device=DEV)
+    hid = rnd(M, F)
+    W_dd, W_fd, W_df = rnd(D, D, scale=0.05), rnd(F, D, scale=0.05), rnd(D, F, scale=0.05)
+    W_2dd = rnd(2 * D, D, scale=0.05)
+    b_d, b_f, b_2d = torch.zeros(D, device=DEV), torch.zeros(F, device=DEV), torch.zeros(2 * D, device=DEV)
+    qs = torch.ones(2 * D, device=DEV)
+    qkv = torch.empty((M, 3 * D), dtype=torch.bfloat16, device=DEV)
+    x2 = rnd(M, 2 * D)
+    cases = [
+        ('qk proj  N=512 K=256 colscale', lambda: ops.gemm_nt(x, W_2dd, b_2d, out=qkv[:, :2 * D], colscale=qs), 2 * D, D, M * D * 2 + M * 2 * D * 2),
+        ('v proj   N=256 K=256', lambda: ops.gemm_nt(x, W_dd, b_d, out=qkv[:, 2 * D:]), D, D, M * D * 4),
+        ('out proj N=256 K=256 f32+res', lambda: ops.gemm_nt(x, W_dd, b_d, residual=x32, out_f32=True), D, D, M * D * (2 + 4 + 4)),
+        ('fc1      N=1024 K=256 gelu+pre', lambda: ops.gemm_nt(x, W_fd, b_f, ops.ACT_GELU, want_pre=True), F, D, M * D * 2 + M * F * 4),
+        ('dgelu    N=1024 K=256', lambda: ops.gemm_nt_dgelu(x, W_fd, hid), F, D, M * D * 2 + M * F * 4),
+        ('fc2      N=256 K=1024 f32+res', lambda: ops.gemm_nt(hid, W_df, b_d, residual=x32, out_f32=True), D, F, M * F * 2 + M * D * 8),
+        ('dx mlp   N=256 K=1024', lambda: ops.gemm_nt(hid, W_df), D, F, M * F * 2 + M * D * 2),
+        ('dx qk    N=256 K=512', lambda: ops.gemm_nt(x2, rnd(D, 2 * D, scale=0.05)), D, 2 * D, M * 2 * D * 2 + M * D * 2),
+    ]
+    for name, fn, n, kk, byts in cases:
+        t = timeit(fn)
+        print(f'{name:34s}: {t * 1e3:7.1f} us  {2.0 * M * n * kk / t / 1e9:6.1f} TFLOP/s  {byts / t / 1e6:6.0f} GB/s')
+    g = rnd(M, D)
+    for name, fn, n, kk, byts in [
+        ('tn dW proj N=256 K=256', lambda: ops.gemm_tn(g, x), D, D, M * D * 4),
+        ('tn dW qk   N=512 K=256', lambda: ops.gemm_tn(x2, x), 2 * D, D, M * D * 6),
+        ('tn dW fc2  N=256 K=1024', lambda: ops.gemm_tn(g, hid), D, F, M * (D + F) * 2),
+        ('tn dW fc1  N=1024 K=256', lambda: ops.gemm_tn(hid, x), F, D, M * (D + F) * 2),
+    ]:
+        t = timeit(fn)
+        print(f'{name:34s}: {t * 1e3:7.1f} us  {2.0 * M * n * kk / t / 1e9:6.1f} TFLOP/s  {byts / t / 1e6:6.0f} GB/s')
+
 if 'ln' in which:
     M = B * L
     x = torch.randn(M, D, device=DEV)
@@ -81,3 +115,19 @@ if 'ln' in which:
     y32, y, yp, mean, rstd = ops.layernorm_fwd(x, g, b_, torch.bfloat16, pos, want32=True)
     t = timeit(lambda: ops.layernorm_bwd(x, y, yp, x, g, mean, rstd, torch.bfloat16, want32=True))
     print(f'ln_bwd [{M},{D}]: {t:.3f} ms  {M * D * (4 + 2 + 2 + 4 + 4 + 2) / t / 1e6:.0f} GB/s')
+
+if 'gate' in which:
+    M = B * L
+    x32 = torch.randn(B, L, D, device=DEV)
+    pos = rnd(B, L, D)
+    u = torch.randn(B, H, D, device=DEV) * 0.05
+    g, b_ = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
+    x32.requires_grad_(True); u.requires_grad_(True)
+    y32, y, yp = ops.gate(x32, pos, u, g, b_, H)
+    t = timeit(lambda: ops.gate(x32, pos, u, g, b_, H))
+    print(f'gate fwd: {t * 1e3:.1f} us')
+    dy32, dy, dyp = torch.randn_like(y32), torch.randn_like(y), torch.randn_like(yp)
+    def bw():
+        torch.autograd.grad((y32, y, yp), (x32, u), (dy32, dy, dyp), retain_graph=True)
+    t = timeit(bw)
+    print(f'gate bwd: {t * 1e3:.1f} us')
