@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs p) {
 struct TnArgs {
     const void* A; const void* B; float* C; float* colsum;
     int64_t lda, ldb, ldc;
-    int Mc, N, K, m_chunk;
+    int Mc, N, K, m_chunk, ktiles, splits;
 };
 
 template <typename T> struct TnCfg;
@@ -168,8 +168,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wk = wave & 1;
-    const int n0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
-    const int m_begin = blockIdx.z * p.m_chunk;
+    // 1-D grid, split index fastest: consecutive workgroup ids go to consecutive XCDs, so with splits % 8 == 0 all
+    // output tiles of one row chunk run on the same XCD and share its L2 for the re-read A / B rows
+    const int split = blockIdx.x % p.splits, tile = blockIdx.x / p.splits;
+    const int kt_ = tile % p.ktiles, nt_ = tile / p.ktiles;
+    const int n0 = nt_ * 128, k0 = kt_ * 128;
+    const int m_begin = split * p.m_chunk;
     const int m_end = min(p.Mc, m_begin + p.m_chunk);
     const T* A = reinterpret_cast<const T*>(p.A);
     const T* B = reinterpret_cast<const T*>(p.B);
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
     const int fr = lane & 15, fq = lane >> 4;
     // optional column sums of A (= bias gradient) on the matrix pipe: A^T * ones, only in the k-tile-0 workgroups'
     // wk == 0 waves (every output column of the extra tile holds the same sum)
-    const bool do_cs = p.colsum != nullptr && blockIdx.x == 0 && wk == 0;
+    const bool do_cs = p.colsum != nullptr && kt_ == 0 && wk == 0;
     f32x4 cs[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -357,6 +361,8 @@ inline int grid_1d(int64_t n, int block) {
 }  // namespace
 
 // bf16 fast path (gemm_bf16.hip)
+int svol_gemm_tn_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
+                           int64_t Mc, int64_t N, int64_t K, hipStream_t s);
 int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
                            int act, void* pre, int64_t ldp, const void* res, int64_t ldr, int out_f32, const void* aux,
                            int64_t ldaux, float* colsum, int epi, const float* colscale, int64_t M, int64_t N, int64_t K,
@@ -432,6 +438,11 @@ int svol_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* 
     if (!A || !B || !C || Mc < 0 || N <= 0 || K <= 0) return SVOL_E_INVALID;
     if (Mc == 0) return SVOL_OK;
     if (dtype != SVOL_BF16 && dtype != SVOL_F32) return SVOL_E_INVALID;
+    static const bool no_fast_tn = getenv("SVOL_TN_GENERIC") != nullptr;
+    if (dtype == SVOL_BF16 && !no_fast_tn) {
+        const int rc = svol_gemm_tn_bf16_fast(A, lda, B, ldb, C, ldc, colsum, Mc, N, K, reinterpret_cast<hipStream_t>(stream));
+        if (rc != SVOL_E_UNSUPPORTED) return rc;
+    }
     const int epc = dtype == SVOL_BF16 ? 8 : 4;
     if (N % epc || K % epc || lda % epc || ldb % epc) return SVOL_E_UNSUPPORTED;
     if (!aligned16(A) || !aligned16(B)) return SVOL_E_INVALID;
@@ -447,10 +458,17 @@ int svol_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* 
     int64_t chunk = (Mc + want - 1) / want;
     chunk = ((chunk + ct - 1) / ct) * ct;
     if (chunk < 4 * ct) chunk = 4 * ct;
-    const int64_t splits = (Mc + chunk - 1) / chunk;
-    if (splits > 65535) return SVOL_E_UNSUPPORTED;
-    TnArgs p{A, B, C, colsum, lda, ldb, ldc, (int)Mc, (int)N, (int)K, (int)chunk};
-    dim3 grid((unsigned)((K + 127) / 128), (unsigned)((N + 127) / 128), (unsigned)splits);
+    int64_t splits = (Mc + chunk - 1) / chunk;
+    if (splits > 8 && splits % 8) {  // keep the split count a multiple of the 8 XCDs when the rows allow it
+        const int64_t s8 = (splits + 7) / 8 * 8;
+        int64_t c8 = (Mc + s8 - 1) / s8;
+        c8 = ((c8 + ct - 1) / ct) * ct;
+        if (c8 >= 4 * ct && (Mc + c8 - 1) / c8 == s8) { chunk = c8; splits = s8; }
+    }
+    const int64_t ktiles = (K + 127) / 128;
+    if (splits * tiles > (1ll << 30)) return SVOL_E_UNSUPPORTED;
+    TnArgs p{A, B, C, colsum, lda, ldb, ldc, (int)Mc, (int)N, (int)K, (int)chunk, (int)ktiles, (int)splits};
+    dim3 grid((unsigned)(splits * tiles));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SVOL_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 0, s, p);

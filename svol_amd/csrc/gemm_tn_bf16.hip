@@ -1,0 +1,212 @@
+// bf16 TN GEMM fast path (gfx950): dW[N,K] (fp32) += A[Mc,N]^T * B[Mc,K]  — the weight gradients.
+//
+// The first TN kernel (gemm.hip, kept for f32 and odd shapes) staged one 64-row slab ahead through
+// registers; with 16 MFMAs per wave per 32 rows the slab's compute is ~0.2 us while an HBM load takes
+// ~2 us, so every workgroup idled on its single outstanding slab (rocprofv3: 32 us for the 51 MB of a
+// d x d projection gradient = 1.6 TB/s).  Here the row slabs go HBM -> LDS by LDS-DMA into a 4-slot ring
+// and THREE slabs stay in flight across the (raw) barriers behind a counted s_waitcnt vmcnt:
+//
+//  * slab = 32 rows x 128 columns of A and of B (8 KiB each), 16 one-KiB DMA instructions per slab, 4 per wave;
+//  * the LDS image is row-major as in memory (both operands are contracted along rows, so the MFMA
+//    fragments are transposed reads, ds_read_b64_tr_b16); 256-byte rows cannot be padded under a
+//    lane-linear DMA, so the 32-byte granules of row r are XOR-permuted by (r & 7) on the SOURCE side,
+//    which keeps every half-wave of a transposed read on 8 distinct granules;
+//  * ragged edges: the buffer descriptor ends at the last valid element of the chunk (reads past it
+//    return 0); columns >= N / >= K of a partial tile read finite-or-not garbage that only ever reaches
+//    output elements that are masked at the final atomics;
+//  * split-M over workgroups with fp32 atomics as before; the bias gradient (column sums of A) rides
+//    the matrix pipe (A^T * ones) in the k-tile-0 workgroups.
+#include <cstdlib>
+
+#include "common.h"
+
+namespace {
+
+struct TnFastArgs {
+    const bf16_t* A; const bf16_t* B; float* C; float* colsum;
+    int64_t lda, ldb, ldc;
+    int Mc, N, K, m_chunk, ktiles, splits;
+};
+
+constexpr int CT = 32;            // rows per slab
+constexpr int STG = 4;            // ring slots
+constexpr int OPB = CT * 256;     // bytes per operand slab
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+// physical byte offset of element (row, col) inside a slab image
+__device__ __forceinline__ int phys(int row, int col) {
+    return row * 256 + ((((col >> 4) ^ (row & 7))) << 5) + (col & 15) * 2;
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_dma(TnFastArgs p) {
+    __shared__ __attribute__((aligned(1024))) char smem[STG * 2 * OPB];  // 64 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wk = wave & 1;
+    const int split = blockIdx.x % p.splits, tile = blockIdx.x / p.splits;
+    const int kt_ = tile % p.ktiles, nt_ = tile / p.ktiles;
+    const int n0 = nt_ * 128, k0 = kt_ * 128;
+    const int m_begin = split * p.m_chunk;
+    const int m_end = min(p.Mc, m_begin + p.m_chunk);
+    const int rows = m_end - m_begin;
+    if (rows <= 0) return;
+    const int nst = (rows + CT - 1) / CT;
+
+    const int colsA = min(128, p.N - n0), colsB = min(128, p.K - k0);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.A + (int64_t)m_begin * p.lda + n0), 0, (int)((((int64_t)rows - 1) * p.lda + colsA) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.B + (int64_t)m_begin * p.ldb + k0), 0, (int)((((int64_t)rows - 1) * p.ldb + colsB) * 2), 0x00020000);
+    // DMA geometry: instruction i of an operand covers slab rows 4i..4i+3 (1 KiB); wave w issues i = 2w, 2w+1.
+    // lane -> (row 4i + lane/16, physical 16-byte slot lane%16); the slot holds source chunk ((slot/2) ^ (row&7))*2 + slot%2
+    int voffA[2], voffB[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wave * 2 + j) * 4 + (lane >> 4);
+        const int s = lane & 15;
+        const int c = ((((s >> 1) ^ (r & 7))) << 1) | (s & 1);
+        voffA[j] = (int)(((int64_t)r * p.lda + c * 8) * 2);
+        voffB[j] = (int)(((int64_t)r * p.ldb + c * 8) * 2);
+    }
+    auto issue = [&](int slot, int stage) {
+        char* sa = smem + slot * (2 * OPB);
+        char* sb = sa + OPB;
+        const int soA = (int)((int64_t)stage * CT * p.lda * 2), soB = (int)((int64_t)stage * CT * p.ldb * 2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(sa + (wave * 2 + j) * 1024), 16, voffA[j], soA, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_ptr)(sb + (wave * 2 + j) * 1024), 16, voffB[j], soB, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    const bool do_cs = p.colsum != nullptr && kt_ == 0 && wk == 0;
+    f32x4 cs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
+
+    // fragment addresses: transposed read of rows 4*fq + q (+16), 4 columns at 4*pp of 16-column tile t
+    const int q = fr >> 2, pp = fr & 3;
+    const int row0 = 4 * fq + q;
+    int offA[4], offB[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        offA[t] = phys(row0, wn * 64 + t * 16 + 4 * pp);
+        offB[t] = OPB + phys(row0, wk * 64 + t * 16 + 4 * pp);
+    }
+
+#pragma unroll
+    for (int s = 0; s < STG - 1; ++s)
+        if (s < nst) issue(s, s);
+    for (int t = 0; t < nst; ++t) {
+        // slab t has landed once at most the younger slabs' DMAs (4 instructions each) are outstanding
+        const int younger = min(STG - 2, nst - 1 - t);
+        if (younger >= 2) wait_vm<8>();
+        else if (younger == 1) wait_vm<4>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();  // everyone's part of slab t is visible; everyone is done reading slab t-1
+        if (t + STG - 1 < nst) issue((t + STG - 1) % STG, t + STG - 1);
+        // the fragment reads are inline asm on purpose: hipcc cannot tell which ring slot an LDS-DMA wrote, so any
+        // LDS read it can see gets an s_waitcnt vmcnt(0) in front of it, which would drain the slabs in flight
+        const unsigned sl = (unsigned)(size_t)(lds_void_ptr)smem + (unsigned)((t % STG) * (2 * OPB));
+        bf16x4 a0[4], a1[4], b0[4], b1[4];
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %16\n\t"
+            "ds_read_b64_tr_b16 %1, %16 offset:4096\n\t"
+            "ds_read_b64_tr_b16 %2, %17\n\t"
+            "ds_read_b64_tr_b16 %3, %17 offset:4096\n\t"
+            "ds_read_b64_tr_b16 %4, %18\n\t"
+            "ds_read_b64_tr_b16 %5, %18 offset:4096\n\t"
+            "ds_read_b64_tr_b16 %6, %19\n\t"
+            "ds_read_b64_tr_b16 %7, %19 offset:4096\n\t"
+            "ds_read_b64_tr_b16 %8, %20\n\t"
+            "ds_read_b64_tr_b16 %9, %20 offset:4096\n\t"
+            "ds_read_b64_tr_b16 %10, %21\n\t"
+            "ds_read_b64_tr_b16 %11, %21 offset:4096\n\t"
+            "ds_read_b64_tr_b16 %12, %22\n\t"
+            "ds_read_b64_tr_b16 %13, %22 offset:4096\n\t"
+            "ds_read_b64_tr_b16 %14, %23\n\t"
+            "ds_read_b64_tr_b16 %15, %23 offset:4096\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(a0[0]), "=&v"(a1[0]), "=&v"(a0[1]), "=&v"(a1[1]), "=&v"(a0[2]), "=&v"(a1[2]), "=&v"(a0[3]), "=&v"(a1[3]),
+              "=&v"(b0[0]), "=&v"(b1[0]), "=&v"(b0[1]), "=&v"(b1[1]), "=&v"(b0[2]), "=&v"(b1[2]), "=&v"(b0[3]), "=&v"(b1[3])
+            : "v"(sl + offA[0]), "v"(sl + offA[1]), "v"(sl + offA[2]), "v"(sl + offA[3]), "v"(sl + offB[0]),
+              "v"(sl + offB[1]), "v"(sl + offB[2]), "v"(sl + offB[3])
+            : "memory");
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i] = __builtin_shufflevector(a0[i], a1[i], 0, 1, 2, 3, 4, 5, 6, 7);
+            bfr[i] = __builtin_shufflevector(b0[i], b1[i], 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+                acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
+        if (do_cs) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) cs[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], ones, cs[nt], 0, 0, 0);
+        }
+    }
+    // C[n][k] += acc: row (output n) = nt*16 + fq*4 + r, col (output k) = kt*16 + fr
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int k = k0 + wk * 64 + kt * 16 + fr;
+            if (k >= p.K) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + nt * 16 + fq * 4 + r;
+                if (n < p.N) atomicAdd(p.C + (int64_t)n * p.ldc + k, acc[nt][kt][r]);
+            }
+        }
+    if (do_cs && fr == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + nt * 16 + fq * 4 + r;
+                if (n < p.N) atomicAdd(p.colsum + n, cs[nt][r]);
+            }
+    }
+}
+
+}  // namespace
+
+// launcher used by gemm.hip's svol_gemm_tn.  Returns SVOL_E_UNSUPPORTED when the shape does not qualify.
+int svol_gemm_tn_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
+                           int64_t Mc, int64_t N, int64_t K, hipStream_t s) {
+    if (N % 8 || K % 8 || lda % 8 || ldb % 8 || !aligned16(A) || !aligned16(B)) return SVOL_E_UNSUPPORTED;
+    if (Mc < 1 || Mc > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return SVOL_E_UNSUPPORTED;
+    const int64_t tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    // split the contraction: few, long-running workgroups for small outputs (the final fp32 atomics dominate
+    // there), ~2 per CU otherwise; a multiple of the 8 XCDs so that the tiles of one row chunk share an L2
+    static const int force_wgs = getenv("SVOL_TN_WGS") ? atoi(getenv("SVOL_TN_WGS")) : 0;
+    const int target_wgs = force_wgs ? force_wgs : (tiles <= 8 ? 256 : 512);
+    int64_t want = (target_wgs + tiles - 1) / tiles;
+    if (want > 8) want = want / 8 * 8;
+    int64_t chunk = (Mc + want - 1) / want;
+    chunk = ((chunk + CT - 1) / CT) * CT;
+    if (chunk < 4 * CT) chunk = 4 * CT;
+    const int64_t splits = (Mc + chunk - 1) / chunk;
+    if (splits * tiles > (1ll << 30)) return SVOL_E_UNSUPPORTED;
+    const int64_t ldmax = lda > ldb ? lda : ldb;
+    if (chunk * ldmax * 2 >= (1ll << 31)) return SVOL_E_UNSUPPORTED;  // 32-bit buffer offsets
+    TnFastArgs p{(const bf16_t*)A, (const bf16_t*)B, C, colsum, lda, ldb, ldc, (int)Mc, (int)N, (int)K, (int)chunk,
+                 (int)((K + 127) / 128), (int)splits};
+    hipLaunchKernelGGL(gemm_tn_bf16_dma, dim3((unsigned)(splits * tiles)), dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
+}
