@@ -496,6 +496,7 @@ __device__ __forceinline__ f32x16 mma_first_c(const uint4 (&a)[2], const uint4 (
 // accumulator initialised from a per-ROW vector in LDS (row constants of the reg-side tile)
 __device__ __forceinline__ f32x16 rows16(const float* v, int sub, int h) {
     f32x16 z;
+
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const f32x4 t = *reinterpret_cast<const f32x4*>(v + sub * 32 + 8 * g + 4 * h);
@@ -663,12 +664,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_pre(Args p) {
     store_acc(dQ, dQo, p.lddq, qrow, qvalid, p.dh, h, p.scale);
 }
 
+// x as two bf16 (hi = rn(x), lo = rn(x - hi)) packed in one dword: |x - hi - lo| <= 2^-17 |x|
+__device__ __forceinline__ unsigned split_bf16x2(float x) {
+    const bf16_t hi = (bf16_t)x;
+    const float rem = x - (float)hi;
+    const bf16_t lo = (bf16_t)rem;
+    return (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+}
+
+// In this kernel the per-QUERY constants (-lse, -delta) run along the 16 accumulator registers of a lane (rows of
+// the score tile are queries), so as initial accumulators they cost four ds_read_b128 per product — half of the
+// loop's LDS traffic, and LDS was the busiest unit (rocprofv3 PMC: ~70 % of its bandwidth).  They ride the matrix
+// pipe instead: one more 16-deep MFMA per product contracts [hi, lo, 0...] (per query, one dword from LDS)
+// with [1, 1, 0...] (constant), i.e. adds -lse / -delta to every score of that query in fp32.
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_pre(Args p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * IMG + 4 * KT * 4];
     char* sQ = smem;
     char* sdO = smem + 2 * IMG;
-    float* sL = reinterpret_cast<float*>(smem + 4 * IMG);  // [2][KT] -lse2
-    float* sD = sL + 2 * KT;                               // [2][KT] -delta
+    unsigned* sL = reinterpret_cast<unsigned*>(smem + 4 * IMG);  // [2][KT] -lse2 as (hi, lo) bf16
+    unsigned* sD = sL + 2 * KT;                                  // [2][KT] -delta as (hi, lo) bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, hh = blockIdx.y;
@@ -691,13 +705,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_pre(Args p) {
     auto load_stats = [&](int row0) {
         if (tid < KT) {
             const int qi = row0 + tid;
-            rl = qi < p.Lq ? -lse_g[qi] : -INFINITY;
+            rl = qi < p.Lq ? -lse_g[qi] : -3.0e38f;  // finite (it meets a 0 in the MFMA), still exp2 -> 0
             rd = qi < p.Lq ? -dl_g[qi] : 0.f;
         }
     };
     auto store_stats = [&](int buf) {
-        if (tid < KT) { sL[buf * KT + tid] = rl; sD[buf * KT + tid] = rd; }
+        if (tid < KT) { sL[buf * KT + tid] = split_bf16x2(rl); sD[buf * KT + tid] = split_bf16x2(rd); }
     };
+    const uint4 ones = h == 0 ? make_uint4(0x3F803F80u, 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);  // [1, 1, 0...]
     load_regs(sq, Q, p.ldq, 0, p.Lq, p.dh, tid);
     load_regs(sdo, dO, p.lddo, 0, p.Lq, p.dh, tid);
     load_stats(0);
@@ -714,19 +729,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_pre(Args p) {
         }
         const char* qimg = sQ + cur * IMG;
         const char* doimg = sdO + cur * IMG;
-        const float* nl = sL + cur * KT;
-        const float* nd = sD + cur * KT;
+        const unsigned* nl = sL + cur * KT;
+        const unsigned* nd = sD + cur * KT;
 #pragma unroll 1
         for (int sub = 0; sub < 4; ++sub) {
             uint4 a[2];
+            // every lane loads its query's pair; for the h = 1 lanes (k = 8..15) `ones` is zero and the pair is finite
+            const uint4 el = make_uint4(nl[sub * 32 + r], 0u, 0u, 0u);
+            const uint4 ed = make_uint4(nd[sub * 32 + r], 0u, 0u, 0u);
             read_rows(a, qimg, sub * 32 + r, h);
-            f32x16 S = mma_first_c(a, kbk, rows16(nl, sub, h));  // score - lse[q]
+            f32x16 S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, el), __builtin_bit_cast(bf16x8, ones),
+                                                               zero16(), 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, kbk[0]), S, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, kbk[1]), S, 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) S[i] = __builtin_amdgcn_exp2f(S[i]);
+            for (int i = 0; i < 16; ++i) S[i] = __builtin_amdgcn_exp2f(S[i]);  // score - lse[q]
             read_tr(a, doimg, sub, lane);
             mma_second(dV, a, S);
             read_rows(a, doimg, sub * 32 + r, h);
-            const f32x16 dP = mma_first_c(a, vbk, rows16(nd, sub, h));  // dO V^T - delta[q]
+            f32x16 dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ed), __builtin_bit_cast(bf16x8, ones),
+                                                                zero16(), 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, vbk[0]), dP, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, vbk[1]), dP, 0, 0, 0);  // dO V^T - delta[q]
 #pragma unroll
             for (int i = 0; i < 16; ++i) S[i] *= dP[i];
             read_tr(a, qimg, sub, lane);
