@@ -238,6 +238,136 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_b16_k64(FastArgs p) { gem
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_f32_k32(FastArgs p) { gemm_nt_bf16_body<float, 32>(p); }
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_b16_k32(FastArgs p) { gemm_nt_bf16_body<bf16_t, 32>(p); }
 
+// ---------------------------------------------------------------------------------------------------
+// Skinny-M variant (the query stream: M = B * num_queries = 800 rows at the benchmark size).  A 128x128
+// tiling leaves 14 workgroups on 256 CUs, each walking the whole K loop on its own (54 us for K = 2048).
+// Here one workgroup owns a 32 x 64 output tile and its four waves split K between them (intra-workgroup
+// split-K: each wave streams its K/4 slice of A and W straight from global memory into MFMA operands, 64
+// elements = 128 contiguous bytes per row and batch, no LDS staging, next batch in flight under the current
+// one), the partial tiles meet in LDS and all 256 threads run the usual epilogue on 8 consecutive columns each.
+constexpr int SK_BM = 32, SK_BN = 64, SK_LD = SK_BN + 4;
+
+template <typename TC>
+__device__ __forceinline__ void gemm_nt_bf16_skinny_body(const FastArgs& p) {
+    __shared__ __attribute__((aligned(16))) float red[4][SK_BM][SK_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int bm = blockIdx.y * SK_BM, bn = blockIdx.x * SK_BN;
+    const int kslice = p.K >> 2;
+    const int nb = kslice >> 6;  // batches of 64
+    const bool va = bm + r < p.M, vb0 = bn + r < p.N, vb1 = bn + 32 + r < p.N;
+    // the contraction index may be permuted freely as long as both operands agree: lane (r, h) takes the 32
+    // consecutive elements [h*32, h*32+32) of each 64-element batch, 8 per MFMA
+    const bf16_t* pa = p.A + (int64_t)(bm + r) * p.lda + wave * kslice + h * 32;
+    const bf16_t* pb0 = p.B + (int64_t)(bn + r) * p.ldb + wave * kslice + h * 32;
+    const bf16_t* pb1 = pb0 + (int64_t)32 * p.ldb;
+    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+    uint4 a[4], b0[4], b1[4], na[4], nb0[4], nb1[4];
+    auto load = [&](uint4 (&xa)[4], uint4 (&xb0)[4], uint4 (&xb1)[4], int bt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xa[i] = va ? *reinterpret_cast<const uint4*>(pa + bt * 64 + i * 8) : z4;
+            xb0[i] = vb0 ? *reinterpret_cast<const uint4*>(pb0 + bt * 64 + i * 8) : z4;
+            xb1[i] = vb1 ? *reinterpret_cast<const uint4*>(pb1 + bt * 64 + i * 8) : z4;
+        }
+    };
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    load(a, b0, b1, 0);
+    for (int bt = 0; bt < nb; ++bt) {
+        if (bt + 1 < nb) load(na, nb0, nb1, bt + 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b0[i]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b1[i]), acc1, 0, 0, 0);
+        }
+        if (bt + 1 < nb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = na[i]; b0[i] = nb0[i]; b1[i] = nb1[i]; }
+        }
+    }
+    // D[m][n]: register 4g+e of lane (n = r, h) is row m = 8g + 4h + e
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[wave][8 * g + 4 * h + e][r] = acc0[4 * g + e];
+            red[wave][8 * g + 4 * h + e][32 + r] = acc1[4 * g + e];
+        }
+    __syncthreads();
+    const int row = tid >> 3, c0 = (tid & 7) * 8;
+    const int m = bm + row, n0 = bn + c0;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(&red[0][row][c0 + 4 * q]);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(&red[w][row][c0 + 4 * q]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] += u[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e];
+    }
+    const bool mv = m < p.M;  // N % 64 == 0 (launcher), so every column of the tile exists
+    TC* C = reinterpret_cast<TC*>(p.C);
+    if (p.epi == 0) {
+        if (mv) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (p.bias) v[e] += p.bias[n0 + e];
+                if (p.colscale) v[e] *= p.colscale[n0 + e];
+            }
+            if (p.pre) {
+                Out4<bf16_t>::store(p.pre + (int64_t)m * p.ldp + n0, f32x4{v[0], v[1], v[2], v[3]});
+                Out4<bf16_t>::store(p.pre + (int64_t)m * p.ldp + n0 + 4, f32x4{v[4], v[5], v[6], v[7]});
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (p.act == SVOL_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                else if (p.act == SVOL_ACT_GELU) v[e] = gelu_fast(v[e]);
+                else if (p.act == SVOL_ACT_SIGMOID) v[e] = 1.f / (1.f + __expf(-v[e]));
+            }
+            if (p.res) {
+                const TC* R = reinterpret_cast<const TC*>(p.res) + (int64_t)m * p.ldr + n0;
+                const f32x4 r0 = Out4<TC>::load(R), r1 = Out4<TC>::load(R + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+            }
+        }
+    } else {  // epi 1: v = acc * gelu'(aux), column sums of v
+        if (mv) {
+            const bf16_t* X = p.aux + (int64_t)m * p.ldaux + n0;
+            const f32x4 x0 = Out4<bf16_t>::load(X), x1 = Out4<bf16_t>::load(X + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] *= dgelu_fast(x0[e]); v[4 + e] *= dgelu_fast(x1[e]); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+        if (p.colsum) {
+            __syncthreads();  // everyone has read the partial tiles
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[0][row][c0 + e] = v[e];
+            __syncthreads();
+            if (tid < SK_BN) {
+                float sacc = 0.f;
+#pragma unroll 8
+                for (int i = 0; i < SK_BM; ++i) sacc += red[0][i][tid];
+                atomicAdd(p.colsum + bn + tid, sacc);
+            }
+        }
+    }
+    if (mv) {
+        Out4<TC>::store(C + (int64_t)m * p.ldc + n0, f32x4{v[0], v[1], v[2], v[3]});
+        Out4<TC>::store(C + (int64_t)m * p.ldc + n0 + 4, f32x4{v[4], v[5], v[6], v[7]});
+    }
+}
+__global__ __launch_bounds__(256) void gemm_nt_bf16_skinny_f32(FastArgs p) { gemm_nt_bf16_skinny_body<float>(p); }
+__global__ __launch_bounds__(256) void gemm_nt_bf16_skinny_b16(FastArgs p) { gemm_nt_bf16_skinny_body<bf16_t>(p); }
+
 }  // namespace
 
 // launcher used by gemm.hip's C-ABI entry points.  Returns SVOL_E_UNSUPPORTED when the shape does not
@@ -256,6 +386,13 @@ int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ld
     if (aux && (ldaux % 4 || (reinterpret_cast<uintptr_t>(aux) % 8))) return SVOL_E_UNSUPPORTED;
     FastArgs p{(const bf16_t*)A, (const bf16_t*)B, C, bias, colscale, (bf16_t*)pre, res, (const bf16_t*)aux, colsum,
                lda, ldb, ldc, ldp, ldr, ldaux, (int)M, (int)N, (int)K, act, epi};
+    static const int skinny_max = getenv("SVOL_GEMM_SKINNY_M") ? atoi(getenv("SVOL_GEMM_SKINNY_M")) : 2048;
+    if (M <= skinny_max && K % 256 == 0 && N % SK_BN == 0) {
+        dim3 g((unsigned)(N / SK_BN), (unsigned)((M + SK_BM - 1) / SK_BM));
+        if (out_f32) hipLaunchKernelGGL(gemm_nt_bf16_skinny_f32, g, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(gemm_nt_bf16_skinny_b16, g, dim3(256), 0, s, p);
+        return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
+    }
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
     if (grid.y > 65535u) return SVOL_E_UNSUPPORTED;
     // K-step 32 keeps the two-stage ring at 32 KiB per workgroup (4-5 workgroups per CU hide the DMA latency of the

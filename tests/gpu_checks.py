@@ -80,13 +80,31 @@ def check_gemm_nt():
         ref = A.double() @ Bm.double().t() + bias.double() + R.double()
         res[f'gemm_nt/{dt}/out_f32'] = (rel_err(out, ref), 2e-5 if dt == torch.float32 else 1e-5)
         res[f'gemm_nt/{dt}/out_f32_dtype'] = (0.0 if out.dtype == torch.float32 else 1.0, 0.5)
+        # skinny-M path (bf16: intra-workgroup split-K kernel): every epilogue, ragged M, deep K, fp32 stream, colscale
+        for (M, N, K) in [(333, 128, 256), (800, 256, 2048), (31, 64, 512)]:
+            A = _rnd((M, K), dt, 11)
+            Bm = _rnd((N, K), dt, 12, 1.0 / math.sqrt(K))
+            bias = _rnd((N,), torch.float32, 13)
+            for act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_GELU, ops.ACT_SIGMOID):
+                R = _rnd((M, N), dt, 14)
+                out = ops.gemm_nt(A.to(DEV), Bm.to(DEV), bias.to(DEV), act, residual=R.to(DEV), want_pre=(act == ops.ACT_GELU))
+                pre_ref = A.double() @ Bm.double().t() + bias.double()
+                if act == ops.ACT_GELU:
+                    out, pre = out
+                    res[f'gemm_nt/{dt}/skinny{M}x{N}x{K}/pre'] = (rel_err(pre, pre_ref), TOL[dt])
+                res[f'gemm_nt/{dt}/skinny{M}x{N}x{K}/act{act}'] = (rel_err(out, _act(pre_ref, act) + R.double()), TOL[dt])
+            R32 = _rnd((M, N), torch.float32, 15)
+            cs = (torch.arange(N) % 3 + 1).float()
+            out = ops.gemm_nt(A.to(DEV), Bm.to(DEV), bias.to(DEV), residual=R32.to(DEV), out_f32=True, colscale=cs.to(DEV))
+            ref = (A.double() @ Bm.double().t() + bias.double()) * cs.double() + R32.double()
+            res[f'gemm_nt/{dt}/skinny{M}x{N}x{K}/out_f32_colscale'] = (rel_err(out, ref), 2e-5 if dt == torch.float32 else 1e-5)
     return res
 
 
 def check_gemm_dgelu():
     res = {}
     for dt in DTYPES:
-        for (M, N, K) in [(300, 256, 64), (1000, 2048, 256), (130, 64, 128), (77, 96, 32)]:
+        for (M, N, K) in [(300, 256, 64), (1000, 2048, 256), (130, 64, 128), (77, 96, 32), (801, 192, 256)]:
             A, W = _rnd((M, K), dt, 50), _rnd((N, K), dt, 51, 1.0 / math.sqrt(K))
             pre = _rnd((M, N), dt, 52)
             out, cs = ops.gemm_nt_dgelu(A.to(DEV), W.to(DEV), pre.to(DEV))
