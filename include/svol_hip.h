@@ -116,15 +116,21 @@ int svol_posenc_sine(const float* mask, void* pos, int64_t B, int64_t L, int64_t
  * q_premul != 0: the caller already multiplied q by q_premul = scale*log2(e) (fused into the projection
  * GEMM epilogue); the kernels then exponentiate the raw MFMA results and dq is still the gradient with
  * respect to the UNscaled q.  Pass 0 for plain q.
+ * ws / ws_bytes: optional 16-byte aligned scratch (may be NULL / 0).  Launches with few queries and many keys
+ * (the N = 100 object queries attending to L = 6272 video tokens: 64 workgroups on 256 CUs) are split over the
+ * keys when the scratch is large enough — svol_attn_ws_bytes() says how much that takes; partial results are
+ * merged by a small second kernel.  Nothing is allocated inside the library.
  * Replaces the core of nn.MultiheadAttention (cross_modal_transformer.py:139,147,154). */
+int64_t svol_attn_ws_bytes(int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t dh);
 int svol_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                   int64_t ldo, float* lse2, const float* kbias, int64_t B, int64_t H, int64_t Lq, int64_t Lk,
-                  int64_t dh, float scale, float q_premul, int dtype, void* stream);
+                  int64_t dh, float scale, float q_premul, void* ws, int64_t ws_bytes, int dtype, void* stream);
 /* delta[B,H,Lq] = rowsum(dO * O) ; then dq / dk / dv (same layouts as q/k/v). */
 int svol_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
                   int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta, const float* kbias,
                   void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int64_t B, int64_t H,
-                  int64_t Lq, int64_t Lk, int64_t dh, float scale, float q_premul, int dtype, void* stream);
+                  int64_t Lq, int64_t Lk, int64_t dh, float scale, float q_premul, void* ws, int64_t ws_bytes,
+                  int dtype, void* stream);
 
 /* ---- sketch->video gate (cross_modal_transformer.py:122-127) ------------
  * Only the head-averaged attention weights of the 1-query MHA are used by the reference, so the

@@ -32,10 +32,11 @@ SIGNATURES = {
     'svol_layernorm_fwd': [_p, _int, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _f32, _u64, _p, _int, _p],
     'svol_layernorm_bwd': [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f32, _u64, _p, _int, _p],
     'svol_posenc_sine': [_p, _p, _i64, _i64, _i64, _int, _p],
-    'svol_attn_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _int,
-                      _p],
+    'svol_attn_ws_bytes': [_i64, _i64, _i64, _i64, _i64],
+    'svol_attn_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _p, _i64,
+                      _int, _p],
     'svol_attn_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64,
-                      _i64, _i64, _i64, _i64, _i64, _f32, _f32, _int, _p],
+                      _i64, _i64, _i64, _i64, _i64, _f32, _f32, _p, _i64, _int, _p],
     'svol_gate_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p],
     'svol_gate_bwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _int,
                       _p],
@@ -68,6 +69,7 @@ def lib():
             f = getattr(L, name)  # AttributeError if the symbol is not exported
             f.restype = _int
             f.argtypes = at
+        L.svol_attn_ws_bytes.restype = _i64
         _LIB = L
     return _LIB
 

@@ -444,17 +444,25 @@ bool ld_ok(int64_t ld, int dtype) { return ld % (dtype == SVOL_BF16 ? 8 : 4) == 
 // bf16 fast path (attention_bf16.hip)
 int svol_attn_fwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                               int64_t ldo, float* lse2, const float* kbias, int B, int H, int Lq, int Lk, int dh, float scale,
-                              float premul, hipStream_t s);
+                              float premul, float* ws, int64_t ws_bytes, hipStream_t s);
 int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                               const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta,
                               const float* kbias, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int B,
-                              int H, int Lq, int Lk, int dh, float scale, float premul, hipStream_t s);
+                              int H, int Lq, int Lk, int dh, float scale, float premul, float* ws, int64_t ws_bytes,
+                              hipStream_t s);
+
+int64_t svol_attn_ws_floats_bf16(int B, int H, int Lq, int Lk, int dh);
 
 extern "C" {
 
+int64_t svol_attn_ws_bytes(int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t dh) {
+    if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || dh <= 0 || B > (1 << 24) || Lq > (1 << 24) || Lk > (1 << 24)) return 0;
+    return 4 * svol_attn_ws_floats_bf16((int)B, (int)H, (int)Lq, (int)Lk, (int)dh);
+}
+
 int svol_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                   int64_t ldo, float* lse2, const float* kbias, int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t dh,
-                  float scale, float q_premul, int dtype, void* stream) {
+                  float scale, float q_premul, void* ws, int64_t ws_bytes, int dtype, void* stream) {
     if (!q || !k || !v || !o || !lse2) return SVOL_E_INVALID;
     int rc = check_common(B, H, Lq, Lk, dh, dtype);
     if (rc) return rc;
@@ -468,7 +476,7 @@ int svol_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SVOL_BF16)
         return svol_attn_fwd_bf16_launch(q, ldq, k, ldk, v, ldv, o, ldo, lse2, kbias, (int)B, (int)H, (int)Lq, (int)Lk, (int)dh,
-                                         scale, q_premul, s);
+                                         scale, q_premul, aligned16(ws) ? (float*)ws : nullptr, ws_bytes, s);
     hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), 0, s, p);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
@@ -477,7 +485,7 @@ int svol_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const 
 int svol_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
                   int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta, const float* kbias, void* dq,
                   int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int64_t B, int64_t H, int64_t Lq, int64_t Lk,
-                  int64_t dh, float scale, float q_premul, int dtype, void* stream) {
+                  int64_t dh, float scale, float q_premul, void* ws, int64_t ws_bytes, int dtype, void* stream) {
     if (!q || !k || !v || !o || !d_o || !lse2 || !delta || !dq || !dk || !dv) return SVOL_E_INVALID;
     int rc = check_common(B, H, Lq, Lk, dh, dtype);
     if (rc) return rc;
@@ -499,7 +507,8 @@ int svol_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const 
     dim3 gk((unsigned)((Lk + 127) / 128), (unsigned)H, (unsigned)B);
     if (dtype == SVOL_BF16)
         return svol_attn_bwd_bf16_launch(q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse2, delta, kbias, dq, lddq, dk, lddk, dv,
-                                         lddv, (int)B, (int)H, (int)Lq, (int)Lk, (int)dh, scale, q_premul, s);
+                                         lddv, (int)B, (int)H, (int)Lq, (int)Lk, (int)dh, scale, q_premul,
+                                         aligned16(ws) ? (float*)ws : nullptr, ws_bytes, s);
     hipLaunchKernelGGL(attn_delta_kernel<float>, gd, dim3(256), 0, s, p);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, gq, dim3(256), 0, s, p);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<float>, gk, dim3(256), 0, s, p);

@@ -15,6 +15,8 @@
 //    formed against the stale maximum and bf16's relative precision is scale free), exp2 arguments come
 //    from one FMA (score * scale*log2e - m), no separate scale or subtract pass;
 //  * backward: the 1/sqrt(d_h) factor of dS is applied once to the dQ / dK accumulators at the end.
+#include <cstdint>
+
 #include "common.h"
 
 namespace {
@@ -33,6 +35,10 @@ struct Args {
     int B, H, Lq, Lk, dh;
     float scale;
     float premul;  // != 0: q was pre-multiplied by premul = scale*log2(e) (fused into the projection GEMM epilogue)
+    // key-split of the few-query (cross attention) launches: ksplit workgroups share one query tile, each takes
+    // tiles_per_split key tiles; partial results meet in the fp32 workspace
+    int ksplit, tiles_per_split;
+    float *ws_o, *ws_ml, *ws_dq;  // [ksplit][B*Lq][H*dh] unnormalised O | [ksplit][B][H][Lq][2] (m2, l) | [B*Lq][H*dh] dQ
 };
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
@@ -155,7 +161,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(Args p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, hh = blockIdx.y;
-    const int qrow = blockIdx.x * 128 + wave * 32 + r;
+    const int qt = blockIdx.x / p.ksplit, sp = blockIdx.x % p.ksplit;
+    const int qrow = qt * 128 + wave * 32 + r;
     const bool qvalid = qrow < p.Lq;
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
@@ -170,17 +177,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(Args p) {
     float m = -INFINITY, l = 0.f;
     f32x16 O = zero16();
 
-    const int nt = (p.Lk + KT - 1) / KT;
+    const int t0 = sp * p.tiles_per_split;
+    const int nt = min((p.Lk + KT - 1) / KT, t0 + p.tiles_per_split);  // this workgroup's key tiles: [t0, nt)
     Stage sk, sv;
-    load_regs(sk, K, p.ldk, 0, p.Lk, p.dh, tid);
-    load_regs(sv, V, p.ldv, 0, p.Lk, p.dh, tid);
+    load_regs(sk, K, p.ldk, t0 * KT, p.Lk, p.dh, tid);
+    load_regs(sv, V, p.ldv, t0 * KT, p.Lk, p.dh, tid);
     store_lds(sK, sk, tid);
     store_lds(sV, sv, tid);
-    if (MASKED) stage_bias(sB, kb, 0, p.Lk, tid);
+    if (MASKED) stage_bias(sB, kb, t0 * KT, p.Lk, tid);
     __syncthreads();
 
-    for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
+    for (int t = t0; t < nt; ++t) {
+        const int cur = (t - t0) & 1;
         if (t + 1 < nt) {
             load_regs(sk, K, p.ldk, (t + 1) * KT, p.Lk, p.dh, tid);
             load_regs(sv, V, p.ldv, (t + 1) * KT, p.Lk, p.dh, tid);
@@ -256,13 +264,69 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(Args p) {
         __syncthreads();
     }
     const float lt = l + __shfl_xor(l, 32, 64);
+    const float m2 = MASKED ? m : m * c;  // scaled log2 domain
+    if (p.ksplit > 1) {  // partial: unnormalised O and (m2, l) to the workspace, attn_combine_bf16 finishes
+        if (qvalid) {
+            float* wo = p.ws_o + (((int64_t)sp * p.B + b) * p.Lq + qrow) * (p.H * p.dh) + hh * p.dh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 8 * g + 4 * h;
+                if (d0 < p.dh) *reinterpret_cast<f32x4*>(wo + d0) = f32x4{O[4 * g], O[4 * g + 1], O[4 * g + 2], O[4 * g + 3]};
+            }
+            if (h == 0) {
+                float* wm = p.ws_ml + ((((int64_t)sp * p.B + b) * p.H + hh) * p.Lq + qrow) * 2;
+                wm[0] = m2;
+                wm[1] = lt;
+            }
+        }
+        return;
+    }
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
     bf16_t* Oo = reinterpret_cast<bf16_t*>(p.out_o) + (int64_t)b * p.Lq * p.ldo + hh * p.dh;
     store_acc(O, Oo, p.ldo, qrow, qvalid, p.dh, h, inv);
-    if (qvalid && h == 0) {
-        const float m2 = MASKED ? m : m * c;  // scaled log2 domain
-        p.lse2[((int64_t)b * p.H + hh) * p.Lq + qrow] = m2 + __builtin_amdgcn_logf(lt);
+    if (qvalid && h == 0) p.lse2[((int64_t)b * p.H + hh) * p.Lq + qrow] = m2 + __builtin_amdgcn_logf(lt);
+}
+
+// merge of the key-split partials: O = sum_i 2^(m_i - M) O_i / sum_i 2^(m_i - M) l_i.  One thread per (row, head).
+__global__ void attn_combine_bf16(Args p) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)p.B * p.Lq * p.H;
+    if (idx >= total) return;
+    const int hh = (int)(idx % p.H);
+    const int64_t row = idx / p.H;
+    const int b = (int)(row / p.Lq), q = (int)(row % p.Lq);
+    float M = -INFINITY;
+    for (int i = 0; i < p.ksplit; ++i) M = fmaxf(M, p.ws_ml[((((int64_t)i * p.B + b) * p.H + hh) * p.Lq + q) * 2]);
+    float L = 0.f, acc[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) acc[d] = 0.f;
+    for (int i = 0; i < p.ksplit; ++i) {
+        const float* ml = p.ws_ml + ((((int64_t)i * p.B + b) * p.H + hh) * p.Lq + q) * 2;
+        if (ml[0] == -INFINITY) continue;  // a split that saw only masked keys (or none)
+        const float w = __builtin_amdgcn_exp2f(ml[0] - M);
+        L += w * ml[1];
+        const float* po = p.ws_o + (((int64_t)i * p.B + b) * p.Lq + q) * (p.H * p.dh) + hh * p.dh;
+#pragma unroll
+        for (int d = 0; d < 32; d += 4) {
+            if (d < p.dh) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(po + d);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[d + e] += w * t[e];
+            }
+        }
     }
+    const float inv = L > 0.f ? 1.f / L : 0.f;
+    bf16_t* o = reinterpret_cast<bf16_t*>(p.out_o) + row * p.ldo + hh * p.dh;
+#pragma unroll
+    for (int d = 0; d < 32; d += 4) {
+        if (d < p.dh) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(acc[d + e] * inv);
+            *reinterpret_cast<bf16x4*>(o + d) = v;
+        }
+    }
+    p.lse2[((int64_t)b * p.H + hh) * p.Lq + q] = M + __builtin_amdgcn_logf(L);
 }
 
 __global__ void attn_delta_bf16(Args p) {
@@ -281,6 +345,28 @@ __global__ void attn_delta_bf16(Args p) {
         for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)c[e];
     }
     p.delta[((int64_t)b * p.H + hh) * p.Lq + q] = s;
+    if (p.ksplit > 1) {  // the key-split dQ pass accumulates with atomics: zero its fp32 target here
+        float* z = p.ws_dq + row * (p.H * p.dh) + hh * p.dh;
+        for (int i = 0; i < p.dh; i += 4) *reinterpret_cast<f32x4*>(z + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// dq (bf16) = scale * ws_dq after the key-split dQ pass.  One thread per (row, head).
+__global__ void attn_dq_finish_bf16(Args p) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)p.B * p.Lq * p.H;
+    if (idx >= total) return;
+    const int hh = (int)(idx % p.H);
+    const int64_t row = idx / p.H;
+    const float* z = p.ws_dq + row * (p.H * p.dh) + hh * p.dh;
+    bf16_t* o = reinterpret_cast<bf16_t*>(p.dq) + row * p.lddq + hh * p.dh;
+    for (int i = 0; i < p.dh; i += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(z + i);
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(t[e] * p.scale);
+        *reinterpret_cast<bf16x4*>(o + i) = v;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -295,7 +381,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(Args p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, hh = blockIdx.y;
-    const int qrow = blockIdx.x * 128 + wave * 32 + r;
+    const int qt = blockIdx.x / p.ksplit, sp = blockIdx.x % p.ksplit;
+    const int qrow = qt * 128 + wave * 32 + r;
     const bool qvalid = qrow < p.Lq;
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
     const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
@@ -312,17 +399,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(Args p) {
     const float dl = qvalid ? p.delta[sidx] : 0.f;
 
     f32x16 dQ = zero16();
-    const int nt = (p.Lk + KT - 1) / KT;
+    const int t0 = sp * p.tiles_per_split;
+    const int nt = min((p.Lk + KT - 1) / KT, t0 + p.tiles_per_split);  // this workgroup's key tiles: [t0, nt)
     Stage sk, sv;
-    load_regs(sk, K, p.ldk, 0, p.Lk, p.dh, tid);
-    load_regs(sv, V, p.ldv, 0, p.Lk, p.dh, tid);
+    load_regs(sk, K, p.ldk, t0 * KT, p.Lk, p.dh, tid);
+    load_regs(sv, V, p.ldv, t0 * KT, p.Lk, p.dh, tid);
     store_lds(sK, sk, tid);
     store_lds(sV, sv, tid);
-    if (MASKED) stage_bias(sB, kb, 0, p.Lk, tid);
+    if (MASKED) stage_bias(sB, kb, t0 * KT, p.Lk, tid);
     __syncthreads();
 
-    for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
+    for (int t = t0; t < nt; ++t) {
+        const int cur = (t - t0) & 1;
         if (t + 1 < nt) {
             load_regs(sk, K, p.ldk, (t + 1) * KT, p.Lk, p.dh, tid);
             load_regs(sv, V, p.ldv, (t + 1) * KT, p.Lk, p.dh, tid);
@@ -363,6 +451,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(Args p) {
             if (MASKED) stage_bias(sB + (cur ^ 1) * KT, kb, (t + 1) * KT, p.Lk, tid);
         }
         __syncthreads();
+    }
+    if (p.ksplit > 1) {  // partial over this key range: fp32 atomics, attn_dq_finish_bf16 scales and rounds
+        if (qvalid) {
+            float* z = p.ws_dq + ((int64_t)b * p.Lq + qrow) * (p.H * p.dh) + hh * p.dh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 8 * g + 4 * h;
+                if (d0 < p.dh) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(z + d0 + e, dQ[4 * g + e]);
+                }
+            }
+        }
+        return;
     }
     bf16_t* dQo = reinterpret_cast<bf16_t*>(p.dq) + (int64_t)b * p.Lq * p.lddq + hh * p.dh;
     store_acc(dQ, dQo, p.lddq, qrow, qvalid, p.dh, h, p.scale);
@@ -772,44 +874,88 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_pre(Args p) {
 }  // namespace
 
 // entry points used by attention.hip's C-ABI functions
+// key-split decision shared by forward and backward: only launches whose (query tiles x heads x batch) grid leaves most
+// CUs idle and whose key loop is long; the workspace must hold the partials.  Returns ksplit (1 = no split).
+static int plan_ksplit(int B, int H, int Lq, int Lk, int dh, int64_t ws_floats, int* tiles_per_split) {
+    const int nt = (Lk + KT - 1) / KT;
+    const int64_t wgs = (int64_t)((Lq + 127) / 128) * H * B;
+    *tiles_per_split = nt;
+    if (wgs >= 192 || nt < 8) return 1;
+    int want = (int)((512 + wgs - 1) / wgs);
+    if (want > 16) want = 16;
+    int tps = (nt + want - 1) / want;
+    if (tps < 2) tps = 2;
+    const int ks = (nt + tps - 1) / tps;
+    const int64_t need = (int64_t)ks * B * Lq * H * dh + (int64_t)ks * B * H * Lq * 2 + (int64_t)B * Lq * H * dh;
+    if (ks < 2 || need > ws_floats) return 1;
+    *tiles_per_split = tps;
+    return ks;
+}
+int64_t svol_attn_ws_floats_bf16(int B, int H, int Lq, int Lk, int dh) {
+    int tps;
+    const int ks = plan_ksplit(B, H, Lq, Lk, dh, INT64_MAX, &tps);
+    if (ks < 2) return 0;
+    return (int64_t)ks * B * Lq * H * dh + (int64_t)ks * B * H * Lq * 2 + (int64_t)B * Lq * H * dh;
+}
+static void bind_ws(Args& p, float* ws) {
+    p.ws_o = ws;
+    p.ws_ml = p.ws_o + (int64_t)p.ksplit * p.B * p.Lq * p.H * p.dh;
+    p.ws_dq = p.ws_ml + (int64_t)p.ksplit * p.B * p.H * p.Lq * 2;
+}
+
 int svol_attn_fwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                               int64_t ldo, float* lse2, const float* kbias, int B, int H, int Lq, int Lk, int dh, float scale,
-                              float premul, hipStream_t s) {
+                              float premul, float* ws, int64_t ws_bytes, hipStream_t s) {
     Args p{};
     p.q = q; p.k = k; p.v = v; p.out_o = o; p.lse2 = lse2; p.kbias = kbias;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.dh = dh; p.scale = scale; p.premul = premul;
-    dim3 grid((unsigned)((Lq + 127) / 128), (unsigned)H, (unsigned)B);
     const bool masked = kbias != nullptr || (Lk % KT) != 0;
-    if (!masked && premul != 0.f) hipLaunchKernelGGL(attn_fwd_bf16_pre, grid, dim3(256), 0, s, p);
+    const bool pre = !masked && premul != 0.f;
+    p.ksplit = (ws && !pre) ? plan_ksplit(B, H, Lq, Lk, dh, ws_bytes / 4, &p.tiles_per_split) : 1;
+    if (p.ksplit == 1) p.tiles_per_split = (Lk + KT - 1) / KT;
+    else bind_ws(p, ws);
+    dim3 grid((unsigned)(((Lq + 127) / 128) * p.ksplit), (unsigned)H, (unsigned)B);
+    if (pre) hipLaunchKernelGGL(attn_fwd_bf16_pre, grid, dim3(256), 0, s, p);
     else if (masked) hipLaunchKernelGGL(attn_fwd_bf16<true>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(attn_fwd_bf16<false>, grid, dim3(256), 0, s, p);
+    if (p.ksplit > 1) {
+        const int64_t total = (int64_t)B * Lq * H;
+        hipLaunchKernelGGL(attn_combine_bf16, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, s, p);
+    }
     return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
 }
 
 int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                               const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta,
                               const float* kbias, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int B,
-                              int H, int Lq, int Lk, int dh, float scale, float premul, hipStream_t s) {
+                              int H, int Lq, int Lk, int dh, float scale, float premul, float* ws, int64_t ws_bytes,
+                              hipStream_t s) {
     Args p{};
     p.q = q; p.k = k; p.v = v; p.o = o; p.d_o = d_o; p.lse2 = const_cast<float*>(lse2); p.delta = delta; p.kbias = kbias;
     p.dq = dq; p.dk = dk; p.dv = dv;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
     p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.dh = dh; p.scale = scale; p.premul = premul;
     const int64_t total = (int64_t)B * Lq * H;
-    dim3 gd((unsigned)((total + 255) / 256));
-    dim3 gq((unsigned)((Lq + 127) / 128), (unsigned)H, (unsigned)B);
-    dim3 gk((unsigned)((Lk + 127) / 128), (unsigned)H, (unsigned)B);
     const bool masked = kbias != nullptr || (Lk % KT) != 0;
+    const bool pre = !masked && premul != 0.f;
+    p.ksplit = (ws && !pre) ? plan_ksplit(B, H, Lq, Lk, dh, ws_bytes / 4, &p.tiles_per_split) : 1;
+    if (p.ksplit == 1) p.tiles_per_split = (Lk + KT - 1) / KT;
+    else bind_ws(p, ws);
+    dim3 gd((unsigned)((total + 255) / 256));
+    dim3 gq((unsigned)(((Lq + 127) / 128) * p.ksplit), (unsigned)H, (unsigned)B);
+    dim3 gk((unsigned)((Lk + 127) / 128), (unsigned)H, (unsigned)B);
     hipLaunchKernelGGL(attn_delta_bf16, gd, dim3(256), 0, s, p);
     if (!masked && premul != 0.f) {
         hipLaunchKernelGGL(attn_bwd_dq_bf16_pre, gq, dim3(256), 0, s, p);
         hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre, gk, dim3(256), 0, s, p);
     } else if (masked) {
         hipLaunchKernelGGL(attn_bwd_dq_bf16<true>, gq, dim3(256), 0, s, p);
+        if (p.ksplit > 1) hipLaunchKernelGGL(attn_dq_finish_bf16, gd, dim3(256), 0, s, p);
         hipLaunchKernelGGL(attn_bwd_dkdv_bf16<true>, gk, dim3(256), 0, s, p);
     } else {
         hipLaunchKernelGGL(attn_bwd_dq_bf16<false>, gq, dim3(256), 0, s, p);
+        if (p.ksplit > 1) hipLaunchKernelGGL(attn_dq_finish_bf16, gd, dim3(256), 0, s, p);
         hipLaunchKernelGGL(attn_bwd_dkdv_bf16<false>, gk, dim3(256), 0, s, p);
     }
     return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;

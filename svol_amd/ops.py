@@ -234,14 +234,21 @@ def posenc_sine(mask_f32: torch.Tensor, D: int, dtype: torch.dtype) -> torch.Ten
     return pos
 
 
+def _attn_ws(q, B, H, Lq, Lk, dh):
+    """scratch for the key-split of few-query launches (None when the library would not split)."""
+    n = _lib.lib().svol_attn_ws_bytes(B, H, Lq, Lk, dh) if q.dtype == torch.bfloat16 else 0
+    return torch.empty((n // 4,), dtype=torch.float32, device=q.device) if n > 0 else None
+
+
 def attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias=None, premul=0.0):
     """q/k/v: 2-D [B*L, >=H*dh] views (column slices allowed). Returns o [B*Lq, H*dh], lse2 [B,H,Lq]."""
     o = torch.empty((B * Lq, H * dh), dtype=q.dtype, device=q.device)
     lse2 = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
+    ws = _attn_ws(q, B, H, Lq, Lk, dh)
     tok = timer.start('attn_fwd', (B, H, Lq, Lk, dh))
     rc = _lib.lib().svol_attn_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o),
                                   o.stride(0), _ptr(lse2), _ptr(kbias), B, H, Lq, Lk, dh, 1.0 / math.sqrt(dh),
-                                  float(premul), _dt(q), _stream())
+                                  float(premul), _ptr(ws), ws.numel() * 4 if ws is not None else 0, _dt(q), _stream())
     timer.stop(tok)
     _lib.check(rc, 'svol_attn_fwd')
     return o, lse2
@@ -251,11 +258,13 @@ def attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias=None, pre
     """Writes dq/dk/dv (2-D views, column slices allowed)."""
     do = do if do.stride(1) == 1 else do.contiguous()
     delta = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
+    ws = _attn_ws(q, B, H, Lq, Lk, dh)
     tok = timer.start('attn_bwd', (B, H, Lq, Lk, dh))
     rc = _lib.lib().svol_attn_bwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o),
                                   o.stride(0), _ptr(do), do.stride(0), _ptr(lse2), _ptr(delta), _ptr(kbias),
                                   _ptr(dq), dq.stride(0), _ptr(dk), dk.stride(0), _ptr(dv), dv.stride(0), B, H, Lq,
-                                  Lk, dh, 1.0 / math.sqrt(dh), float(premul), _dt(q), _stream())
+                                  Lk, dh, 1.0 / math.sqrt(dh), float(premul), _ptr(ws),
+                                  ws.numel() * 4 if ws is not None else 0, _dt(q), _stream())
     timer.stop(tok)
     _lib.check(rc, 'svol_attn_bwd')
 

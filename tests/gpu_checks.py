@@ -262,7 +262,9 @@ def _attn_ref(q, k, v, B, H, Lq, Lk, dh, kbias):
 def check_attention():
     res = {}
     cases = [(2, 4, 70, 150, 8, True), (1, 8, 200, 200, 32, False), (2, 8, 100, 333, 32, True), (1, 2, 129, 64, 16, False),
-             (1, 8, 384, 384, 32, False), (2, 4, 200, 256, 32, False), (1, 2, 100, 128, 8, False)]
+             (1, 8, 384, 384, 32, False), (2, 4, 200, 256, 32, False), (1, 2, 100, 128, 8, False),
+             # few queries x many keys: the bf16 path splits the keys over workgroups (last splits fully masked / ragged)
+             (2, 4, 100, 1500, 32, True), (1, 8, 70, 2048, 32, False), (2, 2, 130, 1100, 16, True)]
     for dt in DTYPES:
         for (B, H, Lq, Lk, dh, masked) in cases:
             d = H * dh
