@@ -370,6 +370,10 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_skinny_b16(FastArgs p) { gem
 
 }  // namespace
 
+int svol_gemm_ws_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias, int act,
+                      void* pre, int64_t ldp, const void* res, int64_t ldr, int out_f32, const void* aux, int64_t ldaux,
+                      float* colsum, int epi, const float* colscale, int64_t M, int64_t N, int64_t K, hipStream_t s);
+
 // launcher used by gemm.hip's C-ABI entry points.  Returns SVOL_E_UNSUPPORTED when the shape does not
 // qualify (the caller then uses the generic kernel).
 int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
@@ -386,6 +390,11 @@ int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ld
     if (aux && (ldaux % 4 || (reinterpret_cast<uintptr_t>(aux) % 8))) return SVOL_E_UNSUPPORTED;
     FastArgs p{(const bf16_t*)A, (const bf16_t*)B, C, bias, colscale, (bf16_t*)pre, res, (const bf16_t*)aux, colsum,
                lda, ldb, ldc, ldp, ldr, ldaux, (int)M, (int)N, (int)K, act, epi};
+    {   // K = 256, tall M: weight-stationary kernel (gemm_ws_bf16.hip)
+        const int rc = svol_gemm_ws_bf16(A, lda, B, ldb, C, ldc, bias, act, pre, ldp, res, ldr, out_f32, aux, ldaux, colsum, epi,
+                                         colscale, M, N, K, s);
+        if (rc != SVOL_E_UNSUPPORTED) return rc;
+    }
     static const int skinny_max = getenv("SVOL_GEMM_SKINNY_M") ? atoi(getenv("SVOL_GEMM_SKINNY_M")) : 2048;
     if (M <= skinny_max && K % 256 == 0 && N % SK_BN == 0) {
         dim3 g((unsigned)(N / SK_BN), (unsigned)((M + SK_BM - 1) / SK_BM));
