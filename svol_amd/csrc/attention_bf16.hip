@@ -16,6 +16,7 @@
 //    from one FMA (score * scale*log2e - m), no separate scale or subtract pass;
 //  * backward: the 1/sqrt(d_h) factor of dS is applied once to the dQ / dK accumulators at the end.
 #include <cstdint>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -833,30 +834,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_pre(Args p) {
         const char* doimg = sdO + cur * IMG;
         const unsigned* nl = sL + cur * KT;
         const unsigned* nd = sD + cur * KT;
-#pragma unroll 1
-        for (int sub = 0; sub < 4; ++sub) {
+        // software pipeline over the four 32-query sub-tiles: the score / dP products of sub-tile s+1 are issued
+        // BEFORE the exp / multiply / convert work of sub-tile s, so the matrix pipe runs under the VALU phase
+        // (a wave's MFMA -> VALU -> MFMA chain is strictly dependent otherwise, and the profile showed time = sum)
+        auto first_products = [&](int sub, f32x16& S, f32x16& dP) {
             uint4 a[2];
             // every lane loads its query's pair; for the h = 1 lanes (k = 8..15) `ones` is zero and the pair is finite
             const uint4 el = make_uint4(nl[sub * 32 + r], 0u, 0u, 0u);
             const uint4 ed = make_uint4(nd[sub * 32 + r], 0u, 0u, 0u);
             read_rows(a, qimg, sub * 32 + r, h);
-            f32x16 S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, el), __builtin_bit_cast(bf16x8, ones),
-                                                               zero16(), 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, el), __builtin_bit_cast(bf16x8, ones),
+                                                        zero16(), 0, 0, 0);
             S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, kbk[0]), S, 0, 0, 0);
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, kbk[1]), S, 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) S[i] = __builtin_amdgcn_exp2f(S[i]);  // score - lse[q]
-            read_tr(a, doimg, sub, lane);
-            mma_second(dV, a, S);
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, kbk[1]), S, 0, 0, 0);  // score - lse[q]
             read_rows(a, doimg, sub * 32 + r, h);
-            f32x16 dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ed), __builtin_bit_cast(bf16x8, ones),
-                                                                zero16(), 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ed), __builtin_bit_cast(bf16x8, ones),
+                                                         zero16(), 0, 0, 0);
             dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, vbk[0]), dP, 0, 0, 0);
             dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, vbk[1]), dP, 0, 0, 0);  // dO V^T - delta[q]
+        };
+        f32x16 S, dP, Sn, dPn;
+        first_products(0, S, dP);
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            if (sub + 1 < 4) first_products(sub + 1, Sn, dPn);
+            uint4 a[2];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[i] = __builtin_amdgcn_exp2f(S[i]);
+            read_tr(a, doimg, sub, lane);
+            mma_second(dV, a, S);
 #pragma unroll
             for (int i = 0; i < 16; ++i) S[i] *= dP[i];
             read_tr(a, qimg, sub, lane);
             mma_second(dK, a, S);
+            if (sub + 1 < 4) { S = Sn; dP = dPn; }
         }
         if (t + 1 < nt) {
             store_lds(sQ + (cur ^ 1) * IMG, sq, tid);
@@ -947,8 +958,9 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
     dim3 gk((unsigned)((Lk + 127) / 128), (unsigned)H, (unsigned)B);
     hipLaunchKernelGGL(attn_delta_bf16, gd, dim3(256), 0, s, p);
     if (!masked && premul != 0.f) {
-        hipLaunchKernelGGL(attn_bwd_dq_bf16_pre, gq, dim3(256), 0, s, p);
-        hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre, gk, dim3(256), 0, s, p);
+        static const int dyn = getenv("SVOL_ATTN_DYN_LDS") ? atoi(getenv("SVOL_ATTN_DYN_LDS")) : 0;  // occupancy experiments
+        hipLaunchKernelGGL(attn_bwd_dq_bf16_pre, gq, dim3(256), dyn, s, p);
+        hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre, gk, dim3(256), dyn, s, p);
     } else if (masked) {
         hipLaunchKernelGGL(attn_bwd_dq_bf16<true>, gq, dim3(256), 0, s, p);
         if (p.ksplit > 1) hipLaunchKernelGGL(attn_dq_finish_bf16, gd, dim3(256), 0, s, p);
