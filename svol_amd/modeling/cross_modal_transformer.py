@@ -43,6 +43,50 @@ class MLP(nn.Module):
         self.fc2 = nn.Linear(hidden_features, in_features)
 
 
+class _GateVectorsFn(torch.autograd.Function):
+    """u[b,h,:] = d_h^-1/2 * W_k,h^T (W_q,h s_b + b_q,h)  (B*d-sized algebra, torch ops on purpose).  A Function of
+    its own so that the packed in_proj parameters get ONE gradient each, written straight into the reducer's
+    bucket when there is one, instead of three slice-backward (zero-fill + copy + add) chains per layer."""
+
+    @staticmethod
+    def forward(ctx, skch, W_in, b_in, h):
+        d = skch.shape[1]
+        dh = d // h
+        q = torch.addmm(b_in[:d], skch, W_in[:d].t())                      # [B,d]
+        wk = W_in[d:2 * d].view(h, dh, d)
+        ctx.save_for_backward(skch, W_in, q)
+        ctx.h = h
+        ctx.sinks = (ops._claim(W_in, ctx.needs_input_grad[1]), ops._claim(b_in, ctx.needs_input_grad[2]))
+        return torch.einsum('bhe,hed->bhd', q.view(-1, h, dh), wk) * (dh ** -0.5)
+
+    @staticmethod
+    def backward(ctx, du):
+        skch, W_in, q = ctx.saved_tensors
+        h = ctx.h
+        d = skch.shape[1]
+        dh = d // h
+        sW, sb = ctx.sinks
+        du = du * (dh ** -0.5)
+        wk = W_in[d:2 * d].view(h, dh, d)
+        dq = torch.einsum('bhd,hed->bhe', du, wk).reshape(-1, d)           # [B,d]
+        dwk = torch.einsum('bhd,bhe->hed', du, q.view(-1, h, dh)).reshape(d, d)
+        dWq = dq.t() @ skch
+        dbq = dq.sum(0)
+        dskch = dq @ W_in[:d] if ctx.needs_input_grad[0] else None
+        if sW is not None:
+            sW.view[:d].add_(dWq)
+            sW.view[d:2 * d].add_(dwk)
+            dW = None
+        else:
+            dW = torch.cat([dWq, dwk, torch.zeros_like(dwk)])
+        if sb is not None:
+            sb.view[:d].add_(dbq)
+            db = None
+        else:
+            db = torch.cat([dbq, torch.zeros(2 * d, dtype=dbq.dtype, device=dbq.device)])
+        return dskch, dW, db, None
+
+
 class CrossModalTransformerLayer(nn.Module):
     def __init__(self, d_model=512, nhead=8, dim_feedforward=D_FF):
         super().__init__()
@@ -64,12 +108,8 @@ class CrossModalTransformerLayer(nn.Module):
         """u[b,h,:] = d_h^-1/2 * W_k,h^T (W_q,h skch_b + b_q,h): the 1-query attention's key
         projection folded into one d-vector per (batch, head).  [B,d] fp32 -> [B,H,d] fp32.
         (B*d-sized host-graph arithmetic; the L-sized work is in GateFn.)"""
-        d, h = self.d_model, self.nhead
-        dh = d // h
         m = self.sketch_video_cross_attn
-        q = torch.addmm(m.in_proj_bias[:d], skch, m.in_proj_weight[:d].t())
-        wk = m.in_proj_weight[d:2 * d].view(h, dh, d)
-        return torch.einsum('bhe,hed->bhd', q.view(-1, h, dh), wk) * (dh ** -0.5)
+        return _GateVectorsFn.apply(skch, m.in_proj_weight, m.in_proj_bias, self.nhead)
 
     def forward(self, mem32, skch32, out, pos, qpos, kbias):
         """mem32: fp32 video stream [B,L,d]; out = (out32, out, out + query_pos) query stream triple."""

@@ -62,11 +62,14 @@ class SetCriterion(nn.Module):
             names += [(0, 'loss_label'), (3, 'class_error')]
         if 'boxes' in self.losses:
             names += [(1, 'loss_bbox'), (2, 'loss_giou')]
+        # one unbind (its backward is ONE stack) instead of a select per dictionary entry (each select's backward is a
+        # zero-fill + copy + add on the [NL,4] loss table)
+        flat = losses.reshape(-1).unbind(0)
         for col, name in names:
-            out[name] = losses[NL - 1, col]
+            out[name] = flat[(NL - 1) * 4 + col]
         for i in range(NL - 1):
             for col, name in names:
-                out[f'{name}_{i}'] = losses[i, col]
+                out[f'{name}_{i}'] = flat[i * 4 + col]
         return out
 
     def last_indices(self):
