@@ -708,6 +708,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_pre(Args p) {
     if (qvalid && h == 0) p.lse2[((int64_t)b * p.H + hh) * p.Lq + qrow] = m + __builtin_amdgcn_logf(lt);
 }
 
+// Two 32-query blocks per wave (256 queries per workgroup): every K / V fragment read from LDS feeds two MFMAs, and
+// a wave always has a second, independent MFMA -> exp -> MFMA chain to issue from while the first one waits.
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_pre(Args p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * IMG];
     char* sK = smem;
@@ -715,21 +717,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_pre(Args p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, hh = blockIdx.y;
-    const int qrow = blockIdx.x * 128 + wave * 32 + r;
-    const bool qvalid = qrow < p.Lq;
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
     const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
     const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
 
-    uint4 qb[2], dob[2];
-    load_lane_block(qb, Q, p.ldq, qrow, qvalid, p.dh, h);
-    load_lane_block(dob, dO, p.lddo, qrow, qvalid, p.dh, h);
-    const int64_t sidx = ((int64_t)b * p.H + hh) * p.Lq + qrow;
-    const f32x16 Cl = splat16(qvalid ? -p.lse2[sidx] : -INFINITY);  // score - lse  (rows past Lq -> p = 0)
-    const f32x16 Cd = splat16(qvalid ? -p.delta[sidx] : 0.f);       // dP - delta
-
-    f32x16 dQ = zero16();
+    int qrow[2];
+    bool qvalid[2];
+    uint4 qb[2][2], dob[2][2];
+    f32x16 Cl[2], Cd[2], dQ[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        qrow[u] = blockIdx.x * 256 + wave * 64 + u * 32 + r;
+        qvalid[u] = qrow[u] < p.Lq;
+        load_lane_block(qb[u], Q, p.ldq, qrow[u], qvalid[u], p.dh, h);
+        load_lane_block(dob[u], dO, p.lddo, qrow[u], qvalid[u], p.dh, h);
+        const int64_t sidx = ((int64_t)b * p.H + hh) * p.Lq + qrow[u];
+        Cl[u] = splat16(qvalid[u] ? -p.lse2[sidx] : -INFINITY);  // score - lse  (rows past Lq -> p = 0)
+        Cd[u] = splat16(qvalid[u] ? -p.delta[sidx] : 0.f);       // dP - delta
+        dQ[u] = zero16();
+    }
     const int nt = p.Lk / KT;
     Stage sk, sv;
     load_regs(sk, K, p.ldk, 0, p.Lk, p.dh, tid);
@@ -747,15 +754,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_pre(Args p) {
         const char* vimg = sV + cur * IMG;
 #pragma unroll 2
         for (int sub = 0; sub < 4; ++sub) {
-            uint4 a[2];
-            read_rows(a, kimg, sub * 32 + r, h);
-            f32x16 S = mma_first_c(a, qb, Cl);
-            read_rows(a, vimg, sub * 32 + r, h);
-            const f32x16 dP = mma_first_c(a, dob, Cd);
+            uint4 ka[2], va[2], kt[2];
+            read_rows(ka, kimg, sub * 32 + r, h);
+            read_rows(va, vimg, sub * 32 + r, h);
+            f32x16 S0 = mma_first_c(ka, qb[0], Cl[0]);
+            f32x16 S1 = mma_first_c(ka, qb[1], Cl[1]);
+            const f32x16 dP0 = mma_first_c(va, dob[0], Cd[0]);
+            const f32x16 dP1 = mma_first_c(va, dob[1], Cd[1]);
+            read_tr(kt, kimg, sub, lane);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) S[i] = __builtin_amdgcn_exp2f(S[i]) * dP[i];
-            read_tr(a, kimg, sub, lane);
-            mma_second(dQ, a, S);
+            for (int i = 0; i < 16; ++i) S0[i] = __builtin_amdgcn_exp2f(S0[i]) * dP0[i];
+            mma_second(dQ[0], kt, S0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S1[i] = __builtin_amdgcn_exp2f(S1[i]) * dP1[i];
+            mma_second(dQ[1], kt, S1);
         }
         if (t + 1 < nt) {
             store_lds(sK + (cur ^ 1) * IMG, sk, tid);
@@ -764,7 +776,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_pre(Args p) {
         __syncthreads();
     }
     bf16_t* dQo = reinterpret_cast<bf16_t*>(p.dq) + (int64_t)b * p.Lq * p.lddq + hh * p.dh;
-    store_acc(dQ, dQo, p.lddq, qrow, qvalid, p.dh, h, p.scale);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) store_acc(dQ[u], dQo, p.lddq, qrow[u], qvalid[u], p.dh, h, p.scale);
 }
 
 // x as two bf16 (hi = rn(x), lo = rn(x - hi)) packed in one dword: |x - hi - lo| <= 2^-17 |x|
@@ -959,7 +972,7 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
     hipLaunchKernelGGL(attn_delta_bf16, gd, dim3(256), 0, s, p);
     if (!masked && premul != 0.f) {
         static const int dyn = getenv("SVOL_ATTN_DYN_LDS") ? atoi(getenv("SVOL_ATTN_DYN_LDS")) : 0;  // occupancy experiments
-        hipLaunchKernelGGL(attn_bwd_dq_bf16_pre, gq, dim3(256), dyn, s, p);
+        hipLaunchKernelGGL(attn_bwd_dq_bf16_pre, dim3((unsigned)((Lq + 255) / 256), (unsigned)H, (unsigned)B), dim3(256), dyn, s, p);
         hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre, gk, dim3(256), dyn, s, p);
     } else if (masked) {
         hipLaunchKernelGGL(attn_bwd_dq_bf16<true>, gq, dim3(256), 0, s, p);
