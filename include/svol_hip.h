@@ -51,6 +51,12 @@ int svol_cast(const void* src, int dtype_src, void* dst, int dtype_dst, int64_t 
 /* src fp32 [R,C] -> dst (dtype) [R,C] (may be null) and dstT (dtype) [C,R] (may be null).
  * Used once per step per weight: nn.Linear weights are [out,in]; dX = dY*W needs W^T K-contiguous. */
 int svol_cast_transpose(const float* src, void* dst, void* dstT, int dtype, int64_t R, int64_t C, void* stream);
+/* The same for MANY weights in one launch (one per training step instead of one per weight).  `descs` is a DEVICE
+ * array of n_desc records, sorted by tile_begin:
+ *   struct { const float* src; void* dst; void* dstT; int32 R, C, tiles_c, tile_begin; }   (40 bytes)
+ * tiles_c = ceil(C/32); a weight owns ceil(R/32)*tiles_c consecutive 32x32 tiles starting at tile_begin;
+ * total_tiles = their sum.  dst or dstT may be NULL per record. */
+int svol_cast_transpose_multi(const void* descs, int32_t n_desc, int64_t total_tiles, int dtype, void* stream);
 
 /* ---- GEMMs (nn.Linear and its backward) --------------------------------- */
 /* C[M,N] = act((A[M,K] * B[N,K]^T + bias[N]) * colscale[N]) + residual[M,N]

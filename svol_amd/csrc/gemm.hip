@@ -338,6 +338,47 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* src, T
     }
 }
 
+// all of a model's weights in ONE launch: block -> (descriptor, 32x32 tile) through a prefix table
+struct CastDesc {
+    const float* src; void* dst; void* dstT;
+    int R, C, tiles_c, tile_begin;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const CastDesc* __restrict__ descs, int n_desc) {
+    __shared__ float tile[32][33];
+    __shared__ int which;
+    if (threadIdx.x == 0) {  // binary search: last descriptor with tile_begin <= blockIdx.x
+        int lo = 0, hi = n_desc - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (descs[mid].tile_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        which = lo;
+    }
+    __syncthreads();
+    const CastDesc d = descs[which];
+    const int t = blockIdx.x - d.tile_begin;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int r0 = (t / d.tiles_c) * 32, c0 = (t % d.tiles_c) * 32;
+    T* dst = reinterpret_cast<T*>(d.dst);
+    T* dstT = reinterpret_cast<T*>(d.dstT);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + 8 * j, c = c0 + tx;
+        float v = (r < d.R && c < d.C) ? d.src[(int64_t)r * d.C + c] : 0.f;
+        tile[ty + 8 * j][tx] = v;
+        if (dst && r < d.R && c < d.C) dst[(int64_t)r * d.C + c] = from_f32<T>(v);
+    }
+    __syncthreads();
+    if (dstT) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + ty + 8 * j, r = r0 + tx;
+            if (r < d.R && c < d.C) dstT[(int64_t)c * d.R + r] = from_f32<T>(tile[tx][ty + 8 * j]);
+        }
+    }
+}
+
 template <typename T>
 __global__ void act_bwd_kernel(const T* dy, const T* aux, T* dpre, int act, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -525,6 +566,19 @@ int svol_cast_transpose(const float* src, void* dst, void* dstT, int dtype, int6
         hipLaunchKernelGGL(cast_transpose_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, (bf16_t*)dstT, (int)R, (int)C);
     else if (dtype == SVOL_F32)
         hipLaunchKernelGGL(cast_transpose_kernel<float>, grid, dim3(256), 0, s, src, (float*)dst, (float*)dstT, (int)R, (int)C);
+    else return SVOL_E_INVALID;
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_cast_transpose_multi(const void* descs, int32_t n_desc, int64_t total_tiles, int dtype, void* stream) {
+    static_assert(sizeof(CastDesc) == 40, "descriptor layout is part of the ABI (include/svol_hip.h)");
+    if (!descs || n_desc <= 0 || total_tiles <= 0) return SVOL_E_INVALID;
+    if (total_tiles > (1ll << 30)) return SVOL_E_UNSUPPORTED;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const CastDesc* d = reinterpret_cast<const CastDesc*>(descs);
+    if (dtype == SVOL_BF16) hipLaunchKernelGGL(cast_transpose_multi_kernel<bf16_t>, dim3((unsigned)total_tiles), dim3(256), 0, s, d, n_desc);
+    else if (dtype == SVOL_F32) hipLaunchKernelGGL(cast_transpose_multi_kernel<float>, dim3((unsigned)total_tiles), dim3(256), 0, s, d, n_desc);
     else return SVOL_E_INVALID;
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;

@@ -196,11 +196,15 @@ __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ m
     }
     __syncthreads();
     const int ntok = min(64, L - l0);
-    for (int e = tid; e < ntok * D; e += 256) {
-        const int t = e / D, i = e - t * D;
+    // a thread keeps its column(s): the frequency 10000^(2*floor(i/2)/D) is computed once, not per element
+    for (int i = tid; i < D; i += 256) {
         const float dim_t = powf(10000.f, (float)(2 * (i / 2)) / (float)D);
-        const float a = xe[t] / dim_t;
-        pos[((int64_t)b * L + l0 + t) * D + i] = from_f32<T>((i & 1) ? cosf(a) : sinf(a));
+        const bool odd = i & 1;
+        T* out = pos + ((int64_t)b * L + l0) * D + i;
+        for (int t = 0; t < ntok; ++t) {
+            const float a = xe[t] / dim_t;
+            out[(int64_t)t * D] = from_f32<T>(odd ? cosf(a) : sinf(a));
+        }
     }
 }
 

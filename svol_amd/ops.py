@@ -274,22 +274,56 @@ def attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias=None, pre
 # optimizer bumps the tensor version.  One cast per weight per step.
 # ----------------------------------------------------------------------------
 class _WeightCache:
-    """fp32 master weight -> compute-dtype copies (W and W^T).
+    """fp32 master weight -> compute-dtype copies (W and W^T) in persistent buffers.
 
-    The copies live ON the parameter object (attribute ``_svol_cache``).  They are refreshed whenever
-    the cache EPOCH advances — the model advances it at the start of every forward, so each weight is
-    cast exactly once per step — because tensor version counters cannot be trusted to see optimizer
-    updates (``torch.optim.AdamW(fused=True)`` rewrites parameters without bumping ``_version`` on
-    ROCm).  With ``static=True`` (frozen weights, e.g. serving) entries are validated by
-    (version, data pointer) instead."""
+    Every weight is (re)cast once per EPOCH — the model advances the epoch at the start of every forward —
+    because tensor version counters cannot be trusted to see optimizer updates (``torch.optim.AdamW(fused=True)``
+    rewrites parameters without bumping ``_version`` on ROCm).  The first time a weight is seen it is cast on the
+    spot and registered; from then on ``new_epoch()`` refreshes ALL registered weights of a (device, dtype) with
+    ONE ``svol_cast_transpose_multi`` launch driven by a device-side descriptor table (64 launches -> 1 per step
+    at the benchmark size).  With ``static=True`` (frozen weights, e.g. serving) nothing is refreshed."""
 
     def __init__(self):
         self.epoch = 0
         self.static = False
+        self._sets = {}  # (device, dtype) -> {'items': [(weakref(param), entry)], 'table': tensor|None, 'tiles': int}
+
+    class _Entry:
+        __slots__ = ('wc', 'wt', 'ptr', 'epoch', 'version', 'shape')
 
     def new_epoch(self):
-        if not self.static:
-            self.epoch += 1
+        if self.static:
+            return
+        self.epoch += 1
+        for key, st in self._sets.items():
+            self._refresh(key, st)
+
+    def _refresh(self, key, st):
+        dev, dtype = key
+        live = [(r, e) for (r, e) in st['items'] if r() is not None and getattr(r(), '_svol_cache', {}).get(dtype) is e
+                and r().data_ptr() == e.ptr]
+        if len(live) != len(st['items']) or st['table'] is None:
+            st['items'] = live
+            st['table'] = None
+            if not live:
+                return
+            recs = []
+            t0 = 0
+            for r, e in live:
+                R, C = e.shape
+                tc = (C + 31) // 32
+                # src, dst, dstT (8 bytes each) ; R, C, tiles_c, tile_begin (int32)
+                recs.append((e.ptr, 0 if dtype == torch.float32 else e.wc.data_ptr(), e.wt.data_ptr(), R, C, tc, t0))
+                t0 += ((R + 31) // 32) * tc
+            import struct
+            blob = b''.join(struct.pack('<QQQiiii', *rec) for rec in recs)
+            st['table'] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+            st['tiles'] = t0
+        _lib.check(_lib.lib().svol_cast_transpose_multi(_ptr(st['table']), len(st['items']), st['tiles'], _DT[dtype],
+                                                        _stream()), 'svol_cast_transpose_multi')
+        for r, e in st['items']:
+            e.epoch = self.epoch
+            e.version = r()._version
 
     def get(self, w: torch.Tensor, dtype: torch.dtype):
         cache = getattr(w, '_svol_cache', None)
@@ -299,18 +333,32 @@ class _WeightCache:
                 w._svol_cache = cache
             except Exception:  # pragma: no cover  (non-leaf views etc.: just do not cache)
                 pass
-        ent = cache.get(dtype)
-        tag = (self.epoch, w._version, w.data_ptr())
-        if ent is None or ent[0] != tag:
-            wd = w.detach()
-            if dtype == torch.float32:
-                _, wt = cast_transpose(wd, dtype, want=False)
-                ent = (tag, wd.contiguous(), wt)
-            else:
-                wc, wt = cast_transpose(wd, dtype)
-                ent = (tag, wc, wt)
-            cache[dtype] = ent
-        return ent[1], ent[2]
+        e = cache.get(dtype)
+        if e is not None and e.ptr == w.data_ptr() and e.version == w._version and (self.static or e.epoch == self.epoch):
+            return e.wc, e.wt
+        wd = w.detach()
+        assert wd.dtype == torch.float32 and wd.dim() == 2 and wd.is_contiguous()
+        fresh = e is None or e.ptr != w.data_ptr() or tuple(w.shape) != e.shape
+        if fresh:
+            e = self._Entry()
+            e.shape, e.ptr = tuple(w.shape), w.data_ptr()
+            R, C = e.shape
+            e.wc = wd if dtype == torch.float32 else torch.empty((R, C), dtype=dtype, device=w.device)
+            e.wt = torch.empty((C, R), dtype=dtype, device=w.device)
+        R, C = e.shape
+        _lib.check(_lib.lib().svol_cast_transpose(_ptr(wd), 0 if dtype == torch.float32 else _ptr(e.wc), _ptr(e.wt),
+                                                  _DT[dtype], R, C, _stream()), 'svol_cast_transpose')
+        e.epoch, e.version = self.epoch, w._version
+        if fresh:
+            cache[dtype] = e
+            st = self._sets.setdefault((w.device, dtype), {'items': [], 'table': None, 'tiles': 0})
+            try:
+                import weakref
+                st['items'].append((weakref.ref(w), e))
+                st['table'] = None
+            except TypeError:  # pragma: no cover
+                pass
+        return e.wc, e.wt
 
 
 weights = _WeightCache()
