@@ -1,0 +1,100 @@
+"""BASELINE.json's full sizes on the MI355X, checked through size-independent properties (the CPU oracle needs
+minutes and 13 GB per video at these sizes, so it is not the checker here):
+
+* cfg2 (T=32, P=196, d=256, 6 layers, N=100): videos are independent — the outputs, the matched assignment and the
+  per-video gradients of a 2-video batch equal those of each video run alone (this is also the property data-parallel
+  sharding relies on);
+* cfg2: padded key frames (src_video_mask = 0 on the last 25 % of frames) leave the query->video cross-attention
+  finite and change the outputs (the mask is honoured);
+* cfg5 (T=128, P=256: L = 32768 tokens): one forward + criterion + backward runs with nothing L x L resident
+  (peak memory bound), every output and gradient finite, boxes inside [0, 1].
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(args, dtype='bf16'):
+    from svol_amd.modeling.loss import build_loss
+    from svol_amd.modeling.svanet import build_svanet
+    args.compute_dtype = dtype
+    torch.manual_seed(1)
+    model = build_svanet(args).cuda().eval()
+    crit = build_loss(args).cuda().eval()
+    return model, crit
+
+
+def _run(model, crit, inp, tg, sl=None):
+    pick = (lambda v: v) if sl is None else (lambda v: v[sl])
+    for p in model.parameters():
+        p.grad = None
+    out = model(pick(inp['src_sketch']), pick(inp['src_sketch_mask']), pick(inp['src_video']), pick(inp['src_video_mask']))
+    ld = crit(out, tg if sl is None else tg[sl])
+    wd = crit.weight_dict
+    loss = sum(ld[k] * wd[k] for k in ld if k in wd)
+    loss.backward()
+    idx = crit.last_indices()
+    return out, ld, loss, idx
+
+
+def test_cfg2_videos_are_independent():
+    from svol_amd import synthetic as syn
+    args = syn.cfg2_args('video_matcher')
+    # fp32 operands: the only differences between the two runs are fp32 summation orders (grid-dependent splits), so
+    # the comparison can be tight and the assignment must be identical; in bf16 the same 1e-7 differences flip
+    # roundings and show up as ~3e-3 output noise (measured), still inside the 1e-2 parity bar
+    model, crit = _build(args, 'fp32')
+    B, T, P = 2, 32, 196
+    inp = {k: v.cuda() for k, v in syn.synth_inputs(args, B, T, P, seed=3).items()}
+    tg = syn.synth_targets(B, T, seed=3)
+    out, ld, loss, idx = _run(model, crit, inp, tg)
+    g_batch = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    for b in range(B):
+        ob, ldb, lossb, idxb = _run(model, crit, inp, tg, slice(b, b + 1))
+        assert (ob['pred_logits'] - out['pred_logits'][b:b + 1]).abs().max() < 2e-4
+        assert (ob['pred_boxes'] - out['pred_boxes'][b:b + 1]).abs().max() < 2e-4
+        for l_ in range(len(idx)):  # every decoder layer's Hungarian assignment, bit-exact
+            assert idxb[l_][0][0].tolist() == idx[l_][b][0].tolist() and idxb[l_][0][1].tolist() == idx[l_][b][1].tolist()
+    assert torch.isfinite(loss)
+    gmax = max(float(g.abs().max()) for g in g_batch.values())
+    assert gmax > 0 and all(torch.isfinite(g).all() for g in g_batch.values())
+
+
+def test_cfg2_key_padding_mask_is_honoured():
+    from svol_amd import synthetic as syn
+    args = syn.cfg2_args('video_matcher')
+    model, crit = _build(args)
+    B, T, P = 1, 32, 196
+    full = {k: v.cuda() for k, v in syn.synth_inputs(args, B, T, P, seed=5).items()}
+    pad = {k: v.cuda() for k, v in syn.synth_inputs(args, B, T, P, seed=5, pad_frames=8).items()}
+    with torch.no_grad():
+        o_full = model(full['src_sketch'], full['src_sketch_mask'], full['src_video'], full['src_video_mask'])
+        o_pad = model(pad['src_sketch'], pad['src_sketch_mask'], pad['src_video'], pad['src_video_mask'])
+        # garbage in the padded frames must not reach the object queries through the masked cross-attention ... but the
+        # reference leaves the video self-attention unmasked (cross_modal_transformer.py:137-141), so only finiteness
+        # and sensitivity are size-independent facts
+        assert torch.isfinite(o_pad['pred_logits']).all() and torch.isfinite(o_pad['pred_boxes']).all()
+        assert (o_pad['pred_boxes'] - o_full['pred_boxes']).abs().max() > 1e-4
+        assert float(o_pad['pred_boxes'].min()) >= 0.0 and float(o_pad['pred_boxes'].max()) <= 1.0
+
+
+def test_cfg5_long_video_runs_streaming():
+    from svol_amd import synthetic as syn
+    args = syn.head_args(num_frames=128)
+    model, crit = _build(args)
+    B, T, P = 1, 128, 256  # L = 32768 tokens
+    inp = {k: v.cuda() for k, v in syn.synth_inputs(args, B, T, P, seed=7).items()}
+    tg = syn.synth_targets(B, T, seed=7)
+    torch.cuda.reset_peak_memory_stats()
+    out, ld, loss, idx = _run(model, crit, inp, tg)
+    assert torch.isfinite(loss)
+    assert torch.isfinite(out['pred_logits']).all() and torch.isfinite(out['pred_boxes']).all()
+    assert float(out['pred_boxes'].detach().min()) >= 0.0 and float(out['pred_boxes'].detach().max()) <= 1.0
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), n
+    # one L x L fp32 score matrix for ONE head would be 4.3 GB; all 8 heads x 6 layers saved for backward 206 GB
+    assert torch.cuda.max_memory_allocated() < 16e9
+    assert len(idx) == args.num_layers and len(idx[-1][0][0]) == min(args.num_queries, sum(
+        len(v) for v in tg[0]['bboxes'].values()))
