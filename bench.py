@@ -76,7 +76,9 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the captured hipGraph (N=1)')
-    ap.add_argument('--batch', type=int, default=8, help='videos per GPU')
+    ap.add_argument('--batch', type=int, default=None, help='videos per GPU (default: 8, cfg5: 1)')
+    ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg5'],
+                    help='cfg2 = the BASELINE metric workload (default); cfg5 = long-video stress case T=128, P=256 (bf16)')
     a = ap.parse_args()
 
     import torch
@@ -97,8 +99,9 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
 
-    B, T, P = a.batch, 32, 196
-    args = syn.cfg2_args('video_matcher')
+    T, P = (32, 196) if a.workload == 'cfg2' else (128, 256)
+    B = a.batch if a.batch is not None else (8 if a.workload == 'cfg2' else 1)
+    args = syn.cfg2_args('video_matcher') if a.workload == 'cfg2' else syn.head_args(num_frames=T)
     args.compute_dtype = a.dtype
     torch.manual_seed(1)  # reference default seed (configs.py:17): identical initial weights on every rank
     model = build_svanet(args).to(dev).train()
@@ -176,6 +179,7 @@ def main():
     fwd = summ.get(('attn_fwd', (B, args.nheads, L, L, dh)))
     bwd = summ.get(('attn_bwd', (B, args.nheads, L, L, dh)))
     attn_fwd_flop = 4.0 * L * L * args.hidden_dim * B          # QK^T + PV  (4 L^2 d per sample)
+    gf_frame = FWD_BWD_GF_PER_FRAME if a.workload == 'cfg2' else 169.3
     roof = None
     if fwd and bwd:
         # backward = 2x forward algorithmically (dV, dP, dQ, dK products; the S recompute gets no credit)
@@ -187,18 +191,18 @@ def main():
                 'launch_ms': ms, 'launches_timed': bwd[0] if bwd[1] >= fwd[1] else fwd[0],
                 'attn_fwd_ms': fwd[1], 'attn_bwd_ms': bwd[1],
                 'attn_fwd_tflops': attn_fwd_flop / (fwd[1] * 1e-3) / 1e12,
-                'whole_step_tflops': fps * FWD_BWD_GF_PER_FRAME / 1e3 / world,
-                'whole_step_frac_of_peak': fps * FWD_BWD_GF_PER_FRAME / 1e3 / world / PEAK_BF16_MFMA_TFLOPS}
+                'whole_step_tflops': fps * gf_frame / 1e3 / world,
+                'whole_step_frac_of_peak': fps * gf_frame / 1e3 / world / PEAK_BF16_MFMA_TFLOPS}
 
     if rank == 0:
         res = {
-            'metric': 'frames/sec (fwd+matcher+bwd), T=32·P=196·d=256',
+            'metric': 'frames/sec (fwd+matcher+bwd), T=%d·P=%d·d=256' % (T, P),
             'value': fps, 'unit': 'frames/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': a.dtype, 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: SVANet head + Hungarian/GIoU criterion, B=%d/GPU, T=32, P=196, '
+            'config': {'workload': 'BASELINE configs[%d]: SVANet head + Hungarian/GIoU criterion, B=%d/GPU, T=%d, P=%d, '
                                    'd=256, h=8, 6 layers, N=100, video_matcher, Din=512, train mode; step = fwd + '
-                                   'criterion + bwd (+RCCL grad all-reduce) + AdamW' % B,
+                                   'criterion + bwd (+RCCL grad all-reduce) + AdamW' % (1 if a.workload == 'cfg2' else 4, B, T, P),
                        'global_batch': B * world, 'parallelism': f'dp{world}'},
             'final_loss': final_loss,
             'launch_mode': 'hipGraph replay (whole step captured)' if use_graph else 'eager',
