@@ -193,3 +193,35 @@ def synth_head_outputs(B: int, N: int, seed: int = 1):
     wh = r.uniform(0.02, 0.5, size=(B, N, 2))
     boxes = np.concatenate([cxcy, wh], -1).astype(np.float32)
     return torch.from_numpy(logits), torch.from_numpy(boxes)
+
+
+def synth_eval_outputs(targets, N: int, T: int, seed: int = 1, noise: float = 0.08, tie_every: int = 0):
+    """Head outputs that make the evaluation metrics non-trivial: the queries of chunk t (``chunk(num_frames)``
+    order, test.py:148) sit near the ground-truth boxes of the t-th annotated frame (when it has any) with
+    ``noise``-sized perturbations, the rest are random; ``tie_every`` > 0 duplicates every k-th logit pair so that
+    equal scores exercise the stable sort.  Returns (pred_logits [B,N,2], pred_boxes [B,N,4]) fp32."""
+    r = _rs('eval_outputs', seed)
+    B = len(targets)
+    chunk = -(-N // T)
+    logits = r.standard_normal((B, N, 2)).astype(np.float32)
+    cxcy = r.uniform(0.1, 0.9, size=(B, N, 2))
+    wh = r.uniform(0.02, 0.5, size=(B, N, 2))
+    boxes = np.concatenate([cxcy, wh], -1).astype(np.float32)
+    for b, tg in enumerate(targets):
+        frames = list(tg['bboxes'].keys())
+        for c in range(-(-N // chunk)):
+            if c >= len(frames):
+                break
+            gts = tg['bboxes'][frames[c]]
+            for j in range(chunk):
+                n = c * chunk + j
+                if n >= N or not gts:
+                    continue
+                if r.uniform() < 0.7:
+                    g = gts[int(r.randint(0, len(gts)))]['bbox'].numpy()
+                    boxes[b, n] = np.clip(g + r.uniform(-noise, noise, size=4) * np.array([1, 1, 0.5, 0.5]), 0.01, 0.99)
+                    logits[b, n, 0] += 1.5
+    if tie_every:
+        for n in range(tie_every, N, tie_every):
+            logits[:, n] = logits[:, n - 1]
+    return torch.from_numpy(logits), torch.from_numpy(boxes.astype(np.float32))
