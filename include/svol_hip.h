@@ -193,6 +193,26 @@ int svol_set_loss(const float* logits, const float* boxes, const float* tgt_boxe
                   int32_t rows_per_layer, float eos_coef, const int32_t* rebase_vid_off, int32_t rows_per_video,
                   void* stream);
 
+/* ---- post-processing + evaluation (the step after the hot path: test.py:133-169, lib/evaluate/eval.py,
+ * lib/evaluate/utils.py) ------------------------------------------------------------------
+ * svol_postprocess: logits [B,N,2], boxes [B,N,4] (cxcywh) fp32 -> out [B,N,5] fp32 = (x0,y0,x1,y1 clamped to [0,1],
+ *   foreground score softmax(logits)[...,0]); rows are grouped in consecutive chunks of `chunk` = ceil(N/num_frames)
+ *   (torch.chunk, test.py:148) and sorted by score, descending and stable, inside each chunk (test.py:150-153). */
+int svol_postprocess(const float* logits, const float* boxes, float* out, int64_t B, int64_t N, int64_t chunk, void* stream);
+/* recall@k / mIoU@k (eval.py:72-99): one record = one (video, frame); pred_box [P,4], gt_box [G,4] xyxy fp64;
+ * pred_off / gt_off [R+1] record offsets; gt_rec [G] record of each ground-truth box.  out[g] = max IoU of box g over the
+ * first k predictions of its record, with the reference's pair layout (utils.py:88-96) and numpy's NaN propagation. */
+int svol_eval_max_iou(const double* pred_box, const int32_t* pred_off, const double* gt_box, const int32_t* gt_off,
+                      const int32_t* gt_rec, double* out, int64_t n_gt, int32_t k, void* stream);
+/* AP per (video, sketch) group at every IoU threshold (utils.py:121-201).  Predictions / ground truths of a group are
+ * contiguous: grp_pred_off / grp_gt_off [n_groups+1]; *_frame are integer ids of the frame keys (equal id <=> same
+ * frame).  Scratch (caller-owned): ws_order int32 [n_pred]; ws_u8 bytes [K*(n_pred + n_gt)];
+ * ws_f64 fp64 [2*K*(n_pred + 2*n_groups)].  ap [n_groups, K] fp64, bit-identical to the reference's numpy result. */
+int svol_eval_ap(const double* pred_box, const double* pred_score, const int32_t* pred_frame, const int32_t* grp_pred_off,
+                 const double* gt_box, const int32_t* gt_frame, const int32_t* grp_gt_off, const double* thresholds,
+                 int32_t n_thresholds, int32_t* ws_order, unsigned char* ws_u8, double* ws_f64, double* ap, int64_t n_pred,
+                 int64_t n_gt, int64_t n_groups, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,5 +29,7 @@ def install_as_lib():
         'lib.modeling.loss': 'svol_amd.modeling.loss',
         'lib.utils': 'svol_amd.utils',
         'lib.utils.box_utils': 'svol_amd.utils.box_utils',
+        'lib.evaluate': 'svol_amd.evaluate',
+        'lib.evaluate.eval': 'svol_amd.evaluate.eval',
     }.items():
         sys.modules[ref] = importlib.import_module(ours)

@@ -32,6 +32,9 @@ SIGNATURES = {
     'svol_layernorm_fwd': [_p, _int, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _f32, _u64, _p, _int, _p],
     'svol_layernorm_bwd': [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f32, _u64, _p, _int, _p],
     'svol_cast_transpose_multi': [_p, _int, _i64, _int, _p],
+    'svol_postprocess': [_p, _p, _p, _i64, _i64, _i64, _p],
+    'svol_eval_max_iou': [_p, _p, _p, _p, _p, _p, _i64, _int, _p],
+    'svol_eval_ap': [_p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _p, _i64, _i64, _i64, _p],
     'svol_posenc_sine': [_p, _p, _i64, _i64, _i64, _int, _p],
     'svol_attn_ws_bytes': [_i64, _i64, _i64, _i64, _i64],
     'svol_attn_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _p, _i64,

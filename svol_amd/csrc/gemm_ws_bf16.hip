@@ -55,9 +55,9 @@ __device__ __forceinline__ int ws_col(int t, int i) { return (t >> 1) * 32 + (i 
 // MODE 1: C (f32)  = acc + bias + residual(f32)            (the fp32 residual stream; extra plane: residual slab)
 // MODE 2: C (bf16) = acc * gelu'(aux), column sums          (extra plane: aux slab)
 template <int MODE> struct WsCfg;
-template <> struct WsCfg<0> { static constexpr int SLOT = A_PLANE, STG = 4, ND = 2, NS_MAX = 4; };
-template <> struct WsCfg<1> { static constexpr int SLOT = A_PLANE + TR * 256 * 4, STG = 3, ND = 6, NS_MAX = 4; };
-template <> struct WsCfg<2> { static constexpr int SLOT = 2 * A_PLANE, STG = 4, ND = 4, NS_MAX = 2; };
+template <> struct WsCfg<0> { static constexpr int SLOT = A_PLANE, STG = 4, ND = 2; };
+template <> struct WsCfg<1> { static constexpr int SLOT = A_PLANE + TR * 256 * 4, STG = 3, ND = 6; };
+template <> struct WsCfg<2> { static constexpr int SLOT = 2 * A_PLANE, STG = 4, ND = 4; };
 
 template <int MODE>
 __device__ __forceinline__ void gemm_ws_body(const WsArgs& p) {
