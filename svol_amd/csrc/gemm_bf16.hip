@@ -374,6 +374,10 @@ int svol_gemm_ws_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, vo
                       void* pre, int64_t ldp, const void* res, int64_t ldr, int out_f32, const void* aux, int64_t ldaux,
                       float* colsum, int epi, const float* colscale, int64_t M, int64_t N, int64_t K, hipStream_t s);
 
+int svol_gemm_n256_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias, int act,
+                        void* pre, const void* res, int64_t ldr, int out_f32, int epi, const float* colscale, int64_t M,
+                        int64_t N, int64_t K, hipStream_t s);
+
 // launcher used by gemm.hip's C-ABI entry points.  Returns SVOL_E_UNSUPPORTED when the shape does not
 // qualify (the caller then uses the generic kernel).
 int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
@@ -393,6 +397,10 @@ int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ld
     {   // K = 256, tall M: weight-stationary kernel (gemm_ws_bf16.hip)
         const int rc = svol_gemm_ws_bf16(A, lda, B, ldb, C, ldc, bias, act, pre, ldp, res, ldr, out_f32, aux, ldaux, colsum, epi,
                                          colscale, M, N, K, s);
+        if (rc != SVOL_E_UNSUPPORTED) return rc;
+    }
+    {   // N = 256, deep K, tall M: full-width tiles (gemm_n256_bf16.hip)
+        const int rc = svol_gemm_n256_bf16(A, lda, B, ldb, C, ldc, bias, act, pre, res, ldr, out_f32, epi, colscale, M, N, K, s);
         if (rc != SVOL_E_UNSUPPORTED) return rc;
     }
     static const int skinny_max = getenv("SVOL_GEMM_SKINNY_M") ? atoi(getenv("SVOL_GEMM_SKINNY_M")) : 2048;

@@ -46,7 +46,8 @@ def _act(x, act):
 # ---------------------------------------------------------------------------
 def check_gemm_nt():
     res = {}
-    shapes = [(300, 200, 96), (128, 128, 64), (50, 2, 32), (1, 256, 512), (257, 130, 8), (640, 2048, 256)]
+    shapes = [(300, 200, 96), (128, 128, 64), (50, 2, 32), (1, 256, 512), (257, 130, 8), (640, 2048, 256),
+              (4200, 256, 512), (4100, 256, 2048), (5000, 256, 256), (4500, 512, 256)]  # tall M: N=256 deep-K and K=256 weight-stationary paths
     for dt in DTYPES:
         for (M, N, K) in shapes:
             for act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_GELU, ops.ACT_SIGMOID):
@@ -79,6 +80,12 @@ def check_gemm_nt():
         out = ops.gemm_nt(A.to(DEV), Bm.to(DEV), bias.to(DEV), residual=R.to(DEV), out_f32=True)
         ref = A.double() @ Bm.double().t() + bias.double() + R.double()
         res[f'gemm_nt/{dt}/out_f32'] = (rel_err(out, ref), 2e-5 if dt == torch.float32 else 1e-5)
+        for (M, N, K) in [(4133, 256, 1024), (4099, 256, 256)]:  # tall-M fp32-stream variants (ragged M)
+            A, Bm = _rnd((M, K), dt, 17), _rnd((N, K), dt, 18, 1.0 / math.sqrt(K))
+            R, bias = _rnd((M, N), torch.float32, 19), _rnd((N,), torch.float32, 20)
+            out = ops.gemm_nt(A.to(DEV), Bm.to(DEV), bias.to(DEV), residual=R.to(DEV), out_f32=True)
+            ref = A.double() @ Bm.double().t() + bias.double() + R.double()
+            res[f'gemm_nt/{dt}/out_f32/{M}x{N}x{K}'] = (rel_err(out, ref), 2e-5 if dt == torch.float32 else 1e-5)
         res[f'gemm_nt/{dt}/out_f32_dtype'] = (0.0 if out.dtype == torch.float32 else 1.0, 0.5)
         # skinny-M path (bf16: intra-workgroup split-K kernel): every epilogue, ragged M, deep K, fp32 stream, colscale
         for (M, N, K) in [(333, 128, 256), (800, 256, 2048), (31, 64, 512)]:
