@@ -27,7 +27,7 @@ struct WsArgs {
     const bf16_t* A; const bf16_t* W; void* C;
     const float* bias; const float* colscale; bf16_t* pre; const void* res; const bf16_t* aux; float* colsum;
     int64_t lda, ldw, ldc, ldp, ldr, ldaux;
-    int M, N, act, tiles_per_wg;
+    int M, N, act, tiles_per_wg, nchunk;
 };
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -66,10 +66,14 @@ __device__ __forceinline__ void gemm_ws_body(const WsArgs& p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int cg0 = blockIdx.x * 256;          // first column of this workgroup
+    // 1-D grid, row chunk fastest: workgroup ids go round-robin over the 8 XCDs, so with nchunk % 8 == 0 the column
+    // groups that share a row chunk (and re-read its A slabs) sit on ONE XCD and meet in its L2
+    // (rocprofv3 FETCH_SIZE of fc1, 8 column groups: 197 MB with the column group fastest = every re-read from memory)
+    const int chunk_id = blockIdx.x % p.nchunk, cg = blockIdx.x / p.nchunk;
+    const int cg0 = cg * 256;                  // first column of this workgroup
     const int c0 = cg0 + wave * 64;            // first column of this wave (N % 64 == 0)
     const bool active = c0 < p.N;              // idle waves still move their share of the slabs
-    const int tile0 = blockIdx.y * p.tiles_per_wg;
+    const int tile0 = chunk_id * p.tiles_per_wg;
     const int row_base = tile0 * TR;
     const int rows_here = min(p.tiles_per_wg * TR, p.M - row_base);
     const int ntile = (rows_here + TR - 1) / TR;
@@ -347,11 +351,16 @@ int svol_gemm_ws_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, vo
     }
     const int64_t ldmax = lda > ldr * 2 ? lda : ldr * 2;
     if (tpw * TR * (ldmax > ldaux ? ldmax : ldaux) * 2 >= (1ll << 31)) return SVOL_E_UNSUPPORTED;
-    const int64_t nchunk = (ntile + tpw - 1) / tpw;
-    if (nchunk > 65535) return SVOL_E_UNSUPPORTED;
+    int64_t nchunk = (ntile + tpw - 1) / tpw;
+    if (ncg > 1 && nchunk > 8 && nchunk % 8) {  // a multiple of the 8 XCDs when column groups share rows
+        const int64_t n8 = (nchunk + 7) / 8 * 8;
+        const int64_t t8 = (ntile + n8 - 1) / n8;
+        if (t8 >= 1 && (ntile + t8 - 1) / t8 == n8) { tpw = t8; nchunk = n8; }
+    }
+    if (nchunk * ncg > (1ll << 30)) return SVOL_E_UNSUPPORTED;
     WsArgs p{(const bf16_t*)A, (const bf16_t*)W, C, bias, colscale, (bf16_t*)pre, res, (const bf16_t*)aux, colsum,
-             lda, ldw, ldc, ldp, ldr, ldaux, (int)M, (int)N, act, (int)tpw};
-    dim3 grid((unsigned)ncg, (unsigned)nchunk);
+             lda, ldw, ldc, ldp, ldr, ldaux, (int)M, (int)N, act, (int)tpw, (int)nchunk};
+    dim3 grid((unsigned)(ncg * nchunk));
     if (mode == 0) hipLaunchKernelGGL(gemm_ws_bf16_m0, grid, dim3(256), 0, s, p);
     else if (mode == 1) hipLaunchKernelGGL(gemm_ws_bf16_m1, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(gemm_ws_bf16_m2, grid, dim3(256), 0, s, p);
