@@ -971,9 +971,8 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
     dim3 gk((unsigned)((Lk + 127) / 128), (unsigned)H, (unsigned)B);
     hipLaunchKernelGGL(attn_delta_bf16, gd, dim3(256), 0, s, p);
     if (!masked && premul != 0.f) {
-        static const int dyn = getenv("SVOL_ATTN_DYN_LDS") ? atoi(getenv("SVOL_ATTN_DYN_LDS")) : 0;  // occupancy experiments
-        hipLaunchKernelGGL(attn_bwd_dq_bf16_pre, dim3((unsigned)((Lq + 255) / 256), (unsigned)H, (unsigned)B), dim3(256), dyn, s, p);
-        hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre, gk, dim3(256), dyn, s, p);
+        hipLaunchKernelGGL(attn_bwd_dq_bf16_pre, dim3((unsigned)((Lq + 255) / 256), (unsigned)H, (unsigned)B), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre, gk, dim3(256), 0, s, p);
     } else if (masked) {
         hipLaunchKernelGGL(attn_bwd_dq_bf16<true>, gq, dim3(256), 0, s, p);
         if (p.ksplit > 1) hipLaunchKernelGGL(attn_dq_finish_bf16, gd, dim3(256), 0, s, p);
