@@ -12,7 +12,9 @@ workload: BASELINE.json configs[1]  — B=8 videos per GPU, T=32 frames, P=196 t
           compute with an fp32 residual stream, train mode (input dropout on), synthetic data,
           weights: module default init.  One step = zero_grad, forward, criterion (all 6 layers matched on
           device), backward (+ bucketed RCCL gradient all-reduce overlapped with backward when N > 1), and
-          the AdamW step (so that the per-step fp32->bf16 weight refresh is inside the timed region).
+          the AdamW step (so that the per-step fp32->bf16 weight refresh is inside the timed region).  Launches are
+          eager (host issue ~15 ms/step, hidden behind ~24 ms of GPU work) at every N, so the N = 1 and N > 1 numbers
+          are the same program; --graph replays the step as one hipGraph instead.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -75,7 +77,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the captured hipGraph (N=1)')
+    ap.add_argument('--graph', action='store_true',
+                    help='N=1 only: replay the whole step as one captured hipGraph (removes the ~15 ms/step of host issue time, '
+                         'but a captured graph serialises the query-stream / video-stream overlap: measured slower)')
+    ap.add_argument('--no-graph', action='store_true', help='accepted for compatibility (eager is the default)')
     ap.add_argument('--batch', type=int, default=None, help='videos per GPU (default: 8, cfg5: 1)')
     ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg5'],
                     help='cfg2 = the BASELINE metric workload (default); cfg5 = long-video stress case T=128, P=256 (bf16)')
@@ -108,7 +113,7 @@ def main():
     crit = build_loss(args).to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
     reducer = parallel.BucketedGradAllReduce(params, skip=parallel.unused_parameters(model))
-    use_graph = world == 1 and not a.no_graph
+    use_graph = world == 1 and a.graph and not a.no_graph
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, fused=True, capturable=use_graph)  # train.py:98-99
     # weak scaling: every rank gets its own B videos (different seeds = a properly sharded global batch)
     inp = {k: v.to(dev) for k, v in syn.synth_inputs(args, B, T, P, seed=1 + rank).items()}

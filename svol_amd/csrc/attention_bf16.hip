@@ -102,6 +102,16 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
     return r;
 }
 
+// The score accumulators are first read by inline-asm v_max3_f32 (max3 above).  hipcc pads an MFMA write -> VALU read
+// of the same registers with the required wait states only for instructions it can see; inline asm is opaque to
+// its hazard recogniser, so without this fence the maxima were taken from accumulators still in flight whenever
+// the wave was not held up by its partner: numerically harmless (the maximum is only the softmax reference point)
+// but the outputs changed by an ulp from run to run.  19 wait states cover a 16-pass MFMA; the "+v" ties place the
+// fence after every score MFMA and before every use.
+__device__ __forceinline__ void mfma_results_ready(f32x16& a, f32x16& b, f32x16& c, f32x16& d) {
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll
@@ -206,6 +216,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(Args p) {
             read_rows(ka, kimg, sub * 32 + r, h);
             S[sub] = mma_first(ka, qb);
         }
+        mfma_results_ready(S[0], S[1], S[2], S[3]);
         if (MASKED) {
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub)
@@ -650,6 +661,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_pre(Args p) {
             read_rows(ka, kimg, sub * 32 + r, h);
             S[sub] = mma_first_c(ka, qb, Cm);  // = score - m
         }
+        mfma_results_ready(S[0], S[1], S[2], S[3]);
         float ml[4];
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {

@@ -24,6 +24,7 @@ SVANet.forward, svanet.py:91) are not materialised.
 from __future__ import annotations
 
 import copy
+import os
 
 import torch
 from torch import nn
@@ -41,6 +42,27 @@ class MLP(nn.Module):
         super().__init__()
         self.fc1 = nn.Linear(in_features, hidden_features)
         self.fc2 = nn.Linear(hidden_features, in_features)
+
+
+OVERLAP_QUERY_STREAM = os.environ.get('SVOL_NO_STREAM_OVERLAP') is None
+_SIDE = {}
+
+
+def _side_stream(dev):
+    s = _SIDE.get(dev)
+    if s is None:
+        s = _SIDE[dev] = torch.cuda.Stream(device=dev)
+        # parameters of the query half get their gradients from side-stream nodes by design
+        try:
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        except AttributeError:  # pragma: no cover  (older torch)
+            pass
+    return s
+
+
+def side_streams(dev):
+    """side streams this module has used on `dev` (svol_amd.parallel joins them before reading gradient buckets)."""
+    return [s for d, s in _SIDE.items() if d == dev]
 
 
 class _GateVectorsFn(torch.autograd.Function):
@@ -117,17 +139,30 @@ class CrossModalTransformerLayer(nn.Module):
         n = lambda m: (m.weight, m.bias)
         mha = lambda m: (m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias)
         mlp = lambda m: (m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
-        # video ("encoder-like") half, :122-143
+        m32, m, mpos = self.video_half(mem32, skch32, pos)
+        return m32, self.query_half(out, m, mpos, qpos, kbias)
+
+    def video_half(self, mem32, skch32, pos):
+        """the "encoder-like" half, :122-143 -> (fp32 stream, compute-dtype copy, copy + pos)."""
+        h = self.nhead
+        n = lambda m: (m.weight, m.bias)
+        mha = lambda m: (m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias)
+        mlp = lambda m: (m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
         m32, m, mpos = ops.gate(mem32, pos, self.gate_vectors(skch32), *n(self.norm1), h)
         m32, m = ops.self_attn_ln(m32, m, mpos, *mha(self.content_self_attn), *n(self.norm2), None, h)
-        m32, m, mpos = ops.mlp_ln(m32, m, *mlp(self.mlp1), *n(self.norm3), pos)
-        # query ("decoder-like") half, :145-158
+        return ops.mlp_ln(m32, m, *mlp(self.mlp1), *n(self.norm3), pos)
+
+    def query_half(self, out, m, mpos, qpos, kbias):
+        """the "decoder-like" half, :145-158: object queries attend to themselves, then to the video tokens."""
+        h = self.nhead
+        n = lambda m_: (m_.weight, m_.bias)
+        mha = lambda m_: (m_.in_proj_weight, m_.in_proj_bias, m_.out_proj.weight, m_.out_proj.bias)
+        mlp = lambda m_: (m_.fc1.weight, m_.fc1.bias, m_.fc2.weight, m_.fc2.bias)
         o32, o, opos = out
         o32, o, opos = ops.self_attn_ln(o32, o, opos, *mha(self.token_self_attn), *n(self.norm4), qpos, h)
         o32, o = ops.cross_attn_ln(o32, o, opos, mpos, m, *mha(self.content_token_cross_attn), *n(self.norm5), None, h,
                                    kbias)
-        out = ops.mlp_ln(o32, o, *mlp(self.mlp2), *n(self.norm6), qpos)
-        return m32, out
+        return ops.mlp_ln(o32, o, *mlp(self.mlp2), *n(self.norm6), qpos)
 
 
 class CrossModalTransformer(nn.Module):
@@ -153,9 +188,38 @@ class CrossModalTransformer(nn.Module):
                qpos.unsqueeze(0).expand(B, -1, -1).contiguous())
         mem32 = src_vid32
         outputs = []
+        if not OVERLAP_QUERY_STREAM:
+            for layer in self.layers:
+                mem32, out = layer(mem32, src_skch32, out, vid_pos, qpos, kbias)
+                outputs.append(out[0])
+            return torch.stack(outputs)
+        # The query half of layer i (N = 100 object queries: skinny GEMMs, 64-512 workgroup attention launches, small
+        # LayerNorms — none of them fills 256 CUs) only needs layer i's video tokens; the video half of layer i+1 does
+        # not need the queries at all.  The query half therefore runs on a side stream under the next layer's video
+        # kernels; autograd replays each node on its forward stream, so the backward overlaps the same way, and a
+        # captured hipGraph gets the fork / join edges.
+        main = torch.cuda.current_stream()
+        side = _side_stream(main.device)
+        side.wait_stream(main)  # qpos
+        qpos.record_stream(side)
+        kbias.record_stream(side)
+        with torch.cuda.stream(side):
+            # the query state lives on the side stream from the start: a tensor allocated on the main stream and
+            # dropped by the host while a side-stream kernel still has it queued (the fp32 zeros are only a GEMM
+            # residual, nothing keeps them alive) would be handed to the next main-stream allocation
+            out = tuple(t.clone() for t in out)
         for layer in self.layers:
-            mem32, out = layer(mem32, src_skch32, out, vid_pos, qpos, kbias)
-            outputs.append(out[0])
+            m32, m, mpos = layer.video_half(mem32, src_skch32, vid_pos)
+            side.wait_stream(main)
+            m.record_stream(side)
+            mpos.record_stream(side)
+            with torch.cuda.stream(side):
+                out = layer.query_half(out, m, mpos, qpos, kbias)
+                outputs.append(out[0])
+            mem32 = m32
+        main.wait_stream(side)
+        for t in outputs:
+            t.record_stream(main)
         return torch.stack(outputs)
 
 

@@ -105,6 +105,12 @@ class BucketedGradAllReduce:
 
     def finish(self):
         """Wait for every in-flight bucket and turn sums into means.  Call after backward()."""
+        if self.on_gpu:
+            # kernels that accumulate straight into the buckets (gradient sinks) may have run on the model's side
+            # stream (query-stream / video-stream overlap): join it before anyone reads the buckets
+            from .modeling import cross_modal_transformer as cmt
+            for s in cmt.side_streams(self.device):
+                torch.cuda.current_stream().wait_stream(s)
         for b in self.buckets:
             if b['pending'] != 0 and self.world > 1:
                 # a parameter of this bucket got no gradient this step (should not happen for a fixed

@@ -64,3 +64,22 @@ def test_lsap_bit_exact_vs_scipy(G):
 def test_criterion_golden(G, name):
     from tests.helpers import load_golden
     _assert(G.check_criterion(*load_golden(name), name))
+
+
+def test_attention_forward_is_deterministic():
+    """Same inputs, same bits, run after run, for both bf16 forward kernels (plain and pre-scaled q).  The softmax
+    maxima are taken by inline-asm v_max3_f32 straight from MFMA accumulators; without the explicit hazard fence
+    (attention_bf16.hip: mfma_results_ready) hipcc does not pad that MFMA-write -> VALU-read and ~5 % of the outputs
+    moved by an ulp from run to run, depending on how the wave interleaved with its SIMD partner."""
+    import math
+    from svol_amd import ops
+    torch.manual_seed(0)
+    B, H, L, DH = 1, 8, 2048, 32
+    D = H * DH
+    qkv = torch.randn(B * L, 3 * D, device='cuda').bfloat16()
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    for pm in (0.0, 1.4426950408889634 / math.sqrt(DH)):
+        o0, l0 = ops.attn_fwd(q, k, v, B, H, L, L, DH, None, pm)
+        for _ in range(3):
+            o1, l1 = ops.attn_fwd(q, k, v, B, H, L, L, DH, None, pm)
+            assert torch.equal(o0, o1) and torch.equal(l0, l1)
