@@ -84,8 +84,12 @@ class BucketedGradAllReduce:
         if self.world == 1:
             return
         if self.on_gpu:
-            # the bucket's gradients were produced on the current (compute) stream
+            # the bucket's gradients were produced on the current (compute) stream — or, for the parameters of the
+            # query half, by gradient-sink kernels on the model's side stream (cross_modal_transformer.py)
+            from .modeling import cross_modal_transformer as cmt
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            for s in cmt.side_streams(self.device):
+                self.comm_stream.wait_stream(s)
             with torch.cuda.stream(self.comm_stream):
                 h = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
