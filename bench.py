@@ -97,11 +97,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU fallback)'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # one rank per GPU; SVOL_DIST_BACKEND=gloo lets several ranks share one card for a functional rehearsal of the
+    # N > 1 path on a one-GPU box (RCCL refuses two ranks on the same device)
+    backend = os.environ.get('SVOL_DIST_BACKEND', 'nccl')
+    local_dev = local_rank % torch.cuda.device_count() if backend != 'nccl' else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device('cuda', local_dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
 
     T, P = (32, 196) if a.workload == 'cfg2' else (128, 256)
@@ -170,7 +177,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
     assert final_loss == final_loss, 'loss is NaN'
 
     ms_per_step = elapsed / a.steps * 1e3
