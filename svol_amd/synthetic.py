@@ -225,3 +225,61 @@ def synth_eval_outputs(targets, N: int, T: int, seed: int = 1, noise: float = 0.
         for n in range(tie_every, N, tie_every):
             logits[:, n] = logits[:, n - 1]
     return torch.from_numpy(logits), torch.from_numpy(boxes.astype(np.float32))
+
+
+# ---- ViT feature extractor: HF ``ViTModel`` semantics, random weights ---------------------
+def vit_config(**over) -> SimpleNamespace:
+    """google/vit-base-patch16-224-in21k shape by default (backbone.py:118-122)."""
+    a = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072, image_size=224,
+             patch_size=16, num_channels=3, layer_norm_eps=1e-12)
+    a.update(over)
+    return SimpleNamespace(**a)
+
+
+def vit_param_shapes(cfg) -> "OrderedDict[str, tuple]":
+    """state-dict names / shapes of ``transformers.ViTModel(config, add_pooling_layer=False)`` (transformers 5.x)."""
+    d, f, p, c = cfg.hidden_size, cfg.intermediate_size, cfg.patch_size, cfg.num_channels
+    n_tok = (cfg.image_size // p) ** 2 + 1
+    sh = OrderedDict()
+    sh['embeddings.cls_token'] = (1, 1, d)
+    sh['embeddings.position_embeddings'] = (1, n_tok, d)
+    sh['embeddings.patch_embeddings.projection.weight'] = (d, c, p, p)
+    sh['embeddings.patch_embeddings.projection.bias'] = (d,)
+    for i in range(cfg.num_hidden_layers):
+        pre = f'layers.{i}.'
+        for nm in ('q_proj', 'k_proj', 'v_proj', 'o_proj'):
+            sh[pre + f'attention.{nm}.weight'] = (d, d)
+            sh[pre + f'attention.{nm}.bias'] = (d,)
+        for nm in ('layernorm_before', 'layernorm_after'):
+            sh[pre + nm + '.weight'] = (d,)
+            sh[pre + nm + '.bias'] = (d,)
+        sh[pre + 'mlp.fc1.weight'] = (f, d)
+        sh[pre + 'mlp.fc1.bias'] = (f,)
+        sh[pre + 'mlp.fc2.weight'] = (d, f)
+        sh[pre + 'mlp.fc2.bias'] = (d,)
+    sh['layernorm.weight'] = (d,)
+    sh['layernorm.bias'] = (d,)
+    return sh
+
+
+def synth_vit_state_dict(cfg, seed: int = 1) -> "OrderedDict[str, torch.Tensor]":
+    r = _rs('vit_weights', seed)
+    sd = OrderedDict()
+    for k, shp in vit_param_shapes(cfg).items():
+        if 'layernorm' in k and k.endswith('weight'):
+            v = 1.0 + 0.1 * r.standard_normal(shp)
+        elif k.endswith('bias'):
+            v = 0.05 * r.standard_normal(shp)
+        elif k.endswith('weight') and len(shp) in (2, 4):
+            fan_in = int(np.prod(shp[1:]))
+            v = r.standard_normal(shp) / np.sqrt(fan_in)
+        else:  # cls token, position embeddings
+            v = 0.5 * r.standard_normal(shp)
+        sd[k] = torch.from_numpy(v.astype(np.float32))
+    return sd
+
+
+def synth_images(n: int, cfg, seed: int = 1) -> torch.Tensor:
+    """pixel_values [n, C, H, W] fp32 as the HF feature extractor hands them over (already normalised)."""
+    r = _rs('images', seed)
+    return torch.from_numpy(r.standard_normal((n, cfg.num_channels, cfg.image_size, cfg.image_size)).astype(np.float32))
