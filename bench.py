@@ -82,8 +82,10 @@ def main():
                          'but a captured graph serialises the query-stream / video-stream overlap: measured slower)')
     ap.add_argument('--no-graph', action='store_true', help='accepted for compatibility (eager is the default)')
     ap.add_argument('--batch', type=int, default=None, help='videos per GPU (default: 8, cfg5: 1)')
-    ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg5'],
-                    help='cfg2 = the BASELINE metric workload (default); cfg5 = long-video stress case T=128, P=256 (bf16)')
+    ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg4', 'cfg5'],
+                    help='cfg2 = the BASELINE metric workload (default); cfg4 = cfg2 with the ViT-B/16 frame + sketch feature '
+                         'extractor run online in front of the head (BASELINE configs[3], end-to-end frames/s); '
+                         'cfg5 = long-video stress case T=128, P=256 (bf16)')
     a = ap.parse_args()
 
     import torch
@@ -111,9 +113,11 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
 
-    T, P = (32, 196) if a.workload == 'cfg2' else (128, 256)
-    B = a.batch if a.batch is not None else (8 if a.workload == 'cfg2' else 1)
-    args = syn.cfg2_args('video_matcher') if a.workload == 'cfg2' else syn.head_args(num_frames=T)
+    T, P = (128, 256) if a.workload == 'cfg5' else (32, 196)
+    B = a.batch if a.batch is not None else (1 if a.workload == 'cfg5' else 8)
+    args = syn.head_args(num_frames=T) if a.workload == 'cfg5' else syn.cfg2_args('video_matcher')
+    if a.workload == 'cfg4':
+        args.input_vid_dim = args.input_skch_dim = 768  # ViT-B/16 features (backbone.py:124-125)
     args.compute_dtype = a.dtype
     torch.manual_seed(1)  # reference default seed (configs.py:17): identical initial weights on every rank
     model = build_svanet(args).to(dev).train()
@@ -126,9 +130,20 @@ def main():
     inp = {k: v.to(dev) for k, v in syn.synth_inputs(args, B, T, P, seed=1 + rank).items()}
     tg = syn.synth_targets(B, T, seed=1 + rank)
     wd = crit.weight_dict
+    backbone = None
+    if a.workload == 'cfg4':
+        # frozen, randomly initialised ViT-B/16 extractors (the pretrained weights cannot be downloaded here); synthetic
+        # normalised pixel values; the extractor runs inside the timed step
+        from svol_amd.modeling.backbone import ViTBackbone, ViTExtractor, vit_base_config
+        backbone = ViTBackbone(ViTExtractor(vit_base_config()), ViTExtractor(vit_base_config())).to(dev).eval()
+        g = torch.Generator(device=dev).manual_seed(1 + rank)
+        pix_video = torch.randn((B, T, 3, 224, 224), device=dev, generator=g)
+        pix_sketch = torch.randn((B, 1, 3, 224, 224), device=dev, generator=g)
 
     def step():
         reducer.zero_grad()
+        if backbone is not None:
+            inp['src_sketch'], inp['src_video'] = backbone(pix_sketch, pix_video)
         out = model(inp['src_sketch'], inp['src_sketch_mask'], inp['src_video'], inp['src_video_mask'])
         ld = crit(out, tg)
         loss = sum(ld[k] * wd[k] for k in ld.keys() if k in wd)  # train.py:227-228
@@ -191,7 +206,9 @@ def main():
     fwd = summ.get(('attn_fwd', (B, args.nheads, L, L, dh)))
     bwd = summ.get(('attn_bwd', (B, args.nheads, L, L, dh)))
     attn_fwd_flop = 4.0 * L * L * args.hidden_dim * B          # QK^T + PV  (4 L^2 d per sample)
-    gf_frame = FWD_BWD_GF_PER_FRAME if a.workload == 'cfg2' else 169.3
+    # SURVEY.md §8d table; cfg4 adds the extractor forward: 2*197*(768*768*4 + 2*768*3072)*12 + attention ~ 35.1 GF per
+    # image, (B*T + B) images per B*T frames
+    gf_frame = {'cfg2': FWD_BWD_GF_PER_FRAME, 'cfg5': 169.3, 'cfg4': FWD_BWD_GF_PER_FRAME * 1.24 + 35.1 * (T + 1) / T}[a.workload]
     roof = None
     if fwd and bwd:
         # backward = 2x forward algorithmically (dV, dP, dQ, dK products; the S recompute gets no credit)
@@ -213,8 +230,10 @@ def main():
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': a.dtype, 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[%d]: SVANet head + Hungarian/GIoU criterion, B=%d/GPU, T=%d, P=%d, '
-                                   'd=256, h=8, 6 layers, N=100, video_matcher, Din=512, train mode; step = fwd + '
-                                   'criterion + bwd (+RCCL grad all-reduce) + AdamW' % (1 if a.workload == 'cfg2' else 4, B, T, P),
+                                   'd=256, h=8, 6 layers, N=100, video_matcher, Din=%d, train mode; step = fwd + '
+                                   'criterion + bwd (+RCCL grad all-reduce) + AdamW' % ({'cfg2': 1, 'cfg4': 3, 'cfg5': 4}[a.workload], B, T, P, args.input_vid_dim) + (
+                                       '; ViT-B/16 extractor (random init, frozen) on all %d frames + %d sketches inside the step' % (B * T, B)
+                                       if a.workload == 'cfg4' else ''),
                        'global_batch': B * world, 'parallelism': f'dp{world}'},
             'final_loss': final_loss,
             'launch_mode': 'hipGraph replay (whole step captured)' if use_graph else 'eager',

@@ -213,6 +213,21 @@ int svol_eval_ap(const double* pred_box, const double* pred_score, const int32_t
                  int32_t n_thresholds, int32_t* ws_order, unsigned char* ws_u8, double* ws_f64, double* ap, int64_t n_pred,
                  int64_t n_gt, int64_t n_groups, void* stream);
 
+/* ---- ViT-B/16 feature extractor pieces (the Hugging Face ViTModel the reference's ViT backbone calls,
+ * lib/modeling/backbone.py:30,48; inference only) ----------------------------------------------------------------
+ * svol_patchify: pixel_values [n,C,H,W] fp32 -> out [n*(H/p)*(W/p), C*p*p] (dtype), the im2col of the stride-p patch
+ *   convolution in the conv weight's (c, ky, kx) order: the patch embedding is then svol_gemm_nt with W [d, C*p*p]. */
+int svol_patchify(const float* pixel_values, void* out, int64_t n, int64_t C, int64_t H, int64_t W, int64_t p, int dtype,
+                  void* stream);
+/* tokens[img, 0] = cls + pos[0]; tokens[img, 1+j] = patch_proj[img*P + j] + pos[1+j]  (patch_proj, cls, pos fp32).
+ * x32 [n, P+1, D] fp32 residual stream; x (dtype, may be NULL) its compute-dtype copy. */
+int svol_vit_embed(const float* patch_proj, const float* cls_token, const float* pos_embed, float* x32, void* x, int64_t n,
+                   int64_t P, int64_t D, int dtype, void* stream);
+/* softmax(q k^T * scale) v for n_seq independent SHORT sequences (L <= 256), H heads of dh = 32 or 64, bf16, forward only;
+ * layouts as svol_attn_fwd (rows = tokens, head h in columns [h*dh, (h+1)*dh)). */
+int svol_attn_small_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo,
+                        int64_t n_seq, int64_t H, int64_t L, int64_t dh, float scale, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

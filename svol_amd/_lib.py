@@ -35,6 +35,9 @@ SIGNATURES = {
     'svol_postprocess': [_p, _p, _p, _i64, _i64, _i64, _p],
     'svol_eval_max_iou': [_p, _p, _p, _p, _p, _p, _i64, _int, _p],
     'svol_eval_ap': [_p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _p, _i64, _i64, _i64, _p],
+    'svol_patchify': [_p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p],
+    'svol_vit_embed': [_p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p],
+    'svol_attn_small_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _f32, _int, _p],
     'svol_posenc_sine': [_p, _p, _i64, _i64, _i64, _int, _p],
     'svol_attn_ws_bytes': [_i64, _i64, _i64, _i64, _i64],
     'svol_attn_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _p, _i64,

@@ -2,9 +2,9 @@
 
 ``build_model(args)`` / ``SketchLocalizationModel.forward(src_sketch, src_video, src_sketch_mask,
 src_video_mask)`` keep the reference's signatures and the ``backbone.`` / ``head.`` state-dict
-prefixes.  The CNN / ViT feature extractors are outside this round's scope:
-``--backbone features`` plugs pre-extracted features in at the measured boundary (SURVEY.md D3);
-asking for ``resnet`` / ``vit`` raises instead of silently running something else.
+prefixes.  ``--backbone features`` plugs pre-extracted features in at the measured boundary (SURVEY.md D3);
+``--backbone vit`` runs the ViT-B/16 extractor of ``backbone.py`` on the device for every frame and the sketch
+(SURVEY.md §8 f1); the torchvision ResNets (f4) raise instead of silently running something else.
 """
 from __future__ import annotations
 
@@ -30,9 +30,16 @@ def build_backbone(args):
         args.input_vid_dim = getattr(args, 'input_vid_dim', 512)
         args.input_skch_dim = getattr(args, 'input_skch_dim', 512)
         return FeatureBackbone()
+    if 'vit' in args.backbone:  # backbone.py:117-132: ViT-B/16 for frames and sketch, 768-wide features
+        from .backbone import ViTBackbone, ViTExtractor, vit_base_config
+        args.input_vid_dim = 768
+        args.input_skch_dim = 768
+        # the pretrained google/vit-base-patch16-224-in21k weights are loaded by the caller
+        # (ViTExtractor.load_hf_state_dict); nothing is downloaded here
+        return ViTBackbone(ViTExtractor(vit_base_config()), ViTExtractor(vit_base_config()))
     raise NotImplementedError(
-        f"backbone '{args.backbone}' (torchvision ResNet-18/34 or HF ViT-B/16 with downloaded weights) is not part "
-        "of the MI355X hot-path build yet (SURVEY.md §8 f1/f4); use --backbone features with pre-extracted features")
+        f"backbone '{args.backbone}' (torchvision ResNet-18/34 with downloaded weights) is not part of the MI355X "
+        "build yet (SURVEY.md §8 f4); use --backbone features with pre-extracted features, or --backbone vit")
 
 
 class SketchLocalizationModel(nn.Module):
