@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Post-processing + evaluation: device path vs the CPU oracle (= the reference's numpy code path,
-proven equal by the goldens) on a synthetic validation set.   python tools/bench_posteval.py [videos]"""
+proven equal by the goldens) on a synthetic validation set.  Lives under tests/ because it runs the oracle.
+    python tests/bench_posteval.py [videos]"""
 import copy
 import os
 import sys
@@ -9,7 +10,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from oracle import posteval as O  # noqa: E402  (tools/ is test infrastructure, like tests/)
+from oracle import posteval as O  # noqa: E402
 from svol_amd import postprocess as PP  # noqa: E402
 from svol_amd import synthetic as syn  # noqa: E402
 from svol_amd.evaluate import eval as E  # noqa: E402
