@@ -1,4 +1,5 @@
-// bf16 NT GEMM with N = 256 and deep K (fc2: K = 2048, the MLP / q|k dX products: K = 2048 / 512), gfx950.
+// bf16 NT GEMM with N a multiple of 256 and deep K (fc2: K = 2048, the MLP / q|k dX products: K = 2048 / 512; the ViT
+// extractor's projections: K = 768 / 3072, N = 768 ... 3072), gfx950.
 //
 // With a 128x128 tiling these launches stream A twice (two column tiles) and re-stage a W tile per 128 rows:
 // 812 MB through the L2 -> LDS path for fc2 at B = 8, which is what bounds them (~9.5 TB/s measured), on a
@@ -21,7 +22,7 @@ struct N256Args {
     const bf16_t* A; const bf16_t* W; void* C;
     const float* bias; const float* res;
     int64_t lda, ldw, ldc, ldr;
-    int M, K;
+    int M, K, act, nrt;  // nrt: row tiles per column group (padded to a multiple of 8 when there are several groups)
 };
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -67,13 +68,18 @@ __device__ __forceinline__ void gemm_n256_body(const N256Args& p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fq = lane >> 4;
-    const int bm = blockIdx.x * BM;
+    // 1-D grid, row tile fastest: the column groups of one row tile land on the same XCD (ids differ by a multiple of 8)
+    // and share its L2 for the A rows they all read
+    const int rt = blockIdx.x % p.nrt, cg = blockIdx.x / p.nrt;
+    const int bm = rt * BM;
+    if (bm >= p.M) return;  // padding workgroups of the XCD-aligned grid
     const int rows = min(BM, p.M - bm);
+    const int bn = cg * BN;
 
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.A + (int64_t)bm * p.lda), 0, (int)((((int64_t)rows - 1) * p.lda + p.K) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rW =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)((((int64_t)BN - 1) * p.ldw + p.K) * 2), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)bn * p.ldw), 0, (int)((((int64_t)BN - 1) * p.ldw + p.K) * 2), 0x00020000);
     // DMA: one instruction = 16 image rows x 4 chunks.  A: instructions 2w, 2w+1; W: 4w .. 4w+3.
     // image row rho of W holds global row  (rho/128)*128 + wcol((rho%128)/16, rho%16)
     int voffA[2], voffW[4];
@@ -152,7 +158,7 @@ __device__ __forceinline__ void gemm_n256_body(const N256Args& p) {
         if (m >= p.M) continue;
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
-            const int n0 = wn * 128 + pr * 32 + fq * 8;
+            const int n0 = bn + wn * 128 + pr * 32 + fq * 8;
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = acc[2 * pr + (e >> 2)][mt][e & 3];
@@ -171,6 +177,10 @@ __device__ __forceinline__ void gemm_n256_body(const N256Args& p) {
                 *reinterpret_cast<f32x4*>(C) = f32x4{v[0], v[1], v[2], v[3]};
                 *reinterpret_cast<f32x4*>(C + 4) = f32x4{v[4], v[5], v[6], v[7]};
             } else {
+                if (p.act == SVOL_ACT_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+                }
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
@@ -190,15 +200,20 @@ int svol_gemm_n256_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, 
                         void* pre, const void* res, int64_t ldr, int out_f32, int epi, const float* colscale, int64_t M,
                         int64_t N, int64_t K, hipStream_t s) {
     static const bool off = getenv("SVOL_GEMM_NO_N256") != nullptr;
-    if (off || N != BN || K % BK || K < 512 || M < 4096) return SVOL_E_UNSUPPORTED;
-    if (epi != 0 || act != SVOL_ACT_NONE || pre || colscale) return SVOL_E_UNSUPPORTED;
+    if (off || N % BN || K % BK || K < 512 || M < 4096) return SVOL_E_UNSUPPORTED;
+    if (epi != 0 || pre || colscale) return SVOL_E_UNSUPPORTED;
+    if (act != SVOL_ACT_NONE && (act != SVOL_ACT_GELU || out_f32)) return SVOL_E_UNSUPPORTED;
     if (res && !out_f32) return SVOL_E_UNSUPPORTED;
     auto al16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
     if (lda % 8 || ldw % 8 || !al16(A) || !al16(W) || !al16(C)) return SVOL_E_UNSUPPORTED;
     if (out_f32 ? (ldc % 4 || (res && (ldr % 4 || !al16(res)))) : (ldc % 8 != 0)) return SVOL_E_UNSUPPORTED;
     if ((int64_t)BM * lda * 2 >= (1ll << 31) || (int64_t)BN * ldw * 2 >= (1ll << 31)) return SVOL_E_UNSUPPORTED;
-    N256Args p{(const bf16_t*)A, (const bf16_t*)W, C, bias, (const float*)res, lda, ldw, ldc, ldr, (int)M, (int)K};
-    dim3 grid((unsigned)((M + BM - 1) / BM));
+    const int64_t ncg = N / BN;
+    int64_t nrt = (M + BM - 1) / BM;
+    if (ncg > 1) nrt = (nrt + 7) / 8 * 8;
+    if (nrt * ncg > (1ll << 30)) return SVOL_E_UNSUPPORTED;
+    N256Args p{(const bf16_t*)A, (const bf16_t*)W, C, bias, (const float*)res, lda, ldw, ldc, ldr, (int)M, (int)K, act, (int)nrt};
+    dim3 grid((unsigned)(nrt * ncg));
     if (out_f32) hipLaunchKernelGGL(gemm_n256_bf16_f32, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(gemm_n256_bf16_b16, grid, dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;

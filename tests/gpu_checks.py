@@ -80,13 +80,17 @@ def check_gemm_nt():
         out = ops.gemm_nt(A.to(DEV), Bm.to(DEV), bias.to(DEV), residual=R.to(DEV), out_f32=True)
         ref = A.double() @ Bm.double().t() + bias.double() + R.double()
         res[f'gemm_nt/{dt}/out_f32'] = (rel_err(out, ref), 2e-5 if dt == torch.float32 else 1e-5)
-        for (M, N, K) in [(4133, 256, 1024), (4099, 256, 256)]:  # tall-M fp32-stream variants (ragged M)
+        for (M, N, K) in [(4133, 256, 1024), (4099, 256, 256), (4200, 768, 768)]:  # tall-M fp32-stream variants (ragged M)
             A, Bm = _rnd((M, K), dt, 17), _rnd((N, K), dt, 18, 1.0 / math.sqrt(K))
             R, bias = _rnd((M, N), torch.float32, 19), _rnd((N,), torch.float32, 20)
             out = ops.gemm_nt(A.to(DEV), Bm.to(DEV), bias.to(DEV), residual=R.to(DEV), out_f32=True)
             ref = A.double() @ Bm.double().t() + bias.double() + R.double()
             res[f'gemm_nt/{dt}/out_f32/{M}x{N}x{K}'] = (rel_err(out, ref), 2e-5 if dt == torch.float32 else 1e-5)
         res[f'gemm_nt/{dt}/out_f32_dtype'] = (0.0 if out.dtype == torch.float32 else 1.0, 0.5)
+        # wide-N deep-K tile kernel with the GELU epilogue (the ViT extractor's fc1)
+        A, Bm, bias = _rnd((4300, 768), dt, 21), _rnd((1024, 768), dt, 22, 1.0 / math.sqrt(768)), _rnd((1024,), torch.float32, 23)
+        out = ops.gemm_nt(A.to(DEV), Bm.to(DEV), bias.to(DEV), ops.ACT_GELU)
+        res[f'gemm_nt/{dt}/wide_gelu'] = (rel_err(out, _act(A.double() @ Bm.double().t() + bias.double(), ops.ACT_GELU)), TOL[dt])
         # skinny-M path (bf16: intra-workgroup split-K kernel): every epilogue, ragged M, deep K, fp32 stream, colscale
         for (M, N, K) in [(333, 128, 256), (800, 256, 2048), (31, 64, 512)]:
             A = _rnd((M, K), dt, 11)
