@@ -79,6 +79,12 @@ int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, co
 int svol_gemm_nt_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                        const void* pre, int64_t ldp, float* colsum, int64_t M, int64_t N, int64_t K, int dtype,
                        void* stream);
+/* The same step for either MLP activation: C = (A * B^T) .* act'(aux), act = SVOL_ACT_GELU (aux = the saved
+ * PRE-activation) or SVOL_ACT_RELU (aux = the saved POST-activation, relu' = [aux > 0]: the F.relu FFN of the
+ * enc/dec Transformer, transformer.py:191,245). */
+int svol_gemm_nt_dact(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                      const void* aux, int64_t ldaux, int act, float* colsum, int64_t M, int64_t N, int64_t K,
+                      int dtype, void* stream);
 /* dW[N,K] (fp32, ld = ldc) (+)= A[Mc,N]^T * B[Mc,K]   (contraction over the Mc rows; weight gradient).
  * The output is accumulated with fp32 atomics: the caller zeroes C first unless it wants accumulation.
  * colsum (fp32 [N], may be NULL, caller zeroes) += column sums of A — the bias gradient, computed on the
@@ -223,6 +229,13 @@ int svol_patchify(const float* pixel_values, void* out, int64_t n, int64_t C, in
  * x32 [n, P+1, D] fp32 residual stream; x (dtype, may be NULL) its compute-dtype copy. */
 int svol_vit_embed(const float* patch_proj, const float* cls_token, const float* pos_embed, float* x32, void* x, int64_t n,
                    int64_t P, int64_t D, int dtype, void* stream);
+/* att[B,Lq,Lk] (fp32) = 1/H * sum_h softmax_l(q_h k_h^T * scale + kbias): the head-averaged attention weights that
+ * nn.MultiheadAttention returns with need_weights=True and the reference's TransformerDecoder stacks per layer
+ * (transformer.py:139-152, 258-262).  Recomputed from q, k (layouts as svol_attn_fwd, q_premul as there) and the
+ * lse2 [B,H,Lq] that svol_attn_fwd wrote; dh in {8,16,32,64}.  No gradient. */
+int svol_attn_weights_mean(const void* q, int64_t ldq, const void* k, int64_t ldk, const float* lse2, const float* kbias,
+                           float* att, int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t dh, float scale,
+                           float q_premul, int dtype, void* stream);
 /* softmax(q k^T * scale) v for n_seq independent SHORT sequences (L <= 256), H heads of dh = 32 or 64, bf16, forward only;
  * layouts as svol_attn_fwd (rows = tokens, head h in columns [h*dh, (h+1)*dh)). */
 int svol_attn_small_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo,

@@ -26,6 +26,7 @@ SIGNATURES = {
     'svol_gemm_nt': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _int, _p, _i64, _p, _i64, _int, _i64, _i64, _i64,
                      _int, _p],
     'svol_gemm_nt_dgelu': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p],
+    'svol_gemm_nt_dact': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _int, _p, _i64, _i64, _i64, _int, _p],
     'svol_gemm_tn': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p],
     'svol_colsum': [_p, _i64, _p, _i64, _i64, _int, _p],
     'svol_act_bwd': [_p, _p, _p, _int, _i64, _int, _p],
@@ -37,6 +38,7 @@ SIGNATURES = {
     'svol_eval_ap': [_p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _p, _i64, _i64, _i64, _p],
     'svol_patchify': [_p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p],
     'svol_vit_embed': [_p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p],
+    'svol_attn_weights_mean': [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _int, _p],
     'svol_attn_small_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _f32, _int, _p],
     'svol_posenc_sine': [_p, _p, _i64, _i64, _i64, _int, _p],
     'svol_attn_ws_bytes': [_i64, _i64, _i64, _i64, _i64],

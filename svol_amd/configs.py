@@ -9,7 +9,9 @@ reference command line parses unchanged.  Differences, all additive:
 * ``--compute_dtype {bf16,fp32}`` selects the kernel element type (the
   reference's only precision knob is apex ``--opt-level``; ``O0`` = fp32);
 * ``--backbone features`` feeds pre-extracted frame / sketch features straight
-  to the head (the measured boundary).
+  to the head (the measured boundary, SURVEY.md D3);
+* ``--enc_layers --dec_layers --mode --feat_dim`` and ``--sketch_head svanet_variants``: what the reference's enc/dec
+  heads read but its parser never defines.
 """
 from __future__ import annotations
 
@@ -68,7 +70,7 @@ _OPTIONS = [
     (('--tight_frame_sampling',), dict(action='store_true')),
     (('--aspect_ratio_grouping',), dict(type=bool, default=False)),
     # model
-    (('--sketch_head',), dict(type=str, default='svanet', choices=['svanet', 'sketch_detr'])),
+    (('--sketch_head',), dict(type=str, default='svanet', choices=['svanet', 'sketch_detr', 'svanet_variants'])),
     (('--backbone',), dict(type=str, default='vit', choices=['vit', 'resnet', 's3d', 'features'])),
     (('--hidden_dim',), dict(type=int, default=256)),
     (('--nheads',), dict(type=int, default=8)),
@@ -105,6 +107,13 @@ _EXTRA = [
                                 help='element type of the HIP kernels (fp32 accumulate either way)')),
     (('--input_vid_dim',), dict(type=int, default=512, help='feature width with --backbone features')),
     (('--input_skch_dim',), dict(type=int, default=512, help='feature width with --backbone features')),
+    # the enc/dec Transformer heads (sketch_detr, svanet_variants) read these; the reference never defines them, which is
+    # why its own --sketch_head sketch_detr cannot be built from its option surface
+    (('--enc_layers',), dict(type=int, default=6)),
+    (('--dec_layers',), dict(type=int, default=6)),
+    (('--mode',), dict(type=str, default='append_to_seq', choices=['concat_to_seq', 'append_to_seq', 'concat_to_qry'],
+                       help='how svanet_variants presents the sketch to the enc/dec Transformer')),
+    (('--feat_dim',), dict(type=int, default=512, help='feature width of the enc/dec heads (one width for sketch and video)')),
 ]
 
 

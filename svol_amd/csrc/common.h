@@ -94,6 +94,12 @@ __device__ __forceinline__ float dgelu_fast(float x) {
     return fmaf(x * 0.39894228040143267794f, E, Phi);
 }
 
+// derivative of the MLP activation for the fused backward epilogue: aux is the PRE-activation for GELU and the
+// POST-activation for ReLU (relu'(pre) = [hid > 0])
+__device__ __forceinline__ float dact_fast(float aux, int act) {
+    return act == SVOL_ACT_RELU ? (aux > 0.f ? 1.f : 0.f) : dgelu_fast(aux);
+}
+
 // exact (erf) GELU and derivative
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float dgelu_f(float x) {

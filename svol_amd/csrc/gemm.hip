@@ -453,25 +453,31 @@ int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, co
     return SVOL_OK;
 }
 
-int svol_gemm_nt_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* pre,
-                       int64_t ldp, float* colsum, int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
-    if (!A || !B || !C || !pre || M < 0 || N < 0 || K <= 0) return SVOL_E_INVALID;
+int svol_gemm_nt_dact(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* aux,
+                      int64_t ldaux, int act, float* colsum, int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
+    if (!A || !B || !C || !aux || M < 0 || N < 0 || K <= 0) return SVOL_E_INVALID;
+    if (act != SVOL_ACT_GELU && act != SVOL_ACT_RELU) return SVOL_E_INVALID;
     if (M == 0 || N == 0) return SVOL_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SVOL_BF16) {
-        const int rc = svol_gemm_nt_bf16_fast(A, lda, B, ldb, C, ldc, nullptr, SVOL_ACT_NONE, nullptr, 0, nullptr, 0, 0, pre, ldp,
-                                              colsum, 1, nullptr, M, N, K, s);
+        const int rc = svol_gemm_nt_bf16_fast(A, lda, B, ldb, C, ldc, nullptr, act, nullptr, 0, nullptr, 0, 0, aux, ldaux, colsum, 1,
+                                              nullptr, M, N, K, s);
         if (rc != SVOL_E_UNSUPPORTED) return rc;
     }
-    // generic composition (f32 / odd shapes): GEMM, then dpre = dh * gelu'(pre) in place, then column sums
-    if (ldc != N || ldp != N) return SVOL_E_UNSUPPORTED;
+    // generic composition (f32 / odd shapes): GEMM, then dpre = dh * act'(aux) in place, then column sums
+    if (ldc != N || ldaux != N) return SVOL_E_UNSUPPORTED;
     int rc = svol_gemm_nt(A, lda, nullptr, 0, B, ldb, C, ldc, nullptr, nullptr, SVOL_ACT_NONE, nullptr, 0, nullptr, 0, 0, M, N, K,
                           dtype, stream);
     if (rc) return rc;
-    rc = svol_act_bwd(C, pre, C, SVOL_ACT_GELU, M * N, dtype, stream);
+    rc = svol_act_bwd(C, aux, C, act, M * N, dtype, stream);
     if (rc) return rc;
     if (colsum) rc = svol_colsum(C, ldc, colsum, M, N, dtype, stream);
     return rc;
+}
+
+int svol_gemm_nt_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* pre,
+                       int64_t ldp, float* colsum, int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
+    return svol_gemm_nt_dact(A, lda, B, ldb, C, ldc, pre, ldp, SVOL_ACT_GELU, colsum, M, N, K, dtype, stream);
 }
 
 int svol_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum, int64_t Mc,

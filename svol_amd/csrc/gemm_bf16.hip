@@ -199,10 +199,10 @@ __device__ __forceinline__ void gemm_nt_bf16_body(const FastArgs& p) {
                     if (colv) {
                         const f32x4 a = Out4<bf16_t>::load(p.aux + (int64_t)m * p.ldaux + ncol);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= dgelu_fast(a[e]);
+                        for (int e = 0; e < 4; ++e) v[e] *= dact_fast(a[e], p.act);
                     } else {
                         for (int e = 0; e < 4; ++e)
-                            v[e] = (ncol + e < p.N) ? v[e] * dgelu_fast((float)p.aux[(int64_t)m * p.ldaux + ncol + e]) : 0.f;
+                            v[e] = (ncol + e < p.N) ? v[e] * dact_fast((float)p.aux[(int64_t)m * p.ldaux + ncol + e], p.act) : 0.f;
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) csum[e] += v[e];
@@ -342,7 +342,7 @@ __device__ __forceinline__ void gemm_nt_bf16_skinny_body(const FastArgs& p) {
             const bf16_t* X = p.aux + (int64_t)m * p.ldaux + n0;
             const f32x4 x0 = Out4<bf16_t>::load(X), x1 = Out4<bf16_t>::load(X + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] *= dgelu_fast(x0[e]); v[4 + e] *= dgelu_fast(x1[e]); }
+            for (int e = 0; e < 4; ++e) { v[e] *= dact_fast(x0[e], p.act); v[4 + e] *= dact_fast(x1[e], p.act); }
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = 0.f;

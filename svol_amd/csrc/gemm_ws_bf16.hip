@@ -225,6 +225,11 @@ __device__ __forceinline__ void gemm_ws_body(const WsArgs& p) {
                     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[hf][e] = gelu_fast(v[hf][e]);
+                } else if (p.act == SVOL_ACT_RELU) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[hf][e] = fmaxf(v[hf][e], 0.f);
                 }
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
@@ -284,7 +289,7 @@ __device__ __forceinline__ void gemm_ws_body(const WsArgs& p) {
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float d = v[hf][e] * dgelu_fast((float)a8[e]);  // rows past M: acc = 0 and aux = 0 (zero-filled slabs)
+                    float d = v[hf][e] * dact_fast((float)a8[e], p.act);  // rows past M: acc = 0 and aux = 0 (zero-filled slabs)
                     d = ok ? d : 0.f;
                     csum[hf][e] += d;
                     o[e] = (bf16_t)d;
@@ -331,7 +336,7 @@ int svol_gemm_ws_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, vo
         if (!res || act != SVOL_ACT_NONE || pre || colscale) return SVOL_E_UNSUPPORTED;
         mode = 1;
     } else {
-        if (res || (act != SVOL_ACT_NONE && act != SVOL_ACT_GELU)) return SVOL_E_UNSUPPORTED;
+        if (res || (act != SVOL_ACT_NONE && act != SVOL_ACT_GELU && act != SVOL_ACT_RELU)) return SVOL_E_UNSUPPORTED;
         mode = 0;
     }
     auto al16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };

@@ -61,6 +61,12 @@ def build_model(args):
     backbone = build_backbone(args)
     if args.sketch_head == 'svanet':
         head = build_svanet(args)
-    else:  # 'sketch_detr' cannot be built from the reference's own option surface
+    elif args.sketch_head == 'sketch_detr':  # model.py:35-36; needs the build's --enc_layers/--dec_layers/--mode/--feat_dim
+        from .sketch_detr import build_sketchdetr
+        head = build_sketchdetr(args)
+    elif args.sketch_head == 'svanet_variants':  # the reference's svanet_variants.py has no dispatch entry of its own
+        from .svanet_variants import build_svanet as build_svanet_variants
+        head = build_svanet_variants(args)
+    else:
         raise NotImplementedError
     return SketchLocalizationModel(backbone, head)

@@ -1,0 +1,274 @@
+"""Encoder/decoder ``Transformer`` (DETR style) on the MI355X kernels — SURVEY.md §8 f2.
+
+Mirrors the reference's module tree (lib/modeling/transformer.py:18-333): same constructor signatures, same
+child names and state-dict keys (``encoder.layers.{i}.self_attn.in_proj_weight`` … ``decoder.norm.bias``), the
+same construction order (so a seed gives the same initial weights) and the same ``forward(src, mask,
+query_embed, pos_embed) -> (hs, memory, att_weights)`` contract.  The ``nn.MultiheadAttention`` / ``nn.Linear`` /
+``nn.LayerNorm`` children are parameter containers only; the arithmetic goes through ``svol_amd.ops``, i.e. the
+same fused blocks as the cross-modal transformer:
+
+  encoder layer, post-norm (:183-194)   AttnLNFn (q = k = x + pos, v = x, key_padding_mask, out_proj + residual, norm1)
+                                        MLPLNFn  (linear1 + ReLU, linear2 + residual, norm2)
+  decoder layer, post-norm (:237-250)   AttnLNFn (query self-attention, norm1), AttnLNFn (query -> memory, norm2,
+                                        optionally the head-averaged weights), MLPLNFn (norm3)
+  pre-norm variants (:196-208, :265-283) LNStreamFn opens each block, AttnLNFn / MLPLNFn run without their norm and
+                                        hand the fp32 sum on; encoder.norm closes the encoder
+  decoder.norm on every layer's output  LNStreamFn (fp32), shared parameters (:139-147)
+
+The residual stream is fp32 throughout (as in the cross-modal transformer); GEMM / attention operands are in the
+compute dtype.  Differences from the reference, all documented in DESIGN.md:
+
+* dropout: the kernels have no attention-probability / residual / FFN dropout.  ``dropout > 0`` is accepted (the
+  reference default is 0.1) but a TRAINING-mode forward then raises; ``eval()`` or ``dropout=0`` run.
+* activation: ``relu`` (the only one ``build_transformer`` can select, :312-322) and ``gelu``; ``glu`` raises.
+* ``att_weights`` carry no gradient (every consumer in the reference discards them: sketch_detr.py:62,
+  svanet_variants.py:107-116); ``need_weights=False`` skips computing them.
+* attn_mask / tgt_mask / memory_mask / tgt_key_padding_mask are never passed by the reference's callers and are
+  not supported (key padding masks are).
+"""
+from __future__ import annotations
+
+import copy
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .. import ops
+
+_DTYPES = {'bf16': torch.bfloat16, 'fp32': torch.float32, torch.bfloat16: torch.bfloat16,
+           torch.float32: torch.float32}
+
+
+def _act_code(activation: str) -> int:
+    """transformer.py:325-333"""
+    if activation == 'relu':
+        return ops.ACT_RELU
+    if activation == 'gelu':
+        return ops.ACT_GELU
+    if activation == 'glu':
+        raise NotImplementedError('glu halves the FFN width; not available on the HIP path')
+    raise RuntimeError(f'activation should be relu/gelu, not {activation}.')
+
+
+_n = lambda m: (m.weight, m.bias)
+_mha = lambda m: (m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias)
+
+
+def _check_dropout(mod):
+    if mod.training and mod.dropout_p > 0.0:
+        raise NotImplementedError(
+            f'{type(mod).__name__}: dropout={mod.dropout_p} in training mode — the HIP attention / FFN blocks have no '
+            'dropout; build with dropout=0.0 (--dropout 0) or call .eval()')
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation='relu', normalize_before=False):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.act = _act_code(activation)
+        self.normalize_before = normalize_before
+        self.nhead, self.dropout_p = nhead, float(dropout)
+
+    def _ffn(self, x32, x, norm, pos_out):
+        g, b = _n(norm) if norm is not None else (None, None)
+        return ops.mlp_ln(x32, x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, g, b,
+                          pos_out, self.act)
+
+    def forward_post(self, state, pos, kbias):
+        """state = (x32, x, x + pos) -> same triple (transformer.py:175-194)."""
+        x32, x, xpos = state
+        y32, y = ops.self_attn_ln(x32, x, xpos, *_mha(self.self_attn), *_n(self.norm1), None, self.nhead, kbias)
+        return self._ffn(y32, y, self.norm2, pos)
+
+    def forward_pre(self, x32, pos, kbias):
+        """x32 -> x32 (transformer.py:196-208)."""
+        dt = pos.dtype
+        y, ypos = ops.ln_stream(x32, *_n(self.norm1), pos, dt)
+        s32 = ops.self_attn_ln(x32, y, ypos, *_mha(self.self_attn), None, None, None, self.nhead, kbias)
+        y2 = ops.ln_stream(s32, *_n(self.norm2), None, dt)
+        return self._ffn(s32, y2, None, None)
+
+    def forward(self, state, pos, kbias):
+        _check_dropout(self)
+        return self.forward_pre(state, pos, kbias) if self.normalize_before else self.forward_post(state, pos, kbias)
+
+
+class TransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation='relu', normalize_before=False):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.act = _act_code(activation)
+        self.normalize_before = normalize_before
+        self.nhead, self.dropout_p = nhead, float(dropout)
+
+    def _ffn(self, x32, x, norm, pos_out):
+        g, b = _n(norm) if norm is not None else (None, None)
+        return ops.mlp_ln(x32, x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, g, b,
+                          pos_out, self.act)
+
+    def forward_post(self, state, mem, mempos, qpos, kbias, need_weights):
+        """state = (t32, t, t + query_pos) -> (same triple, att | None)   (transformer.py:229-250)."""
+        t32, t, tpos = state
+        a32, a, apos = ops.self_attn_ln(t32, t, tpos, *_mha(self.self_attn), *_n(self.norm1), qpos, self.nhead)
+        r = ops.cross_attn_ln(a32, a, apos, mempos, mem, *_mha(self.multihead_attn), *_n(self.norm2), None, self.nhead,
+                              kbias, need_weights)
+        c32, c = r[0], r[1]
+        att = r[2] if need_weights else None
+        return self._ffn(c32, c, self.norm3, qpos), att
+
+    def forward_pre(self, t32, mem, mempos, qpos, kbias, need_weights):
+        """t32 -> (t32, att | None)   (transformer.py:252-283)."""
+        dt = mem.dtype
+        y, ypos = ops.ln_stream(t32, *_n(self.norm1), qpos, dt)
+        s32 = ops.self_attn_ln(t32, y, ypos, *_mha(self.self_attn), None, None, None, self.nhead)
+        y2, y2pos = ops.ln_stream(s32, *_n(self.norm2), qpos, dt)
+        r = ops.cross_attn_ln(s32, y2, y2pos, mempos, mem, *_mha(self.multihead_attn), None, None, None, self.nhead,
+                              kbias, need_weights)
+        c32, att = (r[0], r[1]) if need_weights else (r, None)
+        y3 = ops.ln_stream(c32, *_n(self.norm3), None, dt)
+        return self._ffn(c32, y3, None, None), att
+
+    def forward(self, state, mem, mempos, qpos, kbias, need_weights=False):
+        _check_dropout(self)
+        if self.normalize_before:
+            return self.forward_pre(state, mem, mempos, qpos, kbias, need_weights)
+        return self.forward_post(state, mem, mempos, qpos, kbias, need_weights)
+
+
+def _get_clones(module, N):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers, norm=None, return_intermediate=False):
+        super().__init__()
+        self.layers = _get_clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+        if return_intermediate:  # never requested by the reference's builder (transformer.py:27-29)
+            raise NotImplementedError('encoder return_intermediate')
+
+    def forward(self, src32, pos, kbias):
+        """src32 [B,L,d] fp32, pos [B,L,d] compute dtype, kbias [B,L] fp32 additive key mask or None ->
+        (memory32 [B,L,d] fp32, memory, memory + pos) — what the decoder's cross-attention reads."""
+        dt = pos.dtype
+        pre = len(self.layers) > 0 and self.layers[0].normalize_before
+        if pre:
+            x32 = src32
+            for layer in self.layers:
+                x32 = layer(x32, pos, kbias)
+            if self.norm is not None:  # the builder gives the pre-norm encoder a closing norm (:26)
+                return ops.ln_stream(x32, *_n(self.norm), pos, dt, True)
+            x = ops.cast_ag(x32, dt)
+            return x32, x, x + pos
+        x = ops.cast_ag(src32, dt)
+        state = (src32, x, x + pos)  # layer 0's q = k = src + pos (:183); later layers get it from the norm2 epilogue
+        for layer in self.layers:
+            state = layer(state, pos, kbias)
+        if self.norm is not None:
+            return ops.ln_stream(state[0], *_n(self.norm), pos, dt, True)
+        return state
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, decoder_layer, num_layers, norm=None, return_intermediate=False):
+        super().__init__()
+        self.layers = _get_clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+        self.return_intermediate = return_intermediate
+
+    def forward(self, mem, mempos, qpos, kbias, need_weights=True):
+        """mem / mempos [B,L,d] compute dtype, qpos [N,d] or [B,N,d] compute dtype ->
+        (hs [n,B,N,d] fp32, att [n,B,N,L] fp32 | None); n = num_layers with return_intermediate, else 1 (:116-152)."""
+        B = mem.shape[0]
+        dt = mem.dtype
+        N, d = qpos.shape[-2:]
+        qfull = qpos if qpos.dim() == 3 else qpos.unsqueeze(0).expand(B, -1, -1).contiguous()
+        t32 = torch.zeros((B, N, d), dtype=torch.float32, device=mem.device)  # tgt = zeros_like(query_embed), :64
+        pre = len(self.layers) > 0 and self.layers[0].normalize_before
+        state = t32 if pre else (t32, torch.zeros((B, N, d), dtype=dt, device=mem.device), qfull)
+        inter, atts = [], []
+        for layer in self.layers:
+            state, att = layer(state, mem, mempos, qpos, kbias, need_weights and self.return_intermediate)
+            if self.return_intermediate:
+                o32 = state if pre else state[0]
+                inter.append(ops.ln_stream(o32, *_n(self.norm), None, torch.float32) if self.norm is not None else o32)
+                atts.append(att)
+        if self.return_intermediate:
+            return torch.stack(inter), (torch.stack(atts) if need_weights else None)
+        o32 = state if pre else state[0]
+        if self.norm is not None:
+            o32 = ops.ln_stream(o32, *_n(self.norm), None, torch.float32)
+        return o32.unsqueeze(0), None
+
+
+class Transformer(nn.Module):
+    def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=2048,
+                 dropout=0.1, activation='relu', normalize_before=False, return_intermediate_dec=False,
+                 compute_dtype='bf16'):
+        super().__init__()
+        encoder_layer = TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout, activation, normalize_before)
+        encoder_norm = nn.LayerNorm(d_model) if normalize_before else None
+        self.encoder = TransformerEncoder(encoder_layer, num_encoder_layers, encoder_norm)
+        decoder_layer = TransformerDecoderLayer(d_model, nhead, dim_feedforward, dropout, activation, normalize_before)
+        decoder_norm = nn.LayerNorm(d_model)
+        self.decoder = TransformerDecoder(decoder_layer, num_decoder_layers, decoder_norm,
+                                          return_intermediate=return_intermediate_dec)
+        self._reset_parameters()
+        self.d_model = d_model
+        self.nhead = nhead
+        self.compute_dtype = _DTYPES[compute_dtype]
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, src, mask, query_embed, pos_embed, need_weights: bool = True):
+        """src [B,L,d] (fp32: it starts the fp32 residual stream), mask [B,L] bool with True on PADDED positions (or
+        None), query_embed [N,d] or [N,B,d], pos_embed [B,L,d].  Returns (hs [n_dec,B,N,d] fp32, memory [B,L,d] fp32,
+        att_weights [n_dec,B,N,L] fp32 or None) — transformer.py:43-81."""
+        if not src.is_cuda:
+            raise RuntimeError('svol_amd Transformer runs on the MI355X HIP kernels only (no CPU path; the CPU oracle '
+                               'lives under oracle/)')
+        dt = self.compute_dtype
+        src32 = src if src.dtype == torch.float32 else src.float()
+        pos = pos_embed if pos_embed.dtype == dt else ops.cast_ag(pos_embed.float().contiguous(), dt)
+        kbias = None
+        if mask is not None:
+            kbias = torch.zeros(mask.shape, dtype=torch.float32, device=src.device).masked_fill_(mask.bool(), float('-inf'))
+        if query_embed.dim() == 3:  # [N,B,d] per-sample queries (sketch_detr.py:57-60, svanet_variants.py:215-219)
+            qpos = query_embed.transpose(0, 1)
+        else:
+            qpos = query_embed
+        qpos = ops.cast_ag(qpos.float().contiguous(), dt)
+        mem32, mem, mempos = self.encoder(src32.contiguous(), pos.contiguous(), kbias)
+        hs, att = self.decoder(mem, mempos, qpos, kbias, need_weights)
+        return hs, mem32, att
+
+
+def build_transformer(args):
+    """transformer.py:312-322 (+ the build's compute dtype)."""
+    return Transformer(
+        d_model=args.hidden_dim,
+        dropout=args.dropout,
+        nhead=args.nheads,
+        dim_feedforward=args.dim_feedforward,
+        num_encoder_layers=args.enc_layers,
+        num_decoder_layers=args.dec_layers,
+        normalize_before=args.pre_norm,
+        return_intermediate_dec=True,
+        compute_dtype=getattr(args, 'compute_dtype', 'bf16'),
+    )

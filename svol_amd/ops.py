@@ -144,19 +144,23 @@ def gemm_tn(A, B, out=None, colsum=None):
     return out
 
 
-def gemm_nt_dgelu(A, B, pre, want_colsum=True, colsum_out=None):
-    """(A @ B^T) * gelu'(pre), and its column sums (fp32, accumulated into colsum_out when given) — fused MLP
-    backward step."""
+def gemm_nt_dact(A, B, aux, act, want_colsum=True, colsum_out=None):
+    """(A @ B^T) * act'(aux), and its column sums (fp32, accumulated into colsum_out when given) — fused MLP
+    backward step.  act = ACT_GELU (aux = saved pre-activation) or ACT_RELU (aux = saved post-activation)."""
     M, K = A.shape
     N = B.shape[0]
     out = torch.empty((M, N), dtype=A.dtype, device=A.device)
     cs = colsum_out
     if cs is None and want_colsum:
         cs = torch.zeros((N,), dtype=torch.float32, device=A.device)
-    rc = _lib.lib().svol_gemm_nt_dgelu(_ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), out.stride(0), _ptr(pre),
-                                       pre.stride(0), _ptr(cs), M, N, K, _dt(A), _stream())
-    _lib.check(rc, 'svol_gemm_nt_dgelu')
+    rc = _lib.lib().svol_gemm_nt_dact(_ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), out.stride(0), _ptr(aux),
+                                      aux.stride(0), act, _ptr(cs), M, N, K, _dt(A), _stream())
+    _lib.check(rc, 'svol_gemm_nt_dact')
     return out, cs
+
+
+def gemm_nt_dgelu(A, B, pre, want_colsum=True, colsum_out=None):
+    return gemm_nt_dact(A, B, pre, ACT_GELU, want_colsum, colsum_out)
 
 
 def colsum(X, out=None):
@@ -267,6 +271,16 @@ def attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias=None, pre
                                   ws.numel() * 4 if ws is not None else 0, _dt(q), _stream())
     timer.stop(tok)
     _lib.check(rc, 'svol_attn_bwd')
+
+
+def attn_weights_mean(q, k, lse2, B, H, Lq, Lk, dh, kbias=None, premul=0.0):
+    """head-averaged softmax probabilities [B,Lq,Lk] fp32 (nn.MultiheadAttention's second return value), recomputed
+    from q, k and the lse2 of attn_fwd."""
+    att = torch.empty((B, Lq, Lk), dtype=torch.float32, device=q.device)
+    rc = _lib.lib().svol_attn_weights_mean(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(lse2), _ptr(kbias), _ptr(att),
+                                           B, H, Lq, Lk, dh, 1.0 / math.sqrt(dh), float(premul), _dt(q), _stream())
+    _lib.check(rc, 'svol_attn_weights_mean')
+    return att
 
 
 # ----------------------------------------------------------------------------
@@ -505,11 +519,24 @@ def _ln_out(s32, gamma, beta, pos_out, dt):
     return y32, y, ypos, mean, rstd
 
 
+def _res_grad(ds32, dt, cs_out):
+    """blocks without a post-norm (pre-norm layers): the incoming fp32 stream gradient IS the gradient of the
+    pre-norm sum; cast it for the GEMMs and take its column sums (bias gradient of the Linear that fed the sum)."""
+    D = ds32.shape[-1]
+    ds32 = ds32.reshape(-1, D)
+    if not ds32.is_contiguous():
+        ds32 = ds32.contiguous()
+    g = cast(ds32, dt)
+    return ds32, g, colsum(g, out=cs_out)
+
+
 class MLPLNFn(torch.autograd.Function):
-    """LN(x + fc2(gelu(fc1(x))))  — cross_modal_transformer.py:142-143,157-158 + MLP :163-179."""
+    """LN(x32 + fc2(act(fc1(x))))  — cross_modal_transformer.py:142-143,157-158 + MLP :163-179 (GELU); the FFN of the
+    enc/dec Transformer (ReLU, transformer.py:191-193,245-247).  gamma None: no norm, the fp32 sum is the output
+    (pre-norm layers, transformer.py:205-207: x is then LN(x32), not a copy of x32)."""
 
     @staticmethod
-    def forward(ctx, x32, x, W1, b1, W2, b2, gamma, beta, pos_out):
+    def forward(ctx, x32, x, W1, b1, W2, b2, gamma, beta, pos_out, act=ACT_GELU):
         ctx.set_materialize_grads(False)
         shp = x.shape
         D = shp[-1]
@@ -517,21 +544,29 @@ class MLPLNFn(torch.autograd.Function):
         x2, x32_2 = x.reshape(-1, D), x32.reshape(-1, D)
         W1c, W1T = weights.get(W1, dt)
         W2c, W2T = weights.get(W2, dt)
-        hid, pre = gemm_nt(x2, W1c, b1, ACT_GELU, want_pre=True)
+        if act == ACT_GELU:
+            hid, aux = gemm_nt(x2, W1c, b1, ACT_GELU, want_pre=True)   # aux = pre-activation
+        elif act == ACT_RELU:
+            hid = aux = gemm_nt(x2, W1c, b1, ACT_RELU)                 # relu' = [hid > 0]
+        else:
+            raise _lib.SvolHipError('MLPLNFn: activation must be GELU or ReLU')
         s32 = gemm_nt(hid, W2c, b2, ACT_NONE, residual=x32_2, out_f32=True)
-        y32, y, ypos, mean, rstd = _ln_out(s32, gamma, beta, pos_out, dt)
-        ctx.save_for_backward(x2, pre, hid, s32, gamma, mean, rstd)
-        ctx.W1T, ctx.W2T, ctx.shp = W1T, W2T, shp
+        ctx.W1T, ctx.W2T, ctx.shp, ctx.act, ctx.has_ln = W1T, W2T, shp, act, gamma is not None
         ctx.pos_shape = pos_out.shape if pos_out is not None else None
         nig = ctx.needs_input_grad
         ctx.sinks = tuple(_claim(p_, nig[i]) for i, p_ in ((2, W1), (3, b1), (4, W2), (5, b2), (6, gamma), (7, beta)))
+        if gamma is None:
+            ctx.save_for_backward(x2, aux, hid, None, None, None, None)
+            return s32.view(shp)
+        y32, y, ypos, mean, rstd = _ln_out(s32, gamma, beta, pos_out, dt)
+        ctx.save_for_backward(x2, aux, hid, s32, gamma, mean, rstd)
         if pos_out is not None:
             return y32.view(shp), y.view(shp), ypos.view(shp)
         return y32.view(shp), y.view(shp)
 
     @staticmethod
-    def backward(ctx, dy32, dy, dypos=None):
-        x2, pre, hid, s32, gamma, mean, rstd = ctx.saved_tensors
+    def backward(ctx, dy32, dy=None, dypos=None):
+        x2, aux, hid, s32, gamma, mean, rstd = ctx.saved_tensors
         dt = x2.dtype
         D = x2.shape[1]
         dpos = None
@@ -539,8 +574,12 @@ class MLPLNFn(torch.autograd.Function):
             dpos = _pos_grad(dypos, ctx.pos_shape, D)
         sW1, sb1, sW2, sb2, sg, sbt = ctx.sinks
         vw = lambda s_: s_.view if s_ is not None else None
-        ds32, ds, dg, dbt, db2 = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True,
-                                               want_colsum=True, dg_out=vw(sg), db_out=vw(sbt), cs_out=vw(sb2))
+        if ctx.has_ln:
+            ds32, ds, dg, dbt, db2 = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True,
+                                                   want_colsum=True, dg_out=vw(sg), db_out=vw(sbt), cs_out=vw(sb2))
+        else:
+            ds32, ds, db2 = _res_grad(dy32, dt, vw(sb2))
+            dg = dbt = None
         F_ = hid.shape[1]
         if sW1 is not None and sW2 is not None:
             dW1, dW2 = sW1.view, sW2.view
@@ -548,8 +587,8 @@ class MLPLNFn(torch.autograd.Function):
             wbuf = torch.zeros((2 * D * F_,), dtype=torch.float32, device=ds.device)  # one memset for dW1 | dW2
             dW1, dW2 = wbuf[:D * F_].view(F_, D), wbuf[D * F_:].view(D, F_)
         gemm_tn(ds, hid, out=dW2)
-        # (ds W2) * gelu'(pre) and its column sums, one kernel
-        dpre, db1 = gemm_nt_dgelu(ds, ctx.W2T, pre, colsum_out=vw(sb1))
+        # (ds W2) * act'(aux) and its column sums, one kernel
+        dpre, db1 = gemm_nt_dact(ds, ctx.W2T, aux, ctx.act, colsum_out=vw(sb1))
         gemm_tn(dpre, x2, out=dW1)
         dx = gemm_nt(dpre, ctx.W1T)
         if (sW1 is None) != (sW2 is None):  # only one of the two has a sink: add the other by hand
@@ -558,16 +597,19 @@ class MLPLNFn(torch.autograd.Function):
                     s_.view.add_(g_)
         n_ = lambda s_, g_: None if s_ is not None else g_
         return (ds32.view(ctx.shp), dx.view(ctx.shp), n_(sW1, dW1), n_(sb1, db1), n_(sW2, dW2), n_(sb2, db2), n_(sg, dg),
-                n_(sbt, dbt), dpos)
+                n_(sbt, dbt), dpos, None)
 
 
 class AttnLNFn(torch.autograd.Function):
-    """LN(xq + out_proj(MHA(q = Wq xq_pos, k = Wk xk_pos, v = Wv xv))) with packed in_proj
-    (nn.MultiheadAttention + post-norm, cross_modal_transformer.py:137-141,145-149,151-156).
-    ``self_attn``: xk_pos is xq_pos and xv is xq (one packed projection buffer)."""
+    """LN(xq32 + out_proj(MHA(q = Wq xq_pos, k = Wk xk_pos, v = Wv xv))) with packed in_proj
+    (nn.MultiheadAttention + post-norm, cross_modal_transformer.py:137-141,145-149,151-156; transformer.py:183-189,
+    237-250).  ``self_attn``: xk_pos is xq_pos and xv is xq (one packed projection buffer).  gamma None: no norm, the
+    fp32 sum is the output (pre-norm layers, transformer.py:198-203: xq is then LN(xq32)).  ``need_weights``: also
+    return the head-averaged attention weights [B,Lq,Lk] fp32 (no gradient flows into them)."""
 
     @staticmethod
-    def forward(ctx, xq32, xq, xq_pos, xk_pos, xv, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, kbias, self_attn):
+    def forward(ctx, xq32, xq, xq_pos, xk_pos, xv, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, kbias, self_attn,
+                need_weights=False):
         ctx.set_materialize_grads(False)
         B, Lq, d = xq.shape
         dt = xq.dtype
@@ -595,39 +637,56 @@ class AttnLNFn(torch.autograd.Function):
             gemm_nt(a_v, Wc[2 * d:], b_in[2 * d:], out=kv[:, d:])
             k, v = kv[:, :d], kv[:, d:]
         o, lse2 = attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias, premul)
+        att = attn_weights_mean(q, k, lse2, B, H, Lq, Lk, dh, kbias, premul) if need_weights else None
         s32 = gemm_nt(o, Woc, b_o, residual=xq32.reshape(B * Lq, d), out_f32=True)
-        y32, y, ypos, mean, rstd = _ln_out(s32, gamma, beta, pos_out, dt)
-        ctx.save_for_backward(a_qp, a_q, a_kp, a_v, q, k, v, o, lse2, kbias, s32, gamma, mean, rstd)
         ctx.WcT, ctx.WoT, ctx.dims, ctx.self_attn, ctx.premul = WcT, WoT, (B, H, Lq, Lk, dh, d), self_attn, premul
         ctx.pos_shape = pos_out.shape if pos_out is not None else None
+        ctx.has_ln = gamma is not None
         nig = ctx.needs_input_grad
         ctx.sinks = tuple(_claim(p_, nig[i]) for i, p_ in ((5, W_in), (6, b_in), (7, W_o), (8, b_o), (9, gamma),
                                                            (10, beta)))
-        if any(s_ is None for s_ in ctx.sinks):  # all or nothing
+        if any(s_ is None for s_ in ctx.sinks[:6 if ctx.has_ln else 4]):  # all or nothing
             ctx.sinks = None
         shp = (B, Lq, d)
+        if att is not None:
+            ctx.mark_non_differentiable(att)
+        tail = (att,) if att is not None else ()
+        if gamma is None:
+            ctx.save_for_backward(a_qp, a_q, a_kp, a_v, q, k, v, o, lse2, kbias, None, None, None, None)
+            return (s32.view(shp),) + tail if tail else s32.view(shp)
+        y32, y, ypos, mean, rstd = _ln_out(s32, gamma, beta, pos_out, dt)
+        ctx.save_for_backward(a_qp, a_q, a_kp, a_v, q, k, v, o, lse2, kbias, s32, gamma, mean, rstd)
         if pos_out is not None:
-            return y32.view(shp), y.view(shp), ypos.view(shp)
-        return y32.view(shp), y.view(shp)
+            return (y32.view(shp), y.view(shp), ypos.view(shp)) + tail
+        return (y32.view(shp), y.view(shp)) + tail
 
     @staticmethod
-    def backward(ctx, dy32, dy, dypos=None):
+    def backward(ctx, dy32, *rest):
         a_qp, a_q, a_kp, a_v, q, k, v, o, lse2, kbias, s32, gamma, mean, rstd = ctx.saved_tensors
         B, H, Lq, Lk, dh, d = ctx.dims
         dt = a_q.dtype
         WcT, WoT = ctx.WcT, ctx.WoT  # WcT: [d, 3d] ; WoT: [d, d]
+        dy = rest[0] if ctx.has_ln and len(rest) > 0 else None
+        dypos = rest[1] if ctx.has_ln and ctx.pos_shape is not None and len(rest) > 1 else None
         dpos = None
         if ctx.pos_shape is not None and ctx.needs_input_grad[11] and dypos is not None:
             dpos = _pos_grad(dypos, ctx.pos_shape, d)
         sk = ctx.sinks
+        dg = dbt = None
         if sk is not None:
             dW_in, db_in, dWo = sk[0].view, sk[1].view, sk[2].view
-            ds32, g, dg, dbt, dbo = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True,
-                                                  want_colsum=True, dg_out=sk[4].view, db_out=sk[5].view,
-                                                  cs_out=sk[3].view)
+            if ctx.has_ln:
+                ds32, g, dg, dbt, dbo = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True,
+                                                      want_colsum=True, dg_out=sk[4].view, db_out=sk[5].view,
+                                                      cs_out=sk[3].view)
+            else:
+                ds32, g, dbo = _res_grad(dy32, dt, sk[3].view)
         else:
-            ds32, g, dg, dbt, dbo = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True,
-                                                  want_colsum=True)
+            if ctx.has_ln:
+                ds32, g, dg, dbt, dbo = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True,
+                                                      want_colsum=True)
+            else:
+                ds32, g, dbo = _res_grad(dy32, dt, None)
             gbuf = torch.zeros((3 * d * d + 3 * d + d * d,), dtype=torch.float32, device=g.device)  # one memset
             dW_in, db_in = gbuf[:3 * d * d].view(3 * d, d), gbuf[3 * d * d:3 * d * d + 3 * d]
             dWo = gbuf[3 * d * d + 3 * d:].view(d, d)
@@ -645,7 +704,7 @@ class AttnLNFn(torch.autograd.Function):
             if sk is not None:
                 dW_in = db_in = dWo = dbo = dg = dbt = None
             return (ds32.view(shq), dxq.view(shq), dxq_pos.view(shq), None, None, dW_in, db_in, dWo, dbo, dg, dbt,
-                    dpos, None, None, None)
+                    dpos, None, None, None, None)
         dq = torch.empty((B * Lq, d), dtype=dt, device=g.device)
         dkv = torch.empty((B * Lk, 2 * d), dtype=dt, device=g.device)
         dk, dv = dkv[:, :d], dkv[:, d:]
@@ -660,7 +719,43 @@ class AttnLNFn(torch.autograd.Function):
         if sk is not None:
             dW_in = db_in = dWo = dbo = dg = dbt = None
         return (ds32.view(shq), None, dxq_pos.view(shq), dxk_pos.view(shk), dxv.view(shk), dW_in, db_in, dWo, dbo, dg,
-                dbt, dpos, None, None, None)
+                dbt, dpos, None, None, None, None)
+
+
+class LNStreamFn(torch.autograd.Function):
+    """(y, y + pos) = LN(x32) in the compute dtype from the fp32 residual stream — the norm that OPENS a pre-norm
+    block (transformer.py:198-199, 205, 267-268, 274, 280) and the decoder's shared output norm."""
+
+    @staticmethod
+    def forward(ctx, x32, gamma, beta, pos, dtype, want32):
+        ctx.set_materialize_grads(False)
+        shp = x32.shape
+        D = shp[-1]
+        x2 = x32.reshape(-1, D)
+        y32, y, ypos, mean, rstd = layernorm_fwd(x2, gamma, beta, dtype, pos, want32=want32)
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        ctx.shp, ctx.dtype, ctx.has_pos, ctx.want32 = shp, dtype, pos is not None, want32
+        ctx.pos_shape = pos.shape if pos is not None else None
+        ctx.sinks = (_claim(gamma, ctx.needs_input_grad[1]), _claim(beta, ctx.needs_input_grad[2]))
+        out = ((y32.view(shp),) if want32 else ()) + (y.view(shp),) + ((ypos.view(shp),) if pos is not None else ())
+        return out if len(out) > 1 else out[0]
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        g = list(grads)
+        dy32 = g.pop(0) if ctx.want32 else None
+        dy = g.pop(0)
+        dypos = g.pop(0) if ctx.has_pos else None
+        if dy32 is None and dy is None and dypos is None:
+            return None, None, None, None, None, None
+        sg, sb = ctx.sinks
+        dpos = None
+        if dypos is not None and ctx.needs_input_grad[3]:
+            dpos = _pos_grad(dypos, ctx.pos_shape, x2.shape[1])
+        dx32, _, dg, db = layernorm_bwd(dy32, dy, dypos, x2, gamma, mean, rstd, ctx.dtype, want32=True, want_t=False,
+                                        dg_out=sg.view if sg else None, db_out=sb.view if sb else None)
+        return dx32.view(ctx.shp), None if sg else dg, None if sb else db, dpos, None, None
 
 
 LOG2E = 1.4426950408889634
@@ -678,16 +773,22 @@ def _qscale(d, premul, device):
     return t
 
 
-def mlp_ln(x32, x, W1, b1, W2, b2, gamma, beta, pos_out=None):
-    return MLPLNFn.apply(x32, x, W1, b1, W2, b2, gamma, beta, pos_out)
+def mlp_ln(x32, x, W1, b1, W2, b2, gamma, beta, pos_out=None, act=ACT_GELU):
+    return MLPLNFn.apply(x32, x, W1, b1, W2, b2, gamma, beta, pos_out, act)
 
 
-def self_attn_ln(x32, x, x_pos, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H):
-    return AttnLNFn.apply(x32, x, x_pos, None, None, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, None, True)
+def self_attn_ln(x32, x, x_pos, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, kbias=None):
+    return AttnLNFn.apply(x32, x, x_pos, None, None, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, kbias, True)
 
 
-def cross_attn_ln(xq32, xq, xq_pos, xk_pos, xv, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, kbias):
-    return AttnLNFn.apply(xq32, xq, xq_pos, xk_pos, xv, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, kbias, False)
+def cross_attn_ln(xq32, xq, xq_pos, xk_pos, xv, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, kbias,
+                  need_weights=False):
+    return AttnLNFn.apply(xq32, xq, xq_pos, xk_pos, xv, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, kbias, False,
+                          need_weights)
+
+
+def ln_stream(x32, gamma, beta, pos, dtype, want32=False):
+    return LNStreamFn.apply(x32, gamma, beta, pos, dtype, want32)
 
 
 class GateFn(torch.autograd.Function):

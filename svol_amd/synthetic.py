@@ -283,3 +283,54 @@ def synth_images(n: int, cfg, seed: int = 1) -> torch.Tensor:
     """pixel_values [n, C, H, W] fp32 as the HF feature extractor hands them over (already normalised)."""
     r = _rs('images', seed)
     return torch.from_numpy(r.standard_normal((n, cfg.num_channels, cfg.image_size, cfg.image_size)).astype(np.float32))
+
+
+# ----------------------------------------------------------------------------
+# enc/dec Transformer heads (SURVEY.md §8 f2): svanet_variants / sketch_detr
+# ----------------------------------------------------------------------------
+def encdec_args(**over) -> SimpleNamespace:
+    """head_args + the fields build_transformer / the variant builders read (transformer.py:312-322,
+    svanet_variants.py:289-306, sketch_detr.py:118-132) — absent from the reference's own option surface."""
+    a = dict(enc_layers=2, dec_layers=2, dim_feedforward=64, dropout=0.1, pre_norm=False, mode='append_to_seq', feat_dim=32,
+             backbone='features', hidden_dim=32, nheads=4, num_queries=8)
+    a.update(over)
+    return head_args(**a)
+
+
+def synth_like(shapes, seed: int = 1) -> "OrderedDict[str, torch.Tensor]":
+    """synth_state_dict's recipe for an arbitrary ordered {key: shape} table (taken from a module's state_dict)."""
+    sd = OrderedDict()
+    for k, shp in shapes.items():
+        shp = tuple(shp)
+        r = _rs(k, seed)
+        if k.endswith('query_embed.weight'):
+            v = r.standard_normal(shp)
+        elif len(shp) == 2:
+            a = float(np.sqrt(6.0 / (shp[0] + shp[1])))
+            v = r.uniform(-a, a, size=shp)
+        elif ('norm' in k or 'LayerNorm' in k) and k.endswith('weight'):
+            v = 1.0 + r.uniform(-0.1, 0.1, size=shp)
+        else:
+            v = r.uniform(-0.1, 0.1, size=shp)
+        sd[k] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+    return sd
+
+
+def synth_encdec_inputs(args, B: int, L: int, Ls: int = 1, seed: int = 1, pad: int = 0):
+    """features at the variant heads' boundary: src_sketch [B,Ls,D], src_video [B,L,D]; the last `pad` video tokens of
+    every odd batch element are padding (mask 0)."""
+    r = _rs('encdec_inputs', seed)
+    D = args.feat_dim
+    src_video = r.standard_normal((B, L, D)).astype(np.float32)
+    src_sketch = r.standard_normal((B, Ls, D)).astype(np.float32)
+    vmask = np.ones((B, L), np.float32)
+    for b in range(B):
+        if pad and b % 2 == 1:
+            vmask[b, L - pad:] = 0.0
+    return dict(src_sketch=torch.from_numpy(src_sketch), src_sketch_mask=torch.from_numpy(np.ones((B, Ls), np.float32)),
+                src_video=torch.from_numpy(src_video), src_video_mask=torch.from_numpy(vmask))
+
+
+def synth_probe(shape, key: str, seed: int = 1) -> torch.Tensor:
+    """fixed N(0,1) weights of the linear functional  sum(output * probe)  the gradient fixtures differentiate."""
+    return torch.from_numpy(_rs('probe/' + key, seed).standard_normal(tuple(shape)).astype(np.float32))

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Generate the enc/dec Transformer fixtures FROM THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference).  Imports the reference's ``lib.modeling.svanet_variants`` and
+``lib.modeling.sketch_detr`` (torch-only), loads the deterministic synthetic weights of ``svol_amd.synthetic.synth_like``
+into them, runs forward (eval mode) + a fixed linear functional + backward on CPU fp32 and stores ONLY DATA (outputs,
+decoder states, encoder memory, attention weights, gradients).  Inputs and weights are regenerated bit-for-bit by the tests.
+
+    python tests/golden/make_golden_encdec.py
+"""
+import json
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+REF = os.environ.get('SVOL_REFERENCE', '/root/reference')
+sys.path.insert(0, REF)
+
+from lib.modeling.svanet_variants import build_svanet as ref_build_variants  # noqa: E402  (reference)
+from lib.modeling.sketch_detr import build_sketchdetr as ref_build_sketchdetr  # noqa: E402  (reference)
+
+from svol_amd import synthetic as syn  # noqa: E402
+from tests.golden.make_golden import grad_record  # noqa: E402
+
+CASES = OrderedDict()
+for mode, ls in (('concat_to_seq', 1), ('append_to_seq', 2), ('concat_to_qry', 1)):
+    for pre in (False, True):
+        CASES[f'encdec_{mode}_{"pre" if pre else "post"}'] = dict(
+            head='variants', over=dict(mode=mode, pre_norm=pre), B=2, L=24, Ls=ls, pad=5)
+# benchmark-like widths: d = 256, 8 heads of 32, 100 queries; M = B*L >= 4096 reaches the weight-stationary GEMMs
+CASES['encdec_mid_append_post'] = dict(
+    head='variants', over=dict(mode='append_to_seq', pre_norm=False, hidden_dim=256, nheads=8, dim_feedforward=512, enc_layers=1,
+                               dec_layers=2, num_queries=100, feat_dim=64), B=2, L=2304, Ls=1, pad=300)
+CASES['encdec_mid_qry_pre'] = dict(
+    head='variants', over=dict(mode='concat_to_qry', pre_norm=True, hidden_dim=256, nheads=8, dim_feedforward=512, enc_layers=1,
+                               dec_layers=2, num_queries=100, feat_dim=64), B=2, L=2176, Ls=1, pad=0)
+CASES['encdec_sketch_detr_post'] = dict(head='sketch_detr', over=dict(mode='unused', pre_norm=False), B=2, L=6, Ls=1, pad=0)
+
+
+def probe_loss(stack_logits, stack_boxes):
+    wl = syn.synth_probe(stack_logits.shape, 'logits')
+    wb = syn.synth_probe(stack_boxes.shape, 'boxes')
+    return (stack_logits * wl).sum() + (stack_boxes * wb).sum()
+
+
+def stack_outputs(out):
+    layers = list(out.get('aux_outputs', [])) + [out]
+    return torch.stack([o['pred_logits'] for o in layers]), torch.stack([o['pred_boxes'] for o in layers])
+
+
+def run(name, c):
+    args = syn.encdec_args(**c['over'])
+    torch.manual_seed(1)
+    model = (ref_build_variants if c['head'] == 'variants' else ref_build_sketchdetr)(args)
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in model.state_dict().items())
+    sd = syn.synth_like(shapes, seed=1)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    seen = {}
+
+    def _keep(_m, _i, o):  # (a hook that returns a value would REPLACE the module's output)
+        seen.setdefault('t', o)
+
+    model.transformer.register_forward_hook(_keep)
+    inp = syn.synth_encdec_inputs(args, c['B'], c['L'], c['Ls'], seed=1, pad=c['pad'])
+    out = model(inp['src_sketch'], inp['src_sketch_mask'], inp['src_video'], inp['src_video_mask'])
+    if isinstance(out, tuple):
+        out = out[0]
+    if c['head'] == 'sketch_detr':  # list over frames -> [n_dec, T, B, N, .]
+        per = [stack_outputs(o) for o in out]
+        logits = torch.stack([p[0] for p in per], dim=1)
+        boxes = torch.stack([p[1] for p in per], dim=1)
+    else:
+        logits, boxes = stack_outputs(out)
+    loss = probe_loss(logits, boxes)
+    loss.backward()
+    rec = {'meta': np.asarray(json.dumps(dict(args=vars(args), head=c['head'], B=c['B'], L=c['L'], Ls=c['Ls'], pad=c['pad'],
+                                              torch=torch.__version__))),
+           'keys': np.asarray('\n'.join(shapes.keys())),
+           'shapes': np.asarray(json.dumps([list(s) for s in shapes.values()])),
+           'logits': logits.detach().numpy(), 'boxes': boxes.detach().numpy(), 'loss': np.asarray(float(loss), np.float64)}
+    if c['head'] == 'variants':
+        hs, memory, att = seen['t']
+        rec['hs'] = hs.detach().numpy()
+        step = max(1, memory.numel() // 4096)
+        rec['memory_sample'] = memory.detach().reshape(-1)[::step].numpy()
+        rec['memory_norm'] = np.asarray(float(memory.detach().double().norm()))
+        a = att.detach()
+        rec['att_rowsum_err'] = np.asarray(float((a.sum(-1) - 1).abs().max()))
+        rec['att'] = a.numpy() if a.numel() <= 65536 else a[:, :, ::7, ::37].contiguous().numpy()
+    for k, p in model.named_parameters():
+        grad_record(rec, k, p.grad)
+    path = os.path.join(HERE, f'{name}.npz')
+    np.savez_compressed(path, **rec)
+    print(f'{name}: loss={float(loss):.6f} -> {os.path.getsize(path) / 1024:.1f} KiB', flush=True)
+
+
+if __name__ == '__main__':
+    only = sys.argv[1:]
+    for name, c in CASES.items():
+        if not only or name in only:
+            run(name, c)

@@ -52,3 +52,35 @@ def check_grad(z, key, g, rtol, atol):
         st = z[f'gstat/{key}']
         l2 = np.sqrt((flat ** 2).sum())
         assert abs(l2 - st[2]) <= rtol * st[2] + atol * np.sqrt(flat.size), f'{key}: l2 {l2} vs {st[2]}'
+
+
+ENCDEC_CASES = ['encdec_concat_to_seq_post', 'encdec_concat_to_seq_pre', 'encdec_append_to_seq_post', 'encdec_append_to_seq_pre',
+                'encdec_concat_to_qry_post', 'encdec_concat_to_qry_pre', 'encdec_mid_append_post', 'encdec_mid_qry_pre',
+                'encdec_sketch_detr_post']
+
+
+def encdec_case(name):
+    """Regenerate (args, state_dict, inputs) of an enc/dec golden case (tests/golden/make_golden_encdec.py)."""
+    from collections import OrderedDict
+    z, meta = load_golden(name)
+    args = syn.encdec_args(**meta['args'])
+    shapes = OrderedDict(zip(str(z['keys']).split('\n'), [tuple(s) for s in json.loads(str(z['shapes']))]))
+    sd = syn.synth_like(shapes, seed=1)
+    inp = syn.synth_encdec_inputs(args, meta['B'], meta['L'], meta['Ls'], seed=1, pad=meta['pad'])
+    return z, meta, args, sd, inp
+
+
+def encdec_stack(out, head):
+    """model output -> (logits, boxes) stacked like the fixtures: [n_dec,B,N,.] or, for sketch_detr, [n_dec,T,B,N,.]"""
+    def st(o):
+        layers = list(o.get('aux_outputs', [])) + [o]
+        return torch.stack([l['pred_logits'] for l in layers]), torch.stack([l['pred_boxes'] for l in layers])
+    if head == 'sketch_detr':
+        per = [st(o) for o in out]
+        return torch.stack([p[0] for p in per], dim=1), torch.stack([p[1] for p in per], dim=1)
+    return st(out)
+
+
+def encdec_att_view(att, z):
+    """the slice of the attention-weight stack a fixture stores (make_golden_encdec.py)."""
+    return att if att.numel() <= 65536 else att[:, :, ::7, ::37]

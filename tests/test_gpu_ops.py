@@ -31,6 +31,14 @@ def test_gemm_nt_dgelu_fused(G):
     _assert(G.check_gemm_dgelu())
 
 
+def test_gemm_nt_drelu_fused(G):
+    _assert(G.check_gemm_drelu())
+
+
+def test_attention_weights_mean(G):
+    _assert(G.check_attn_weights())
+
+
 def test_gemm_tn(G):
     _assert(G.check_gemm_tn())
 
