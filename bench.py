@@ -82,10 +82,11 @@ def main():
                          'but a captured graph serialises the query-stream / video-stream overlap: measured slower)')
     ap.add_argument('--no-graph', action='store_true', help='accepted for compatibility (eager is the default)')
     ap.add_argument('--batch', type=int, default=None, help='videos per GPU (default: 8, cfg5: 1)')
-    ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg4', 'cfg5'],
+    ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg4', 'cfg5', 'encdec'],
                     help='cfg2 = the BASELINE metric workload (default); cfg4 = cfg2 with the ViT-B/16 frame + sketch feature '
                          'extractor run online in front of the head (BASELINE configs[3], end-to-end frames/s); '
-                         'cfg5 = long-video stress case T=128, P=256 (bf16)')
+                         'cfg5 = long-video stress case T=128, P=256 (bf16); encdec = the cfg2 shapes through the 6+6 enc/dec Transformer '
+                         '(svanet_variants, append_to_seq) instead of the cross-modal transformer')
     a = ap.parse_args()
 
     import torch
@@ -118,6 +119,14 @@ def main():
     args = syn.head_args(num_frames=T) if a.workload == 'cfg5' else syn.cfg2_args('video_matcher')
     if a.workload == 'cfg4':
         args.input_vid_dim = args.input_skch_dim = 768  # ViT-B/16 features (backbone.py:124-125)
+    if a.workload == 'encdec':
+        # DETR-style 6 + 6 encoder / decoder, post-norm, ReLU FFN (--dim_feedforward default 1024), no
+        # dropout inside the transformer (the HIP blocks have none); the sketch token is prepended to the video tokens
+        from svol_amd.modeling.svanet_variants import build_svanet as build_svanet
+        args = syn.encdec_args(hidden_dim=256, nheads=8, num_queries=100, num_frames=T, enc_layers=6, dec_layers=6,
+                               dim_feedforward=1024, dropout=0.0, pre_norm=False, mode='append_to_seq', feat_dim=512,
+                               matcher='video_matcher', num_layers=6)
+        args.input_vid_dim = args.input_skch_dim = args.feat_dim
     args.compute_dtype = a.dtype
     torch.manual_seed(1)  # reference default seed (configs.py:17): identical initial weights on every rank
     model = build_svanet(args).to(dev).train()
@@ -200,7 +209,7 @@ def main():
     fps = frames / (elapsed / a.steps)
 
     # ---- roofline of the dominant kernel: video self-attention (L x L, 67 % of the layer's FLOPs) ----
-    L = T * P
+    L = T * P + (1 if a.workload == 'encdec' else 0)
     dh = args.hidden_dim // args.nheads
     summ = ops.timer.summary()
     fwd = summ.get(('attn_fwd', (B, args.nheads, L, L, dh)))
@@ -208,7 +217,11 @@ def main():
     attn_fwd_flop = 4.0 * L * L * args.hidden_dim * B          # QK^T + PV  (4 L^2 d per sample)
     # SURVEY.md §8d table; cfg4 adds the extractor forward: 2*197*(768*768*4 + 2*768*3072)*12 + attention ~ 35.1 GF per
     # image, (B*T + B) images per B*T frames
-    gf_frame = {'cfg2': FWD_BWD_GF_PER_FRAME, 'cfg5': 169.3, 'cfg4': FWD_BWD_GF_PER_FRAME * 1.24 + 35.1 * (T + 1) / T}[a.workload]
+    gf_frame = {'cfg2': FWD_BWD_GF_PER_FRAME, 'cfg5': 169.3, 'cfg4': FWD_BWD_GF_PER_FRAME * 1.24 + 35.1 * (T + 1) / T,
+                # enc/dec, per sample forward: input proj + 6 x (8Ld^2 + 4L^2d + 4LdF) encoder + 6 x (4Ld^2 K/V proj + 4NLd) decoder
+                # memory side (query-side terms < 1 %), x3 for fwd+bwd, / T frames; L = T*P + 1, F = 1024
+                'encdec': 3.0 * (2 * L * 512 * 256 + 2 * L * 256 * 256 + 6 * (8 * L * 256 ** 2 + 4 * L * L * 256 + 4 * L * 256 * 1024)
+                                 + 6 * (4 * L * 256 ** 2 + 4 * 100 * L * 256)) / T / 1e9}[a.workload]
     roof = None
     if fwd and bwd:
         # backward = 2x forward algorithmically (dV, dP, dQ, dK products; the S recompute gets no credit)
@@ -229,9 +242,12 @@ def main():
             'value': fps, 'unit': 'frames/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': a.dtype, 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[%d]: SVANet head + Hungarian/GIoU criterion, B=%d/GPU, T=%d, P=%d, '
+            'config': {'workload': ('enc/dec Transformer head (svanet_variants append_to_seq, 6 + 6 layers, post-norm, F=1024) on the '
+                                    'BASELINE configs[1] shapes' if a.workload == 'encdec' else 'BASELINE configs[%d]: SVANet head' %
+                                    {'cfg2': 1, 'cfg4': 3, 'cfg5': 4}[a.workload]) + (
+                                   ' + Hungarian/GIoU criterion, B=%d/GPU, T=%d, P=%d, '
                                    'd=256, h=8, 6 layers, N=100, video_matcher, Din=%d, train mode; step = fwd + '
-                                   'criterion + bwd (+RCCL grad all-reduce) + AdamW' % ({'cfg2': 1, 'cfg4': 3, 'cfg5': 4}[a.workload], B, T, P, args.input_vid_dim) + (
+                                   'criterion + bwd (+RCCL grad all-reduce) + AdamW' % (B, T, P, args.input_vid_dim)) + (
                                        '; ViT-B/16 extractor (random init, frozen) on all %d frames + %d sketches inside the step' % (B * T, B)
                                        if a.workload == 'cfg4' else ''),
                        'global_batch': B * world, 'parallelism': f'dp{world}'},

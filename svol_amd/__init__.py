@@ -25,6 +25,9 @@ def install_as_lib():
         'lib.modeling.svanet': 'svol_amd.modeling.svanet',
         'lib.modeling.cross_modal_transformer': 'svol_amd.modeling.cross_modal_transformer',
         'lib.modeling.position_encoding': 'svol_amd.modeling.position_encoding',
+        'lib.modeling.transformer': 'svol_amd.modeling.transformer',
+        'lib.modeling.svanet_variants': 'svol_amd.modeling.svanet_variants',
+        'lib.modeling.sketch_detr': 'svol_amd.modeling.sketch_detr',
         'lib.modeling.matcher': 'svol_amd.modeling.matcher',
         'lib.modeling.loss': 'svol_amd.modeling.loss',
         'lib.utils': 'svol_amd.utils',

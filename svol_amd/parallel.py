@@ -141,11 +141,16 @@ class BucketedGradAllReduce:
 
 
 def unused_parameters(model: torch.nn.Module):
-    """Parameters of the SVANet head that never receive a gradient (reference: grad None):
-    the gate MHA's out_proj (only its attention WEIGHTS are used) and the unused ``class_head``."""
+    """Parameters that never receive a gradient (reference: grad None): the SVANet gate MHA's out_proj
+    (only its attention WEIGHTS are used), the unused ``class_head``, and — svanet_variants — the input projections of
+    the fusion modes the model was not built for."""
+    mode = getattr(model, 'mode', None) or getattr(getattr(model, 'head', None), 'mode', None)
+    dead = {'concat_to_seq': ('input_sketch_proj', 'input_video_proj', 'input_query_proj'),
+            'append_to_seq': ('input_proj.', 'input_query_proj'),
+            'concat_to_qry': ('input_proj.', 'input_sketch_proj')}.get(mode, ())
     out = []
     for name, p in model.named_parameters():
-        if 'sketch_video_cross_attn.out_proj' in name or 'class_head' in name:
+        if 'sketch_video_cross_attn.out_proj' in name or 'class_head' in name or any(d in name for d in dead):
             out.append(p)
     return out
 
