@@ -41,6 +41,7 @@ extern "C" {
 #define SVOL_ACT_RELU 1
 #define SVOL_ACT_GELU 2    /* exact erf GELU: cross_modal_transformer.py:189-190 */
 #define SVOL_ACT_SIGMOID 3 /* svanet.py:127 */
+#define SVOL_ACT_RELU_RES 4 /* relu(A*B^T + bias + residual): the ReLU AFTER the identity add of a ResNet BasicBlock (svol_gemm_nt only) */
 
 int svol_abi_version(void);
 const char* svol_strerror(int code);
@@ -229,6 +230,20 @@ int svol_patchify(const float* pixel_values, void* out, int64_t n, int64_t C, in
  * x32 [n, P+1, D] fp32 residual stream; x (dtype, may be NULL) its compute-dtype copy. */
 int svol_vit_embed(const float* patch_proj, const float* cls_token, const float* pos_embed, float* x32, void* x, int64_t n,
                    int64_t P, int64_t D, int dtype, void* stream);
+/* ---- convolutional backbone pieces (torchvision ResNet-18/34, backbone.py:65-89,133-152) --------------
+ * A convolution is svol_im2col followed by svol_gemm_nt (weights [Cout, kh*kw*Cin] in (ky, kx, c) order with the eval-mode
+ * BatchNorm scale folded in, BatchNorm shift as bias, SVOL_ACT_RELU / SVOL_ACT_RELU_RES epilogue); activations are NHWC.
+ * cols[(n,ho,wo), (ky,kx,c)] = x[n, ho*stride-pad+ky, wo*stride-pad+kx, c] (0 outside the image); columns kh*kw*C .. ldcols-1
+ * are zero-filled.  x is addressed by element strides (sn, sh, sw, sc), so NCHW pixel tensors and NHWC activations both fit;
+ * src_dtype / dtype: element types of x / cols (fp32 -> bf16 conversion happens here for the stem). */
+int svol_im2col(const void* x, int64_t sn, int64_t sh, int64_t sw, int64_t sc, int src_dtype, void* cols, int64_t ldcols,
+                int64_t N, int64_t H, int64_t W, int64_t C, int64_t kh, int64_t kw, int64_t stride, int64_t pad, int dtype,
+                void* stream);
+/* nn.MaxPool2d(k, stride, pad) on NHWC activations, C % 8 == 0 (resnet stem: 3, 2, 1). */
+int svol_maxpool_nhwc(const void* x, void* y, int64_t N, int64_t H, int64_t W, int64_t C, int64_t k, int64_t stride,
+                      int64_t pad, int dtype, void* stream);
+/* nn.AdaptiveAvgPool2d(1) on NHWC activations: y[n, c] (fp32) = mean over the HW positions. */
+int svol_avgpool_nhwc(const void* x, float* y, int64_t N, int64_t HW, int64_t C, int dtype, void* stream);
 /* att[B,Lq,Lk] (fp32) = 1/H * sum_h softmax_l(q_h k_h^T * scale + kbias): the head-averaged attention weights that
  * nn.MultiheadAttention returns with need_weights=True and the reference's TransformerDecoder stacks per layer
  * (transformer.py:139-152, 258-262).  Recomputed from q, k (layouts as svol_attn_fwd, q_premul as there) and the

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs p) {
                 else if (p.act == SVOL_ACT_GELU) v = gelu_f(v);
                 else if (p.act == SVOL_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
                 if (res) v += to_f32(res[(int64_t)m * p.ldr + n]);
+                if (p.act == SVOL_ACT_RELU_RES) v = fmaxf(v, 0.f);
                 C[(int64_t)m * p.ldc + n] = from_f32<TC>(v);
             }
         }

@@ -195,6 +195,10 @@ __device__ __forceinline__ void gemm_nt_bf16_body(const FastArgs& p) {
                                 if (ncol + e < p.N) v[e] += to_f32(R[(int64_t)m * p.ldr + ncol + e]);
                         }
                     }
+                    if (p.act == SVOL_ACT_RELU_RES) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
                 } else {  // epi 1: v = acc * gelu'(aux), column sums of v
                     if (colv) {
                         const f32x4 a = Out4<bf16_t>::load(p.aux + (int64_t)m * p.ldaux + ncol);
@@ -335,6 +339,10 @@ __device__ __forceinline__ void gemm_nt_bf16_skinny_body(const FastArgs& p) {
                 const f32x4 r0 = Out4<TC>::load(R), r1 = Out4<TC>::load(R + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+            }
+            if (p.act == SVOL_ACT_RELU_RES) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
         }
     } else {  // epi 1: v = acc * gelu'(aux), column sums of v

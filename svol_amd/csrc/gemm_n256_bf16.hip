@@ -181,6 +181,10 @@ __device__ __forceinline__ void gemm_n256_body(const N256Args& p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
                 }
+                if (p.act == SVOL_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
@@ -202,7 +206,7 @@ int svol_gemm_n256_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, 
     static const bool off = getenv("SVOL_GEMM_NO_N256") != nullptr;
     if (off || N % BN || K % BK || K < 512 || M < 4096) return SVOL_E_UNSUPPORTED;
     if (epi != 0 || pre || colscale) return SVOL_E_UNSUPPORTED;
-    if (act != SVOL_ACT_NONE && (act != SVOL_ACT_GELU || out_f32)) return SVOL_E_UNSUPPORTED;
+    if (act != SVOL_ACT_NONE && ((act != SVOL_ACT_GELU && act != SVOL_ACT_RELU) || out_f32)) return SVOL_E_UNSUPPORTED;
     if (res && !out_f32) return SVOL_E_UNSUPPORTED;
     auto al16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
     if (lda % 8 || ldw % 8 || !al16(A) || !al16(W) || !al16(C)) return SVOL_E_UNSUPPORTED;

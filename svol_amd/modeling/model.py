@@ -4,7 +4,7 @@
 src_video_mask)`` keep the reference's signatures and the ``backbone.`` / ``head.`` state-dict
 prefixes.  ``--backbone features`` plugs pre-extracted features in at the measured boundary (SURVEY.md D3);
 ``--backbone vit`` runs the ViT-B/16 extractor of ``backbone.py`` on the device for every frame and the sketch
-(SURVEY.md §8 f1); the torchvision ResNets (f4) raise instead of silently running something else.
+(SURVEY.md §8 f1); ``--backbone resnet`` the ResNet-34 / ResNet-18 extractors of ``resnet.py`` (f4), both frozen.
 """
 from __future__ import annotations
 
@@ -37,9 +37,15 @@ def build_backbone(args):
         # the pretrained google/vit-base-patch16-224-in21k weights are loaded by the caller
         # (ViTExtractor.load_hf_state_dict); nothing is downloaded here
         return ViTBackbone(ViTExtractor(vit_base_config()), ViTExtractor(vit_base_config()))
-    raise NotImplementedError(
-        f"backbone '{args.backbone}' (torchvision ResNet-18/34 with downloaded weights) is not part of the MI355X "
-        "build yet (SURVEY.md §8 f4); use --backbone features with pre-extracted features, or --backbone vit")
+    if 'resnet' in args.backbone:  # backbone.py:133-152: ResNet-34 on the frames (7x7 tokens), ResNet-18 + avgpool on the sketch
+        from .resnet import ResNetBackbone, resnet18, resnet34
+        args.input_vid_dim = 512
+        args.input_skch_dim = 512
+        cd = getattr(args, 'compute_dtype', 'bf16')
+        # frozen / inference only; the torchvision IMAGENET1K_V1 weights are loaded by the caller (load_state_dict with the
+        # reference's backbone.* keys) — nothing is downloaded here
+        return ResNetBackbone(resnet34(compute_dtype=cd), resnet18(avgpool=True, compute_dtype=cd))
+    raise NotImplementedError(f"backbone '{args.backbone}' is not part of the MI355X build (the reference has it commented out)")
 
 
 class SketchLocalizationModel(nn.Module):

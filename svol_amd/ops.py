@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_RELU_RES = 0, 1, 2, 3, 4
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 
 
@@ -271,6 +271,33 @@ def attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias=None, pre
                                   ws.numel() * 4 if ws is not None else 0, _dt(q), _stream())
     timer.stop(tok)
     _lib.check(rc, 'svol_attn_bwd')
+
+
+def im2col(x, N, H, W, C, kh, kw, stride, pad, dtype, strides=None, ldcols=None):
+    """x: image batch addressed by element `strides` (sn, sh, sw, sc) — default NHWC contiguous — -> (cols [N*Ho*Wo, ldcols]
+    in `dtype`, Ho, Wo); column order (ky, kx, c), zero padding outside the image and in columns >= kh*kw*C."""
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    K = kh * kw * C
+    ldcols = K if ldcols is None else ldcols
+    sn, sh, sw, sc = strides if strides is not None else (H * W * C, W * C, C, 1)
+    cols = torch.empty((N * Ho * Wo, ldcols), dtype=dtype, device=x.device)
+    rc = _lib.lib().svol_im2col(_ptr(x), sn, sh, sw, sc, _dt(x), _ptr(cols), ldcols, N, H, W, C, kh, kw, stride, pad, _DT[dtype],
+                                _stream())
+    _lib.check(rc, 'svol_im2col')
+    return cols, Ho, Wo
+
+
+def maxpool_nhwc(x, N, H, W, C, k, stride, pad):
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y = torch.empty((N * Ho * Wo, C), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().svol_maxpool_nhwc(_ptr(x), _ptr(y), N, H, W, C, k, stride, pad, _dt(x), _stream()), 'svol_maxpool_nhwc')
+    return y, Ho, Wo
+
+
+def avgpool_nhwc(x, N, HW, C):
+    y = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().svol_avgpool_nhwc(_ptr(x), _ptr(y), N, HW, C, _dt(x), _stream()), 'svol_avgpool_nhwc')
+    return y
 
 
 def attn_weights_mean(q, k, lse2, B, H, Lq, Lk, dh, kbias=None, premul=0.0):

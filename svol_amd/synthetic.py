@@ -334,3 +334,55 @@ def synth_encdec_inputs(args, B: int, L: int, Ls: int = 1, seed: int = 1, pad: i
 def synth_probe(shape, key: str, seed: int = 1) -> torch.Tensor:
     """fixed N(0,1) weights of the linear functional  sum(output * probe)  the gradient fixtures differentiate."""
     return torch.from_numpy(_rs('probe/' + key, seed).standard_normal(tuple(shape)).astype(np.float32))
+
+
+# ----------------------------------------------------------------------------
+# ResNet extractor (SURVEY.md §8 f4)
+# ----------------------------------------------------------------------------
+def resnet_param_shapes(depths=(2, 2, 2, 2), widths=(64, 128, 256, 512), stem=64) -> "OrderedDict[str, tuple]":
+    """state-dict keys / shapes of ``nn.Sequential(*list(torchvision resnet.children())[:-2])`` (BasicBlock nets)."""
+    sh = OrderedDict()
+
+    def bn(p, c):
+        for k in ('weight', 'bias', 'running_mean', 'running_var'):
+            sh[f'{p}.{k}'] = (c,)
+        sh[f'{p}.num_batches_tracked'] = ()
+
+    sh['0.weight'] = (stem, 3, 7, 7)
+    bn('1', stem)
+    inp = stem
+    for li, (n, planes) in enumerate(zip(depths, widths)):
+        for bi in range(n):
+            p = f'{4 + li}.{bi}'
+            stride = (1 if li == 0 else 2) if bi == 0 else 1
+            sh[p + '.conv1.weight'] = (planes, inp, 3, 3)
+            bn(p + '.bn1', planes)
+            sh[p + '.conv2.weight'] = (planes, planes, 3, 3)
+            bn(p + '.bn2', planes)
+            if stride != 1 or inp != planes:
+                sh[p + '.downsample.0.weight'] = (planes, inp, 1, 1)
+                bn(p + '.downsample.1', planes)
+            inp = planes
+    return sh
+
+
+def synth_resnet_state_dict(shapes, seed: int = 1) -> "OrderedDict[str, torch.Tensor]":
+    """He-uniform convolutions, BatchNorm weight ~ 1 (0.5 on a block's second norm, which keeps the residual stream O(1)
+    through 16 blocks), small shifts / running means, running variances in [0.8, 1.2]."""
+    sd = OrderedDict()
+    for k, shp in shapes.items():
+        r = _rs('resnet/' + k, seed)
+        if k.endswith('num_batches_tracked'):
+            sd[k] = torch.zeros((), dtype=torch.int64)
+            continue
+        if len(shp) == 4:
+            a = float(np.sqrt(6.0 / (shp[1] * shp[2] * shp[3])))
+            v = r.uniform(-a, a, size=shp)
+        elif k.endswith('running_var'):
+            v = r.uniform(0.8, 1.2, size=shp)
+        elif k.endswith('running_mean') or k.endswith('bias'):
+            v = r.uniform(-0.1, 0.1, size=shp)
+        else:  # BatchNorm weight
+            v = (0.5 if '.bn2.' in k else 1.0) + r.uniform(-0.1, 0.1, size=shp)
+        sd[k] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+    return sd
