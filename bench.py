@@ -82,11 +82,12 @@ def main():
                          'but a captured graph serialises the query-stream / video-stream overlap: measured slower)')
     ap.add_argument('--no-graph', action='store_true', help='accepted for compatibility (eager is the default)')
     ap.add_argument('--batch', type=int, default=None, help='videos per GPU (default: 8, cfg5: 1)')
-    ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg4', 'cfg5', 'encdec'],
+    ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg4', 'cfg5', 'encdec', 'resnet'],
                     help='cfg2 = the BASELINE metric workload (default); cfg4 = cfg2 with the ViT-B/16 frame + sketch feature '
                          'extractor run online in front of the head (BASELINE configs[3], end-to-end frames/s); '
                          'cfg5 = long-video stress case T=128, P=256 (bf16); encdec = the cfg2 shapes through the 6+6 enc/dec Transformer '
-                         '(svanet_variants, append_to_seq) instead of the cross-modal transformer')
+                         '(svanet_variants, append_to_seq) instead of the cross-modal transformer; resnet = the reference\'s default backbone '
+                         '(frozen ResNet-34 on the frames -> 49 tokens each, ResNet-18 on the sketch) online in front of the head')
     a = ap.parse_args()
 
     import torch
@@ -114,7 +115,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
 
-    T, P = (128, 256) if a.workload == 'cfg5' else (32, 196)
+    T, P = (128, 256) if a.workload == 'cfg5' else (32, 49 if a.workload == 'resnet' else 196)
     B = a.batch if a.batch is not None else (1 if a.workload == 'cfg5' else 8)
     args = syn.head_args(num_frames=T) if a.workload == 'cfg5' else syn.cfg2_args('video_matcher')
     if a.workload == 'cfg4':
@@ -145,6 +146,17 @@ def main():
         # normalised pixel values; the extractor runs inside the timed step
         from svol_amd.modeling.backbone import ViTBackbone, ViTExtractor, vit_base_config
         backbone = ViTBackbone(ViTExtractor(vit_base_config()), ViTExtractor(vit_base_config())).to(dev).eval()
+        g = torch.Generator(device=dev).manual_seed(1 + rank)
+        pix_video = torch.randn((B, T, 3, 224, 224), device=dev, generator=g)
+        pix_sketch = torch.randn((B, 1, 3, 224, 224), device=dev, generator=g)
+    if a.workload == 'resnet':
+        # frozen, randomly initialised torchvision-layout ResNets (IMAGENET1K_V1 cannot be downloaded here), synthetic pixels;
+        # the extractors run inside the timed step (backbone.py:133-152: ResNet-34 frames, ResNet-18 + avgpool sketch)
+        from svol_amd.modeling.resnet import ResNetBackbone, resnet18, resnet34
+        backbone = ResNetBackbone(resnet34(compute_dtype=a.dtype), resnet18(avgpool=True, compute_dtype=a.dtype))
+        backbone.video_backbone.load_state_dict(syn.synth_resnet_state_dict(syn.resnet_param_shapes((3, 4, 6, 3)), seed=1))
+        backbone.sketch_backbone.load_state_dict(syn.synth_resnet_state_dict(syn.resnet_param_shapes((2, 2, 2, 2)), seed=2))
+        backbone = backbone.to(dev).eval()
         g = torch.Generator(device=dev).manual_seed(1 + rank)
         pix_video = torch.randn((B, T, 3, 224, 224), device=dev, generator=g)
         pix_sketch = torch.randn((B, 1, 3, 224, 224), device=dev, generator=g)
@@ -217,7 +229,8 @@ def main():
     attn_fwd_flop = 4.0 * L * L * args.hidden_dim * B          # QK^T + PV  (4 L^2 d per sample)
     # SURVEY.md §8d table; cfg4 adds the extractor forward: 2*197*(768*768*4 + 2*768*3072)*12 + attention ~ 35.1 GF per
     # image, (B*T + B) images per B*T frames
-    gf_frame = {'cfg2': FWD_BWD_GF_PER_FRAME, 'cfg5': 169.3, 'cfg4': FWD_BWD_GF_PER_FRAME * 1.24 + 35.1 * (T + 1) / T,
+    gf_frame = {'cfg2': FWD_BWD_GF_PER_FRAME, 'resnet': 0.0,  # (no closed form quoted: conv FLOPs 7.3 GF/frame + the head at L = 1568)
+                'cfg5': 169.3, 'cfg4': FWD_BWD_GF_PER_FRAME * 1.24 + 35.1 * (T + 1) / T,
                 # enc/dec, per sample forward: input proj + 6 x (8Ld^2 + 4L^2d + 4LdF) encoder + 6 x (4Ld^2 K/V proj + 4NLd) decoder
                 # memory side (query-side terms < 1 %), x3 for fwd+bwd, / T frames; L = T*P + 1, F = 1024
                 'encdec': 3.0 * (2 * L * 512 * 256 + 2 * L * 256 * 256 + 6 * (8 * L * 256 ** 2 + 4 * L * L * 256 + 4 * L * 256 * 1024)
@@ -244,12 +257,12 @@ def main():
             'dtype': a.dtype, 'data': 'synthetic',
             'config': {'workload': ('enc/dec Transformer head (svanet_variants append_to_seq, 6 + 6 layers, post-norm, F=1024) on the '
                                     'BASELINE configs[1] shapes' if a.workload == 'encdec' else 'BASELINE configs[%d]: SVANet head' %
-                                    {'cfg2': 1, 'cfg4': 3, 'cfg5': 4}[a.workload]) + (
+                                    {'cfg2': 1, 'cfg4': 3, 'cfg5': 4, 'resnet': 1}[a.workload]) + (
                                    ' + Hungarian/GIoU criterion, B=%d/GPU, T=%d, P=%d, '
                                    'd=256, h=8, 6 layers, N=100, video_matcher, Din=%d, train mode; step = fwd + '
                                    'criterion + bwd (+RCCL grad all-reduce) + AdamW' % (B, T, P, args.input_vid_dim)) + (
                                        '; ViT-B/16 extractor (random init, frozen) on all %d frames + %d sketches inside the step' % (B * T, B)
-                                       if a.workload == 'cfg4' else ''),
+                                       if a.workload == 'cfg4' else ('; frozen ResNet-34 (frames, 7x7 tokens) + ResNet-18 (sketch) extractors inside the step' if a.workload == 'resnet' else '')),
                        'global_batch': B * world, 'parallelism': f'dp{world}'},
             'final_loss': final_loss,
             'launch_mode': 'hipGraph replay (whole step captured)' if use_graph else 'eager',

@@ -30,6 +30,45 @@ __global__ void im2col_generic_kernel(const TS* __restrict__ x, int64_t sn, int6
     cols[i] = from_f32<TD>(v);
 }
 
+// The stem: few channels (C <= 4), any source strides (NCHW fp32 pixels).  A workgroup owns WT consecutive output positions of
+// one output row: the kh input rows they touch are staged in LDS with reads that run along the image row (coalesced in the
+// source), then the WT destination rows are written as 16-byte chunks (coalesced in the destination).
+constexpr int STEM_WT = 32;
+template <typename TS>
+__global__ __launch_bounds__(256) void im2col_stem_kernel(const TS* __restrict__ x, int64_t sn, int64_t sh, int64_t sw, int64_t sc,
+                                                           bf16_t* __restrict__ cols, int64_t ldcols, int H, int W, int C, int kh,
+                                                           int kw, int stride, int pad, int Ho, int Wo) {
+    extern __shared__ float tile[];  // [C][kh][span]
+    const int span = (STEM_WT - 1) * stride + kw;
+    const int wo0 = blockIdx.x * STEM_WT, ho = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const int wi0 = wo0 * stride - pad, hi0 = ho * stride - pad;
+    for (int i = threadIdx.x; i < C * kh * span; i += 256) {
+        const int xx = i % span, ky = (i / span) % kh, c = i / (span * kh);
+        const int hi = hi0 + ky, wi = wi0 + xx;
+        tile[i] = (hi >= 0 && hi < H && wi >= 0 && wi < W) ? to_f32(x[n * sn + hi * sh + wi * sw + c * sc]) : 0.f;
+    }
+    __syncthreads();
+    const int K = kh * kw * C;
+    const int chunks = (int)(ldcols / 8);
+    for (int j = threadIdx.x; j < STEM_WT * chunks; j += 256) {
+        const int r = j / chunks, k8 = (j - r * chunks) * 8;
+        if (wo0 + r >= Wo) continue;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k8 + e;
+            float v = 0.f;
+            if (k < K) {
+                const int c = k % C, kx = (k / C) % kw, ky = k / (C * kw);
+                v = tile[(c * kh + ky) * span + r * stride + kx];
+            }
+            o[e] = (bf16_t)v;
+        }
+        *reinterpret_cast<bf16x8*>(cols + ((n * Ho + ho) * (int64_t)Wo + wo0 + r) * ldcols + k8) = o;
+    }
+}
+
 // NHWC contiguous source, C % 8 == 0 (bf16) / C % 4 == 0 (fp32): one 16-byte chunk per thread, consecutive threads walk
 // c, then kx, then ky of one output position (contiguous in the destination row)
 template <typename T>
@@ -131,6 +170,21 @@ extern "C" int svol_im2col(const void* x, int64_t sn, int64_t sh, int64_t sw, in
         }
         SVOL_CHECK_LAUNCH();
         return SVOL_OK;
+    }
+    if (dtype == SVOL_BF16 && C <= 4 && ldcols % 8 == 0 && aligned16(cols) && Ho <= 65535 && N <= 65535) {
+        const size_t sh_bytes = (size_t)C * kh * ((STEM_WT - 1) * stride + kw) * sizeof(float);
+        if (sh_bytes <= 64 * 1024) {
+            const dim3 gs((unsigned)((Wo + STEM_WT - 1) / STEM_WT), (unsigned)Ho, (unsigned)N);
+            if (src_dtype == SVOL_F32)
+                hipLaunchKernelGGL(im2col_stem_kernel<float>, gs, dim3(256), sh_bytes, s, (const float*)x, sn, sh, sw, sc, (bf16_t*)cols,
+                                   ldcols, (int)H, (int)W, (int)C, (int)kh, (int)kw, (int)stride, (int)pad, (int)Ho, (int)Wo);
+            else if (src_dtype == SVOL_BF16)
+                hipLaunchKernelGGL(im2col_stem_kernel<bf16_t>, gs, dim3(256), sh_bytes, s, (const bf16_t*)x, sn, sh, sw, sc, (bf16_t*)cols,
+                                   ldcols, (int)H, (int)W, (int)C, (int)kh, (int)kw, (int)stride, (int)pad, (int)Ho, (int)Wo);
+            else return SVOL_E_INVALID;
+            SVOL_CHECK_LAUNCH();
+            return SVOL_OK;
+        }
     }
     const dim3 g(nblk(rows * ldcols));
 #define SVOL_I2C(TS, TD)                                                                                                             \
