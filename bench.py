@@ -167,7 +167,7 @@ def main():
             inp['src_sketch'], inp['src_video'] = backbone(pix_sketch, pix_video)
         out = model(inp['src_sketch'], inp['src_sketch_mask'], inp['src_video'], inp['src_video_mask'])
         ld = crit(out, tg)
-        loss = sum(ld[k] * wd[k] for k in ld.keys() if k in wd)  # train.py:227-228
+        loss = crit.weighted_total()  # = sum(ld[k] * wd[k] for k in ld if k in wd) (train.py:227-228), one multiply + one reduction
         loss.backward()
         reducer.finish()
         opt.step()

@@ -75,6 +75,45 @@ __device__ __forceinline__ int wave_max_i(int x) {
     return x;
 }
 
+// (value, preference key) arg-min over the wave in ONE butterfly: smaller value wins, ties go to the LARGER key.  The four
+// intra-row steps are DPP lane permutations (quad xor 1 / xor 2, row_half_mirror, row_mirror: no LDS traffic, a few cycles
+// each), the xor-16 step is the one remaining ds_bpermute round trip and the xor-32 step is v_permlane32_swap; every lane
+// ends up with the wave's winner.  (Three __shfl_xor reductions — a double min, an int max, an int min = 24 dependent
+// ds_bpermutes — were 0.3 ms of this kernel's 0.55 ms critical path at the benchmark size.)
+struct MinKey { double s; int key; };
+__device__ __forceinline__ MinKey better(const MinKey a, const MinKey b) { return (b.s < a.s || (b.s == a.s && b.key > a.key)) ? b : a; }
+template <int CTRL>
+__device__ __forceinline__ MinKey dpp_step(const MinKey a) {
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, a.s);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)bits, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(bits >> 32), CTRL, 0xf, 0xf, false);
+    MinKey o;
+    o.s = __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+    o.key = __builtin_amdgcn_mov_dpp(a.key, CTRL, 0xf, 0xf, false);
+    return better(a, o);
+}
+__device__ __forceinline__ MinKey wave_argmin(MinKey a) {
+    a = dpp_step<0xB1>(a);   // quad_perm [1,0,3,2]
+    a = dpp_step<0x4E>(a);   // quad_perm [2,3,0,1]
+    a = dpp_step<0x141>(a);  // row_half_mirror: quads 0<->1, 2<->3 (every lane of a quad already holds the quad's winner)
+    a = dpp_step<0x140>(a);  // row_mirror: halves of the 16-lane row
+    MinKey o;
+    o.s = __shfl_xor(a.s, 16, 64);
+    o.key = __shfl_xor(a.key, 16, 64);
+    a = better(a, o);
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, a.s);
+    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)bits, (unsigned)bits, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)(bits >> 32), (unsigned)(bits >> 32), false, false);
+    const auto k = __builtin_amdgcn_permlane32_swap((unsigned)a.key, (unsigned)a.key, false, false);
+    // permlane32_swap(x, x) returns {lanes 0-31 of x | lanes 0-31 of x} and {lanes 32-63 | lanes 32-63}: both halves of the wave
+    MinKey p0, p1;
+    p0.s = __builtin_bit_cast(double, ((unsigned long long)h[0] << 32) | l[0]);
+    p0.key = (int)k[0];
+    p1.s = __builtin_bit_cast(double, ((unsigned long long)h[1] << 32) | l[1]);
+    p1.key = (int)k[1];
+    return better(p0, p1);
+}
+
 __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost, const int64_t* __restrict__ cost_off,
                                                   const int32_t* __restrict__ pred_off, const int32_t* __restrict__ pred_cnt,
                                                   const int32_t* __restrict__ tgt_off, const int32_t* __restrict__ tgt_cnt,
@@ -151,10 +190,15 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost
                     if (una) last_una = it;
                 }
             }
-            const double gmin = wave_min_d(lmin);
-            const int best_una = wave_max_i(lmin == gmin ? last_una : -1);
-            const int best_first = wave_min_i(lmin == gmin ? first_it : 0x7fffffff);
-            const int index = best_una >= 0 ? best_una : best_first;
+            // scipy's rule over the remaining columns: lowest cost; among equal costs the LAST unassigned column visited,
+            // else the FIRST column visited.  Per lane that is (lmin, last_una >= 0 ? last_una : first_it); the key makes
+            // any unassigned candidate beat any assigned one, larger `it` better among the former, smaller among the latter.
+            MinKey mk;
+            mk.s = lmin;
+            mk.key = last_una >= 0 ? 0x40000000 + last_una : 0x3fffffff - min(first_it, 0x3fffffff);
+            mk = wave_argmin(mk);
+            const double gmin = mk.s;
+            const int index = mk.key >= 0x40000000 ? mk.key - 0x40000000 : 0x3fffffff - mk.key;
             min_val = gmin;
             if (min_val == INFINITY) {  // infeasible
                 if (lane == 0) status[p] = 2;

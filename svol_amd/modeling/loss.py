@@ -34,14 +34,22 @@ class SetCriterion(nn.Module):
                 raise AssertionError(f'do you really want to compute {l_} loss?')
         self.last_match = None
         self.last_packed = None
+        self.last_losses = None
         # optional StaticPackedTargets (svol_amd.graph): when set, `targets` passed to forward() are ignored and
         # the pre-loaded static buffers are used (hipGraph capture / replay)
         self.static_packed = None
 
     def forward(self, outputs, targets):
-        if self.sketch_head == 'sketch_detr':
-            raise NotImplementedError('sketch_detr is not constructible from the reference option surface '
-                                      '(SURVEY.md D1); only the svanet criterion path is built')
+        if self.sketch_head == 'sketch_detr':  # loss.py:133-134,159-190: the same criterion on every per-frame output dict
+            packed = None
+            res = []
+            for o in outputs:
+                ld, packed = self._forward_one(o, targets, packed)
+                res.append(ld)
+            return res
+        return self._forward_one(outputs, targets, None)[0]
+
+    def _forward_one(self, outputs, targets, packed):
         if '_svol_stacked' in outputs:
             logits_all, boxes_all = outputs['_svol_stacked']
         else:  # a hand-made outputs dict: aux layers first, last layer last (svanet.py:128-137 order)
@@ -52,10 +60,11 @@ class SetCriterion(nn.Module):
             raise RuntimeError('svol_amd.SetCriterion runs on the MI355X only (no CPU fallback)')
         NL, B, N = logits_all.shape[:3]
         m = self.matcher
-        packed = self.static_packed if self.static_packed is not None else m.pack(targets, NL, B, N, logits_all.device)
+        if packed is None:
+            packed = self.static_packed if self.static_packed is not None else m.pack(targets, NL, B, N, logits_all.device)
         losses, match = ops.SetCriterionFn.apply(logits_all, boxes_all, packed, m.cost_bbox, m.cost_giou,
                                                  m.cost_class, self.eos_coef)
-        self.last_match, self.last_packed = match, packed
+        self.last_match, self.last_packed, self.last_losses = match, packed, losses
         out = {}
         names = []
         if 'labels' in self.losses:
@@ -70,7 +79,24 @@ class SetCriterion(nn.Module):
         for i in range(NL - 1):
             for col, name in names:
                 out[f'{name}_{i}'] = flat[i * 4 + col]
-        return out
+        return out, packed
+
+    def weighted_total(self):
+        """sum(loss_dict[k] * weight_dict[k] for k in loss_dict if k in weight_dict) (train.py:227-228) of the LAST forward,
+        as one multiply + one reduction over the [n_layers, 4] loss table instead of a Python sum over 3 * n_layers
+        0-d tensors (18 multiplies + 18 adds, and as many backward kernels, at 6 layers)."""
+        losses = self.last_losses
+        NL = losses.shape[0]
+        w = getattr(self, '_wtab', None)
+        if w is None or w.shape[0] != NL or w.device != losses.device:
+            cols = {'loss_label': 0, 'loss_bbox': 1, 'loss_giou': 2}
+            t = torch.zeros((NL, 4), dtype=torch.float32)
+            for name, col in cols.items():
+                t[NL - 1, col] = float(self.weight_dict.get(name, 0.0))
+                for i in range(NL - 1):
+                    t[i, col] = float(self.weight_dict.get(f'{name}_{i}', 0.0))
+            w = self._wtab = t.to(losses.device)
+        return (losses * w).sum()
 
     def last_indices(self):
         """Reference-format matcher indices of the last forward, per layer (synchronises)."""
