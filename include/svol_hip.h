@@ -132,7 +132,10 @@ int svol_posenc_sine(const float* mask, void* pos, int64_t B, int64_t L, int64_t
  * ws / ws_bytes: optional 16-byte aligned scratch (may be NULL / 0).  Launches with few queries and many keys
  * (the N = 100 object queries attending to L = 6272 video tokens: 64 workgroups on 256 CUs) are split over the
  * keys when the scratch is large enough — svol_attn_ws_bytes() says how much that takes; partial results are
- * merged by a small second kernel.  Nothing is allocated inside the library.
+ * merged by a small second kernel.  Launches with a key bias or a key count that is not a multiple of 128 and MANY queries
+ * use the scratch for one int per (batch, 128-key tile) — the tile's class: no bias / mixed / fully masked (skipped) — so
+ * that the fast kernels can serve them; without scratch such launches run on the general (slower) kernels.
+ * Nothing is allocated inside the library.
  * Replaces the core of nn.MultiheadAttention (cross_modal_transformer.py:139,147,154). */
 int64_t svol_attn_ws_bytes(int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t dh);
 int svol_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,

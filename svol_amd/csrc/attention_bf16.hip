@@ -40,6 +40,7 @@ struct Args {
     // tiles_per_split key tiles; partial results meet in the fp32 workspace
     int ksplit, tiles_per_split;
     float *ws_o, *ws_ml, *ws_dq;  // [ksplit][B*Lq][H*dh] unnormalised O | [ksplit][B][H][Lq][2] (m2, l) | [B*Lq][H*dh] dQ
+    const int* tile_flags;        // [B][ceil(Lk/KT)] key-tile classes of the masked fast kernels (attn_tile_flags_bf16)
 };
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
@@ -620,6 +621,163 @@ __device__ __forceinline__ f32x16 rows16(const float* v, int sub, int h) {
     return z;
 }
 
+// x as two bf16 (hi = rn(x), lo = rn(x - hi)) packed in one dword: |x - hi - lo| <= 2^-17 |x|
+__device__ __forceinline__ unsigned split_bf16x2(float x) {
+    const bf16_t hi = (bf16_t)x;
+    const float rem = x - (float)hi;
+    const bf16_t lo = (bf16_t)rem;
+    return (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+}
+
+// additive key bias in the log2 domain; keys past Lk are masked
+__device__ __forceinline__ float key_bias_log2(const float* kb, int key, int Lk) {
+    return key < Lk ? (kb ? kb[key] * LOG2E : 0.f) : -INFINITY;
+}
+// S (keys x queries, swapped product) += bias[key]: one more 16-deep MFMA contracts [bias_hi, bias_lo, 0...] (this lane's key) with
+// [1, 1, 0...] — the mixed tiles of the masked kernels pay one matrix instruction per 32x32 block and no vector work
+__device__ __forceinline__ f32x16 add_key_bias(const f32x16& S, const float* kb, int key, int Lk, int h) {
+    const float bv = key_bias_log2(kb, key, Lk);
+    const unsigned pair = bv == -INFINITY ? 0x0000FF80u : split_bf16x2(bv);  // (-inf, 0): x - hi would be NaN
+    const uint4 a = h == 0 ? make_uint4(pair, 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+    const uint4 o = h == 0 ? make_uint4(0x3F803F80u, 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, o), S, 0, 0, 0);
+}
+// flags[b][t] = 0 (the 128 keys of tile t all have zero bias), 2 (all at -inf or past Lk), 1 (anything else)
+__global__ __launch_bounds__(64) void attn_tile_flags_bf16(const float* __restrict__ kbias, int Lk, int nt, int* __restrict__ flags) {
+    const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const float* kb = kbias ? kbias + (int64_t)b * Lk : nullptr;
+    const float b0 = key_bias_log2(kb, t * KT + lane, Lk), b1 = key_bias_log2(kb, t * KT + 64 + lane, Lk);
+    int flag = 0;
+    if (__any(b0 != 0.f || b1 != 0.f)) flag = __all(b0 == -INFINITY && b1 == -INFINITY) ? 2 : 1;
+    if (lane == 0) flags[(int64_t)b * nt + t] = flag;
+}
+
+// MASKED: additive key bias and / or a key count that is not a multiple of the tile.  Every 128-key tile is classified once per
+// workgroup pass (two bias loads per lane, issued one tile ahead, and two ballots): all-zero bias -> the unmasked code path;
+// every key at -inf (padding, or past Lk) -> the tile is skipped outright; anything else -> the bias is staged in LDS and
+// added to the scores (16 adds per 32x32 block, only in the tiles that straddle a mask boundary).
+template <bool MASKED>
+__device__ __forceinline__ void attn_fwd_pre_body(const Args p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * IMG];
+    char* sK = smem;
+    char* sV = smem + 2 * IMG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, hh = blockIdx.y;
+    const int qrow = blockIdx.x * 128 + wave * 32 + r;
+    const bool qvalid = qrow < p.Lq;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
+    const float* kb = (MASKED && p.kbias) ? p.kbias + (int64_t)b * p.Lk : nullptr;
+
+    uint4 qb[2];
+    load_lane_block(qb, Q, p.ldq, qrow, qvalid, p.dh, h);
+    float m = 0.f, l = 0.f;       // m: running reference (log2 domain), scores enter the softmax as s - m
+    f32x16 O = zero16();
+    f32x16 Cm = zero16();         // -m in every accumulator register of this lane's query
+    bool started = false;         // the first tile that is not skipped anchors the reference
+
+    const int nt = MASKED ? (p.Lk + KT - 1) / KT : p.Lk / KT;  // unmasked: the launcher guarantees Lk % KT == 0
+    Stage sk, sv;
+    load_regs(sk, K, p.ldk, 0, p.Lk, p.dh, tid);
+    load_regs(sv, V, p.ldv, 0, p.Lk, p.dh, tid);
+    const int* fl = MASKED ? p.tile_flags + (int64_t)b * nt : nullptr;
+    unsigned long long mixed = 0, dead = 0;
+    store_lds(sK, sk, tid);
+    store_lds(sV, sv, tid);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            load_regs(sk, K, p.ldk, (t + 1) * KT, p.Lk, p.dh, tid);
+            load_regs(sv, V, p.ldv, (t + 1) * KT, p.Lk, p.dh, tid);
+        }
+        // tile classes as two 64-bit wave-uniform masks (SGPR pairs), refreshed every 64 tiles with one load per lane: a scalar
+        // load per tile would put an s_waitcnt lgkmcnt(0) — which also drains the LDS reads in flight — at the top of every tile
+        if (MASKED && (t & 63) == 0) {
+            const int f = (t + lane < nt) ? fl[t + lane] : 2;
+            mixed = __ballot(f == 1);
+            dead = __ballot(f == 2);
+        }
+        const int flag = MASKED ? (int)((mixed >> (t & 63)) & 1) + 2 * (int)((dead >> (t & 63)) & 1) : 0;  // 0 plain, 1 mixed, 2 skip
+        if (!MASKED || flag != 2) {
+            const char* kimg = sK + cur * IMG;
+            const char* vimg = sV + cur * IMG;
+            f32x16 S[4];
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                uint4 ka[2];
+                read_rows(ka, kimg, sub * 32 + r, h);
+                S[sub] = mma_first_c(ka, qb, Cm);  // = score - m
+            }
+            if (MASKED && flag == 1) {
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub) S[sub] = add_key_bias(S[sub], kb, t * KT + sub * 32 + r, p.Lk, h);
+            }
+            mfma_results_ready(S[0], S[1], S[2], S[3]);  // (after the bias products: max3 below is inline asm)
+            float ml[4];
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                float mm = max3(S[sub][0], S[sub][1], S[sub][2]);
+#pragma unroll
+                for (int i = 3; i < 15; i += 2) mm = max3(mm, S[sub][i], S[sub][i + 1]);
+                ml[sub] = max3(mm, S[sub][15], mm);
+            }
+            float mloc = max3(ml[0], ml[1], fmaxf(ml[2], ml[3]));
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc),
+                                                                 __builtin_bit_cast(unsigned, mloc), false, false);
+                mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+            }
+            const bool first = MASKED ? !started : (t == 0);
+            if (first || __any(mloc > LAZY_THR)) {  // wave-uniform
+                // first tile: anchor the reference at this tile's maximum (may move down); later: only upward moves
+                const float dm = first ? mloc : fmaxf(mloc, 0.f);
+                if (!first) {
+                    const float alpha = __builtin_amdgcn_exp2f(-dm);
+                    l *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) O[i] *= alpha;
+                }
+                m += dm;
+                Cm = splat16(-m);
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) S[sub][i] -= dm;
+            }
+            started = true;
+            float ls[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    S[sub][i] = __builtin_amdgcn_exp2f(S[sub][i]);
+                    ls[sub] += S[sub][i];
+                }
+            l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                uint4 va[2];
+                read_tr(va, vimg, sub, lane);
+                mma_second(O, va, S[sub]);
+            }
+        }
+        if (t + 1 < nt) {
+            store_lds(sK + (cur ^ 1) * IMG, sk, tid);
+            store_lds(sV + (cur ^ 1) * IMG, sv, tid);
+        }
+        __syncthreads();
+    }
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    bf16_t* Oo = reinterpret_cast<bf16_t*>(p.out_o) + (int64_t)b * p.Lq * p.ldo + hh * p.dh;
+    store_acc(O, Oo, p.ldo, qrow, qvalid, p.dh, h, inv);
+    if (qvalid && h == 0) p.lse2[((int64_t)b * p.H + hh) * p.Lq + qrow] = m + __builtin_amdgcn_logf(lt);
+}
+// The unmasked kernel is kept as its own function: instantiating the template above with MASKED = false compiles to 174
+// VGPRs (2 waves per SIMD) instead of this body's 163 (3 waves), 4 % slower.
 __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_pre(Args p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * IMG];
     char* sK = smem;
@@ -719,10 +877,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_pre(Args p) {
     store_acc(O, Oo, p.ldo, qrow, qvalid, p.dh, h, inv);
     if (qvalid && h == 0) p.lse2[((int64_t)b * p.H + hh) * p.Lq + qrow] = m + __builtin_amdgcn_logf(lt);
 }
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_pre_masked(Args p) { attn_fwd_pre_body<true>(p); }
 
 // Two 32-query blocks per wave (256 queries per workgroup): every K / V fragment read from LDS feeds two MFMAs, and
 // a wave always has a second, independent MFMA -> exp -> MFMA chain to issue from while the first one waits.
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_pre(Args p) {
+template <bool MASKED>
+__device__ __forceinline__ void attn_bwd_dq_pre_body(const Args& p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * IMG];
     char* sK = smem;
     char* sV = smem + 2 * IMG;
@@ -749,10 +909,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_pre(Args p) {
         Cd[u] = splat16(qvalid[u] ? -p.delta[sidx] : 0.f);       // dP - delta
         dQ[u] = zero16();
     }
-    const int nt = p.Lk / KT;
+    const float* kb = (MASKED && p.kbias) ? p.kbias + (int64_t)b * p.Lk : nullptr;
+    const int nt = MASKED ? (p.Lk + KT - 1) / KT : p.Lk / KT;
     Stage sk, sv;
     load_regs(sk, K, p.ldk, 0, p.Lk, p.dh, tid);
     load_regs(sv, V, p.ldv, 0, p.Lk, p.dh, tid);
+    const int* fl = MASKED ? p.tile_flags + (int64_t)b * nt : nullptr;
+    unsigned long long mixed = 0, dead = 0;
     store_lds(sK, sk, tid);
     store_lds(sV, sv, tid);
     __syncthreads();
@@ -762,10 +925,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_pre(Args p) {
             load_regs(sk, K, p.ldk, (t + 1) * KT, p.Lk, p.dh, tid);
             load_regs(sv, V, p.ldv, (t + 1) * KT, p.Lk, p.dh, tid);
         }
+        if (MASKED && (t & 63) == 0) {  // tile classes as in the forward kernel
+            const int f = (t + lane < nt) ? fl[t + lane] : 2;
+            mixed = __ballot(f == 1);
+            dead = __ballot(f == 2);
+        }
+        const int flag = MASKED ? (int)((mixed >> (t & 63)) & 1) + 2 * (int)((dead >> (t & 63)) & 1) : 0;
         const char* kimg = sK + cur * IMG;
         const char* vimg = sV + cur * IMG;
 #pragma unroll 2
-        for (int sub = 0; sub < 4; ++sub) {
+        for (int sub = 0; sub < ((MASKED && flag == 2) ? 0 : 4); ++sub) {
             uint4 ka[2], va[2], kt[2];
             read_rows(ka, kimg, sub * 32 + r, h);
             read_rows(va, vimg, sub * 32 + r, h);
@@ -774,6 +943,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_pre(Args p) {
             const f32x16 dP0 = mma_first_c(va, dob[0], Cd[0]);
             const f32x16 dP1 = mma_first_c(va, dob[1], Cd[1]);
             read_tr(kt, kimg, sub, lane);
+            if (MASKED && flag == 1) {
+                S0 = add_key_bias(S0, kb, t * KT + sub * 32 + r, p.Lk, h);
+                S1 = add_key_bias(S1, kb, t * KT + sub * 32 + r, p.Lk, h);
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) S0[i] = __builtin_amdgcn_exp2f(S0[i]) * dP0[i];
             mma_second(dQ[0], kt, S0);
@@ -791,21 +964,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_pre(Args p) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) store_acc(dQ[u], dQo, p.lddq, qrow[u], qvalid[u], p.dh, h, p.scale);
 }
-
-// x as two bf16 (hi = rn(x), lo = rn(x - hi)) packed in one dword: |x - hi - lo| <= 2^-17 |x|
-__device__ __forceinline__ unsigned split_bf16x2(float x) {
-    const bf16_t hi = (bf16_t)x;
-    const float rem = x - (float)hi;
-    const bf16_t lo = (bf16_t)rem;
-    return (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
-}
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_pre(Args p) { attn_bwd_dq_pre_body<false>(p); }
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_pre_masked(Args p) { attn_bwd_dq_pre_body<true>(p); }
 
 // In this kernel the per-QUERY constants (-lse, -delta) run along the 16 accumulator registers of a lane (rows of
 // the score tile are queries), so as initial accumulators they cost four ds_read_b128 per product — half of the
 // loop's LDS traffic, and LDS was the busiest unit (rocprofv3 PMC: ~70 % of its bandwidth).  They ride the matrix
 // pipe instead: one more 16-deep MFMA per product contracts [hi, lo, 0...] (per query, one dword from LDS)
 // with [1, 1, 0...] (constant), i.e. adds -lse / -delta to every score of that query in fp32.
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_pre(Args p) {
+template <bool MASKED>
+__device__ __forceinline__ void attn_bwd_dkdv_pre_body(const Args& p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * IMG + 4 * KT * 4];
     char* sQ = smem;
     char* sdO = smem + 2 * IMG;
@@ -841,6 +1009,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_pre(Args p) {
         if (tid < KT) { sL[buf * KT + tid] = split_bf16x2(rl); sD[buf * KT + tid] = split_bf16x2(rd); }
     };
     const uint4 ones = h == 0 ? make_uint4(0x3F803F80u, 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);  // [1, 1, 0...]
+    // MASKED: the key bias is a per-LANE constant here (keys are the columns of the score tile).  It rides the same extra
+    // MFMA as -lse: the query side gets [hi, lo, 1, 1, 0...] and this key's side [1, 1, bias_hi, bias_lo, 0...] — no
+    // per-score instruction at all.  Keys past Lk get -inf (p = 0).  A wave whose 32 keys are all masked only helps staging.
+    float kbl = 0.f;
+    if (MASKED) kbl = kvalid ? (p.kbias ? p.kbias[(int64_t)b * p.Lk + krow] * LOG2E : 0.f) : -INFINITY;
+    const bool wave_dead = MASKED && __all(kbl == -INFINITY);
+    const unsigned kb_pair = kbl == -INFINITY ? 0x0000FF80u : split_bf16x2(kbl);  // (-inf, 0): x - hi would be NaN
+    const uint4 ones_s = (MASKED && h == 0) ? make_uint4(0x3F803F80u, kb_pair, 0u, 0u) : ones;
+    const unsigned q_one = MASKED ? 0x3F803F80u : 0u;
     load_regs(sq, Q, p.ldq, 0, p.Lq, p.dh, tid);
     load_regs(sdo, dO, p.lddo, 0, p.Lq, p.dh, tid);
     load_stats(0);
@@ -865,10 +1042,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_pre(Args p) {
         auto first_products = [&](int sub, f32x16& S, f32x16& dP) {
             uint4 a[2];
             // every lane loads its query's pair; for the h = 1 lanes (k = 8..15) `ones` is zero and the pair is finite
-            const uint4 el = make_uint4(nl[sub * 32 + r], 0u, 0u, 0u);
+            const uint4 el = make_uint4(nl[sub * 32 + r], q_one, 0u, 0u);
             const uint4 ed = make_uint4(nd[sub * 32 + r], 0u, 0u, 0u);
             read_rows(a, qimg, sub * 32 + r, h);
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, el), __builtin_bit_cast(bf16x8, ones),
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, el), __builtin_bit_cast(bf16x8, ones_s),
                                                         zero16(), 0, 0, 0);
             S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, kbk[0]), S, 0, 0, 0);
             S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, kbk[1]), S, 0, 0, 0);  // score - lse[q]
@@ -879,9 +1056,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_pre(Args p) {
             dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, vbk[1]), dP, 0, 0, 0);  // dO V^T - delta[q]
         };
         f32x16 S, dP, Sn, dPn;
-        first_products(0, S, dP);
+        if (!wave_dead) first_products(0, S, dP);
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
+        for (int sub = 0; sub < (wave_dead ? 0 : 4); ++sub) {
             if (sub + 1 < 4) first_products(sub + 1, Sn, dPn);
             uint4 a[2];
 #pragma unroll
@@ -906,6 +1083,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_pre(Args p) {
     store_acc(dK, dKo, p.lddk, krow, kvalid, p.dh, h, p.scale / p.premul);
     store_acc(dV, dVo, p.lddv, krow, kvalid, p.dh, h, 1.f);
 }
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_pre(Args p) { attn_bwd_dkdv_pre_body<false>(p); }
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_pre_masked(Args p) { attn_bwd_dkdv_pre_body<true>(p); }
 
 }  // namespace
 
@@ -930,8 +1109,14 @@ static int plan_ksplit(int B, int H, int Lq, int Lk, int dh, int64_t ws_floats, 
 int64_t svol_attn_ws_floats_bf16(int B, int H, int Lq, int Lk, int dh) {
     int tps;
     const int ks = plan_ksplit(B, H, Lq, Lk, dh, INT64_MAX, &tps);
-    if (ks < 2) return 0;
+    if (ks < 2) return (int64_t)B * ((Lk + KT - 1) / KT);  // key-tile classes of the masked fast kernels (one int each)
     return (int64_t)ks * B * Lq * H * dh + (int64_t)ks * B * H * Lq * 2 + (int64_t)B * Lq * H * dh;
+}
+// masked / ragged launches take the fast kernels when the key-split would not have been chosen anyway (enough query tiles to
+// fill the chip): the encoder self-attention of the enc/dec Transformer, video lengths that are not a multiple of 128
+static bool pre_masked_ok(int B, int H, int Lq, int Lk, int dh) {
+    int tps;
+    return plan_ksplit(B, H, Lq, Lk, dh, INT64_MAX, &tps) == 1;
 }
 static void bind_ws(Args& p, float* ws) {
     p.ws_o = ws;
@@ -947,12 +1132,20 @@ int svol_attn_fwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.dh = dh; p.scale = scale; p.premul = premul;
     const bool masked = kbias != nullptr || (Lk % KT) != 0;
-    const bool pre = !masked && premul != 0.f;
+    // pre-multiplied q: the fast kernels; masked launches with few queries keep the key-split path below
+    static const bool no_pre_masked = getenv("SVOL_ATTN_NO_PRE_MASKED") != nullptr;
+    const int ntk = (Lk + KT - 1) / KT;
+    const bool pre = premul != 0.f && (!masked || (!no_pre_masked && pre_masked_ok(B, H, Lq, Lk, dh) && ws &&
+                                                   ws_bytes >= (int64_t)B * ntk * 4));
     p.ksplit = (ws && !pre) ? plan_ksplit(B, H, Lq, Lk, dh, ws_bytes / 4, &p.tiles_per_split) : 1;
-    if (p.ksplit == 1) p.tiles_per_split = (Lk + KT - 1) / KT;
+    if (p.ksplit == 1) p.tiles_per_split = ntk;
     else bind_ws(p, ws);
     dim3 grid((unsigned)(((Lq + 127) / 128) * p.ksplit), (unsigned)H, (unsigned)B);
-    if (pre) hipLaunchKernelGGL(attn_fwd_bf16_pre, grid, dim3(256), 0, s, p);
+    if (pre && masked) {
+        p.tile_flags = reinterpret_cast<const int*>(ws);
+        hipLaunchKernelGGL(attn_tile_flags_bf16, dim3((unsigned)ntk, (unsigned)B), dim3(64), 0, s, kbias, Lk, ntk, reinterpret_cast<int*>(ws));
+        hipLaunchKernelGGL(attn_fwd_bf16_pre_masked, grid, dim3(256), 0, s, p);
+    } else if (pre) hipLaunchKernelGGL(attn_fwd_bf16_pre, grid, dim3(256), 0, s, p);
     else if (masked) hipLaunchKernelGGL(attn_fwd_bf16<true>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(attn_fwd_bf16<false>, grid, dim3(256), 0, s, p);
     if (p.ksplit > 1) {
@@ -974,15 +1167,23 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
     p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.dh = dh; p.scale = scale; p.premul = premul;
     const int64_t total = (int64_t)B * Lq * H;
     const bool masked = kbias != nullptr || (Lk % KT) != 0;
-    const bool pre = !masked && premul != 0.f;
+    static const bool no_pre_masked = getenv("SVOL_ATTN_NO_PRE_MASKED") != nullptr;
+    const int ntk = (Lk + KT - 1) / KT;
+    const bool pre = premul != 0.f && (!masked || (!no_pre_masked && pre_masked_ok(B, H, Lq, Lk, dh) && ws &&
+                                                   ws_bytes >= (int64_t)B * ntk * 4));
     p.ksplit = (ws && !pre) ? plan_ksplit(B, H, Lq, Lk, dh, ws_bytes / 4, &p.tiles_per_split) : 1;
-    if (p.ksplit == 1) p.tiles_per_split = (Lk + KT - 1) / KT;
+    if (p.ksplit == 1) p.tiles_per_split = ntk;
     else bind_ws(p, ws);
     dim3 gd((unsigned)((total + 255) / 256));
     dim3 gq((unsigned)(((Lq + 127) / 128) * p.ksplit), (unsigned)H, (unsigned)B);
     dim3 gk((unsigned)((Lk + 127) / 128), (unsigned)H, (unsigned)B);
     hipLaunchKernelGGL(attn_delta_bf16, gd, dim3(256), 0, s, p);
-    if (!masked && premul != 0.f) {
+    if (pre && masked) {
+        p.tile_flags = reinterpret_cast<const int*>(ws);
+        hipLaunchKernelGGL(attn_tile_flags_bf16, dim3((unsigned)ntk, (unsigned)B), dim3(64), 0, s, kbias, Lk, ntk, reinterpret_cast<int*>(ws));
+        hipLaunchKernelGGL(attn_bwd_dq_bf16_pre_masked, dim3((unsigned)((Lq + 255) / 256), (unsigned)H, (unsigned)B), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre_masked, gk, dim3(256), 0, s, p);
+    } else if (pre) {
         hipLaunchKernelGGL(attn_bwd_dq_bf16_pre, dim3((unsigned)((Lq + 255) / 256), (unsigned)H, (unsigned)B), dim3(256), 0, s, p);
         hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre, gk, dim3(256), 0, s, p);
     } else if (masked) {

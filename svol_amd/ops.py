@@ -238,17 +238,20 @@ def posenc_sine(mask_f32: torch.Tensor, D: int, dtype: torch.dtype) -> torch.Ten
     return pos
 
 
-def _attn_ws(q, B, H, Lq, Lk, dh):
-    """scratch for the key-split of few-query launches (None when the library would not split)."""
+def _attn_ws(q, B, H, Lq, Lk, dh, masked):
+    """scratch of the attention launches: partial results of the key-split (few queries, many keys) or the key-tile classes of
+    the masked fast kernels; None when the library needs none."""
     n = _lib.lib().svol_attn_ws_bytes(B, H, Lq, Lk, dh) if q.dtype == torch.bfloat16 else 0
-    return torch.empty((n // 4,), dtype=torch.float32, device=q.device) if n > 0 else None
+    if n <= 0 or (not masked and n == B * ((Lk + 127) // 128) * 4):
+        return None
+    return torch.empty((n // 4,), dtype=torch.float32, device=q.device)
 
 
 def attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias=None, premul=0.0):
     """q/k/v: 2-D [B*L, >=H*dh] views (column slices allowed). Returns o [B*Lq, H*dh], lse2 [B,H,Lq]."""
     o = torch.empty((B * Lq, H * dh), dtype=q.dtype, device=q.device)
     lse2 = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
-    ws = _attn_ws(q, B, H, Lq, Lk, dh)
+    ws = _attn_ws(q, B, H, Lq, Lk, dh, kbias is not None or Lk % 128 != 0)
     tok = timer.start('attn_fwd', (B, H, Lq, Lk, dh))
     rc = _lib.lib().svol_attn_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o),
                                   o.stride(0), _ptr(lse2), _ptr(kbias), B, H, Lq, Lk, dh, 1.0 / math.sqrt(dh),
@@ -262,7 +265,7 @@ def attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias=None, pre
     """Writes dq/dk/dv (2-D views, column slices allowed)."""
     do = do if do.stride(1) == 1 else do.contiguous()
     delta = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
-    ws = _attn_ws(q, B, H, Lq, Lk, dh)
+    ws = _attn_ws(q, B, H, Lq, Lk, dh, kbias is not None or Lk % 128 != 0)
     tok = timer.start('attn_bwd', (B, H, Lq, Lk, dh))
     rc = _lib.lib().svol_attn_bwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o),
                                   o.stride(0), _ptr(do), do.stride(0), _ptr(lse2), _ptr(delta), _ptr(kbias),
