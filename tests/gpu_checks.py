@@ -235,6 +235,9 @@ def check_small_ops():
             res[f'act_bwd/{dt}/act{act}'] = (rel_err(got, ref), TOL[dt])
         x32 = _rnd((1000,), torch.float32, 13)
         res[f'cast/{dt}'] = (rel_err(ops.cast(x32.to(DEV), dt), x32.to(dt)), 0.0)
+        for n in (1003, 8 * 4097):  # scalar tail path / the 8-per-thread vector path
+            xx = _rnd((n,), torch.float32, 14)
+            res[f'cast/{dt}/{n}'] = (rel_err(ops.cast(xx.to(DEV), dt), xx.to(dt)), 0.0)
     return res
 
 
