@@ -241,8 +241,22 @@ def main():
         which = 'attn_bwd (delta + dQ pass + dK/dV pass)' if bwd[1] >= fwd[1] else 'attn_fwd'
         flop, ms = (2.0 * attn_fwd_flop, bwd[1]) if bwd[1] >= fwd[1] else (attn_fwd_flop, fwd[1])
         ach = flop / (ms * 1e-3) / 1e12
+        # memory-side bytes per launch of the dominant kernel(s): from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+        # this very command (profiles/round1_hbm_traffic.json; separate counter runs cannot happen inside the timed process)
+        traffic = traffic_src = None
+        if a.workload == 'cfg2' and B == 8:
+            try:
+                tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'round1_hbm_traffic.json')))
+                pick = (['attn_bwd_dq_bf16_pre|', 'attn_bwd_dkdv_bf16_pre|', 'attn_delta_bf16|'] if bwd[1] >= fwd[1]
+                        else ['attn_fwd_bf16_pre|'])
+                tot = sum((v['read_MB'] + v['write_MB']) * 1048576.0 for k_, v in tj.items() if any(k_.startswith(q_) for q_ in pick))
+                if tot > 0:
+                    traffic, traffic_src = tot, 'profiles/round1_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)'
+            except (OSError, ValueError, KeyError):
+                pass
         roof = {'bound': 'mfma', 'kernel': which, 'achieved': ach, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ach / PEAK_BF16_MFMA_TFLOPS, 'traffic': None,
+                'frac': ach / PEAK_BF16_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes per launch (HBM side)',
+                'traffic_source': traffic_src,
                 'launch_ms': ms, 'launches_timed': bwd[0] if bwd[1] >= fwd[1] else fwd[0],
                 'attn_fwd_ms': fwd[1], 'attn_bwd_ms': bwd[1],
                 'attn_fwd_tflops': attn_fwd_flop / (fwd[1] * 1e-3) / 1e12,

@@ -41,6 +41,7 @@ struct Args {
     int ksplit, tiles_per_split;
     float *ws_o, *ws_ml, *ws_dq;  // [ksplit][B*Lq][H*dh] unnormalised O | [ksplit][B][H][Lq][2] (m2, l) | [B*Lq][H*dh] dQ
     const int* tile_flags;        // [B][ceil(Lk/KT)] key-tile classes of the masked fast kernels (attn_tile_flags_bf16)
+    int head_xcd, nxt;            // != 0: 1-D grid of B*H*nxt workgroups with the heads dealt to the 8 XCDs (block_coords)
 };
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
@@ -621,6 +622,26 @@ __device__ __forceinline__ f32x16 rows16(const float* v, int sub, int h) {
     return z;
 }
 
+// Workgroup -> (x tile, head, batch).  Every workgroup of one (batch, head) streams that head's whole K / V (or Q / dO): 0.8 MB
+// at L = 6272.  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so with the plain 3-D grid the tiles of a
+// head are spread over all eight L2s and every L2 sees every head in flight (measured: 0.56 GB memory-side reads per launch for
+// 0.05 GB of K / V).  With B*H a multiple of 8 the launchers use a 1-D grid instead: id % 8 = XCD, and each XCD walks its own
+// heads tile by tile, so a head's K / V is fetched into ONE L2.
+__device__ __forceinline__ void block_coords(const Args& p, int& xt, int& hh, int& b) {
+    if (p.head_xcd) {
+        const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+        const int hl = slot / p.nxt;
+        xt = slot - hl * p.nxt;
+        const int head = hl * 8 + xcd;
+        hh = head % p.H;
+        b = head / p.H;
+    } else {
+        xt = blockIdx.x;
+        hh = blockIdx.y;
+        b = blockIdx.z;
+    }
+}
+
 // x as two bf16 (hi = rn(x), lo = rn(x - hi)) packed in one dword: |x - hi - lo| <= 2^-17 |x|
 __device__ __forceinline__ unsigned split_bf16x2(float x) {
     const bf16_t hi = (bf16_t)x;
@@ -663,8 +684,9 @@ __device__ __forceinline__ void attn_fwd_pre_body(const Args p) {
     char* sV = smem + 2 * IMG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, hh = blockIdx.y;
-    const int qrow = blockIdx.x * 128 + wave * 32 + r;
+    int xt, hh, b;
+    block_coords(p, xt, hh, b);
+    const int qrow = xt * 128 + wave * 32 + r;
     const bool qvalid = qrow < p.Lq;
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
@@ -784,8 +806,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_pre(Args p) {
     char* sV = smem + 2 * IMG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, hh = blockIdx.y;
-    const int qrow = blockIdx.x * 128 + wave * 32 + r;
+    int xt, hh, b;
+    block_coords(p, xt, hh, b);
+    const int qrow = xt * 128 + wave * 32 + r;
     const bool qvalid = qrow < p.Lq;
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
@@ -888,7 +911,8 @@ __device__ __forceinline__ void attn_bwd_dq_pre_body(const Args& p) {
     char* sV = smem + 2 * IMG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, hh = blockIdx.y;
+    int xt, hh, b;
+    block_coords(p, xt, hh, b);
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
     const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
@@ -900,7 +924,7 @@ __device__ __forceinline__ void attn_bwd_dq_pre_body(const Args& p) {
     f32x16 Cl[2], Cd[2], dQ[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        qrow[u] = blockIdx.x * 256 + wave * 64 + u * 32 + r;
+        qrow[u] = xt * 256 + wave * 64 + u * 32 + r;
         qvalid[u] = qrow[u] < p.Lq;
         load_lane_block(qb[u], Q, p.ldq, qrow[u], qvalid[u], p.dh, h);
         load_lane_block(dob[u], dO, p.lddo, qrow[u], qvalid[u], p.dh, h);
@@ -981,8 +1005,9 @@ __device__ __forceinline__ void attn_bwd_dkdv_pre_body(const Args& p) {
     unsigned* sD = sL + 2 * KT;                                  // [2][KT] -delta as (hi, lo) bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, hh = blockIdx.y;
-    const int krow = blockIdx.x * 128 + wave * 32 + r;
+    int xt, hh, b;
+    block_coords(p, xt, hh, b);
+    const int krow = xt * 128 + wave * 32 + r;
     const bool kvalid = krow < p.Lk;
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
     const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
@@ -1141,6 +1166,12 @@ int svol_attn_fwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
     if (p.ksplit == 1) p.tiles_per_split = ntk;
     else bind_ws(p, ws);
     dim3 grid((unsigned)(((Lq + 127) / 128) * p.ksplit), (unsigned)H, (unsigned)B);
+    static const bool no_head_xcd = getenv("SVOL_ATTN_NO_HEAD_XCD") != nullptr;
+    if (pre && !no_head_xcd && (B * H) % 8 == 0) {  // heads dealt to the XCDs (block_coords)
+        p.head_xcd = 1;
+        p.nxt = (Lq + 127) / 128;
+        grid = dim3((unsigned)(B * H * p.nxt));
+    }
     if (pre && masked) {
         p.tile_flags = reinterpret_cast<const int*>(ws);
         hipLaunchKernelGGL(attn_tile_flags_bf16, dim3((unsigned)ntk, (unsigned)B), dim3(64), 0, s, kbias, Lk, ntk, reinterpret_cast<int*>(ws));
@@ -1178,14 +1209,27 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
     dim3 gq((unsigned)(((Lq + 127) / 128) * p.ksplit), (unsigned)H, (unsigned)B);
     dim3 gk((unsigned)((Lk + 127) / 128), (unsigned)H, (unsigned)B);
     hipLaunchKernelGGL(attn_delta_bf16, gd, dim3(256), 0, s, p);
-    if (pre && masked) {
-        p.tile_flags = reinterpret_cast<const int*>(ws);
-        hipLaunchKernelGGL(attn_tile_flags_bf16, dim3((unsigned)ntk, (unsigned)B), dim3(64), 0, s, kbias, Lk, ntk, reinterpret_cast<int*>(ws));
-        hipLaunchKernelGGL(attn_bwd_dq_bf16_pre_masked, dim3((unsigned)((Lq + 255) / 256), (unsigned)H, (unsigned)B), dim3(256), 0, s, p);
-        hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre_masked, gk, dim3(256), 0, s, p);
-    } else if (pre) {
-        hipLaunchKernelGGL(attn_bwd_dq_bf16_pre, dim3((unsigned)((Lq + 255) / 256), (unsigned)H, (unsigned)B), dim3(256), 0, s, p);
-        hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre, gk, dim3(256), 0, s, p);
+    if (pre) {
+        static const bool no_head_xcd = getenv("SVOL_ATTN_NO_HEAD_XCD") != nullptr;
+        Args pq = p, pk = p;
+        dim3 gq2((unsigned)((Lq + 255) / 256), (unsigned)H, (unsigned)B);
+        dim3 gk2 = gk;
+        if (!no_head_xcd && (B * H) % 8 == 0) {  // heads dealt to the XCDs (block_coords)
+            pq.head_xcd = pk.head_xcd = 1;
+            pq.nxt = (Lq + 255) / 256;
+            pk.nxt = (Lk + 127) / 128;
+            gq2 = dim3((unsigned)(B * H * pq.nxt));
+            gk2 = dim3((unsigned)(B * H * pk.nxt));
+        }
+        if (masked) {
+            pq.tile_flags = pk.tile_flags = reinterpret_cast<const int*>(ws);
+            hipLaunchKernelGGL(attn_tile_flags_bf16, dim3((unsigned)ntk, (unsigned)B), dim3(64), 0, s, kbias, Lk, ntk, reinterpret_cast<int*>(ws));
+            hipLaunchKernelGGL(attn_bwd_dq_bf16_pre_masked, gq2, dim3(256), 0, s, pq);
+            hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre_masked, gk2, dim3(256), 0, s, pk);
+        } else {
+            hipLaunchKernelGGL(attn_bwd_dq_bf16_pre, gq2, dim3(256), 0, s, pq);
+            hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre, gk2, dim3(256), 0, s, pk);
+        }
     } else if (masked) {
         hipLaunchKernelGGL(attn_bwd_dq_bf16<true>, gq, dim3(256), 0, s, p);
         if (p.ksplit > 1) hipLaunchKernelGGL(attn_dq_finish_bf16, gd, dim3(256), 0, s, p);
