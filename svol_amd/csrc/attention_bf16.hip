@@ -239,9 +239,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(Args p) {
         }
         float mloc = max3(ml[0], ml[1], fmaxf(ml[2], ml[3]));
         {   // other half-wave's maximum for the same query: v_permlane32_swap (VALU, no LDS round trip)
-            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc),
-                                                             __builtin_bit_cast(unsigned, mloc), false, false);
-            mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+            const HalfPair sw = swap_halves(__builtin_bit_cast(unsigned, mloc));
+            mloc = fmaxf(__builtin_bit_cast(float, sw.lo), __builtin_bit_cast(float, sw.hi));
         }
         const float thr = MASKED ? LAZY_THR : LAZY_THR / c;
         if (__any(mloc > m + thr)) {  // wave-uniform: rescale only when some query's maximum really moved
@@ -748,9 +747,8 @@ __device__ __forceinline__ void attn_fwd_pre_body(const Args p) {
             }
             float mloc = max3(ml[0], ml[1], fmaxf(ml[2], ml[3]));
             {
-                const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc),
-                                                                 __builtin_bit_cast(unsigned, mloc), false, false);
-                mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+                const HalfPair sw = swap_halves(__builtin_bit_cast(unsigned, mloc));
+                mloc = fmaxf(__builtin_bit_cast(float, sw.lo), __builtin_bit_cast(float, sw.hi));
             }
             const bool first = MASKED ? !started : (t == 0);
             if (first || __any(mloc > LAZY_THR)) {  // wave-uniform
@@ -853,9 +851,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_pre(Args p) {
         }
         float mloc = max3(ml[0], ml[1], fmaxf(ml[2], ml[3]));
         {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc),
-                                                             __builtin_bit_cast(unsigned, mloc), false, false);
-            mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+            const HalfPair sw = swap_halves(__builtin_bit_cast(unsigned, mloc));
+            mloc = fmaxf(__builtin_bit_cast(float, sw.lo), __builtin_bit_cast(float, sw.hi));
         }
         if (t == 0 || __any(mloc > LAZY_THR)) {  // wave-uniform
             // first tile: anchor the reference at this tile's maximum (may move down); later: only upward moves
@@ -915,6 +912,7 @@ __device__ __forceinline__ void attn_bwd_dq_pre_body(const Args& p) {
     block_coords(p, xt, hh, b);
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
     const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
+    const bf16_t* O = reinterpret_cast<const bf16_t*>(p.o) + (int64_t)b * p.Lq * p.ldo + hh * p.dh;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
     const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
 
@@ -930,7 +928,23 @@ __device__ __forceinline__ void attn_bwd_dq_pre_body(const Args& p) {
         load_lane_block(dob[u], dO, p.lddo, qrow[u], qvalid[u], p.dh, h);
         const int64_t sidx = ((int64_t)b * p.H + hh) * p.Lq + qrow[u];
         Cl[u] = splat16(qvalid[u] ? -p.lse2[sidx] : -INFINITY);  // score - lse  (rows past Lq -> p = 0)
-        Cd[u] = splat16(qvalid[u] ? -p.delta[sidx] : 0.f);       // dP - delta
+        // delta = rowsum(dO . O), computed here instead of in a kernel of its own (this lane and lane ^ 32 hold the two halves
+        // of the row) and published for the dK/dV pass, which runs after this kernel on the same stream
+        float dl = 0.f;
+        {
+            uint4 ob[2];
+            load_lane_block(ob, O, p.ldo, qrow[u], qvalid[u], p.dh, h);
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, ob[s_]), c = __builtin_bit_cast(bf16x8, dob[u][s_]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dl += (float)a[e] * (float)c[e];
+            }
+            const HalfPair sw = swap_halves(__builtin_bit_cast(unsigned, dl));
+            dl = __builtin_bit_cast(float, sw.lo) + __builtin_bit_cast(float, sw.hi);
+        }
+        if (qvalid[u] && h == 0) p.delta[sidx] = dl;
+        Cd[u] = splat16(qvalid[u] ? -dl : 0.f);                  // dP - delta
         dQ[u] = zero16();
     }
     const float* kb = (MASKED && p.kbias) ? p.kbias + (int64_t)b * p.Lk : nullptr;
@@ -1208,7 +1222,7 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
     dim3 gd((unsigned)((total + 255) / 256));
     dim3 gq((unsigned)(((Lq + 127) / 128) * p.ksplit), (unsigned)H, (unsigned)B);
     dim3 gk((unsigned)((Lk + 127) / 128), (unsigned)H, (unsigned)B);
-    hipLaunchKernelGGL(attn_delta_bf16, gd, dim3(256), 0, s, p);
+    if (!pre) hipLaunchKernelGGL(attn_delta_bf16, gd, dim3(256), 0, s, p);  // (the fast dQ kernel computes delta in its prologue)
     if (pre) {
         static const bool no_head_xcd = getenv("SVOL_ATTN_NO_HEAD_XCD") != nullptr;
         Args pq = p, pk = p;

@@ -19,6 +19,17 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// v_permlane32_swap of a value with itself: lo = the value held by lane (i & 31), hi = the value held by lane (i | 32), in
+// EVERY lane i.  The second operand is laundered through an empty asm: with two identical SSA operands hipcc (ROCm 7.2) folds the
+// two results of the builtin into one register (v_permlane32_swap v1, v3 ; v_add_f32 v3, v1, v1) and the partner's value is lost.
+struct HalfPair { unsigned lo, hi; };
+__device__ __forceinline__ HalfPair swap_halves(unsigned x) {
+    unsigned y = x;
+    asm volatile("" : "+v"(y));
+    const auto sw = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    return HalfPair{sw[0], sw[1]};
+}
+
 // ---- scalar conversions ---------------------------------------------------
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }

