@@ -135,7 +135,10 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     reducer = parallel.BucketedGradAllReduce(params, skip=parallel.unused_parameters(model))
     use_graph = world == 1 and a.graph and not a.no_graph
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, fused=True, capturable=use_graph)  # train.py:98-99
+    if use_graph:  # (the captured step keeps torch's capturable optimizer: its step counter lives on the device)
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, fused=True, capturable=True)  # train.py:98-99
+    else:  # the same update as one streaming kernel per gradient bucket (svol_amd.parallel.FlatAdamW)
+        opt = parallel.FlatAdamW(reducer, lr=1e-4, weight_decay=1e-4)
     # weak scaling: every rank gets its own B videos (different seeds = a properly sharded global batch)
     inp = {k: v.to(dev) for k, v in syn.synth_inputs(args, B, T, P, seed=1 + rank).items()}
     tg = syn.synth_targets(B, T, seed=1 + rank)

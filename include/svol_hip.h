@@ -59,6 +59,13 @@ int svol_cast_transpose(const float* src, void* dst, void* dstT, int dtype, int6
  * total_tiles = their sum.  dst or dstT may be NULL per record. */
 int svol_cast_transpose_multi(const void* descs, int32_t n_desc, int64_t total_tiles, int dtype, void* stream);
 
+/* One AdamW step (torch.optim.AdamW semantics: decoupled weight decay, amsgrad / maximize off — the reference's optimizer,
+ * train.py:98-99) over a FLAT fp32 range of parameters p with gradients g and moment buffers m, v, all 16-byte aligned:
+ *   g' = g * grad_scale;  p *= 1 - lr*wd;  m += (g' - m)(1 - b1);  v = b2*v + (1 - b2) g'^2;
+ *   p -= lr/(1 - b1^step) * m / (sqrt(v)/sqrt(1 - b2^step) + eps).          step counts from 1. */
+int svol_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int64_t step, float grad_scale, void* stream);
+
 /* ---- GEMMs (nn.Linear and its backward) --------------------------------- */
 /* C[M,N] = act((A[M,K] * B[N,K]^T + bias[N]) * colscale[N]) + residual[M,N]
  *   A2/n_split: output columns n >= n_split read their A operand from A2 instead of A

