@@ -55,15 +55,39 @@ template <> struct Vec4<bf16_t> {
 };
 
 // ---- wave-level reductions (64 lanes) --------------------------------------
+// Wave-wide butterfly reductions without the LDS crossbar: four DPP lane permutations inside the 16-lane rows (quad xor 1,
+// quad xor 2, row_half_mirror, row_mirror — after the quad steps all lanes of a quad agree, so the mirrors pair disjoint
+// groups), then v_permlane16_swap and v_permlane32_swap (gfx950) across rows.  Every lane ends with the full result.
+// (__shfl_xor lowers to ds_bpermute_b32: six dependent LDS round trips per reduction, which bounded the row kernels.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ HalfPair swap_rows16(unsigned x) {  // lo: rows 0,0,2,2   hi: rows 1,1,3,3  (16-lane rows)
+    unsigned y = x;
+    asm volatile("" : "+v"(y));
+    const auto sw = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+    return HalfPair{sw[0], sw[1]};
+}
 __device__ __forceinline__ float wave_sum(float x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-    return x;
+    x += dpp_f32<0xB1>(x);
+    x += dpp_f32<0x4E>(x);
+    x += dpp_f32<0x141>(x);
+    x += dpp_f32<0x140>(x);
+    const HalfPair a = swap_rows16(__builtin_bit_cast(unsigned, x));
+    x = __builtin_bit_cast(float, a.lo) + __builtin_bit_cast(float, a.hi);
+    const HalfPair b = swap_halves(__builtin_bit_cast(unsigned, x));
+    return __builtin_bit_cast(float, b.lo) + __builtin_bit_cast(float, b.hi);
 }
 __device__ __forceinline__ float wave_max(float x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
-    return x;
+    x = fmaxf(x, dpp_f32<0xB1>(x));
+    x = fmaxf(x, dpp_f32<0x4E>(x));
+    x = fmaxf(x, dpp_f32<0x141>(x));
+    x = fmaxf(x, dpp_f32<0x140>(x));
+    const HalfPair a = swap_rows16(__builtin_bit_cast(unsigned, x));
+    x = fmaxf(__builtin_bit_cast(float, a.lo), __builtin_bit_cast(float, a.hi));
+    const HalfPair b = swap_halves(__builtin_bit_cast(unsigned, x));
+    return fmaxf(__builtin_bit_cast(float, b.lo), __builtin_bit_cast(float, b.hi));
 }
 
 // ---- counter-based RNG for dropout (stateless: same mask in fwd and bwd) ----
