@@ -32,8 +32,24 @@ __global__ __launch_bounds__(256) void gate_scores_kernel(const float* __restric
 #pragma unroll
             for (int e = 0; e < 4; ++e) ur[hh][j][e] = (hh < H && c < D) ? u[((int64_t)b * H + hh) * D + c + e] : 0.f;
         }
-    for (int l = l0; l < l0 + rpw && l < L; ++l) {
+    const int lend = min(l0 + rpw, L);
+    Vec4<float> xv[NP], nxv[NP];
+    Vec4<T> pv[NP], npv[NP];
+    auto fetch = [&](int l, Vec4<float> (&xr)[NP], Vec4<T> (&pr)[NP]) {
         const int64_t row = (int64_t)b * L + l;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            if (c < D) {
+                xr[j].load(x + row * D + c);
+                pr[j].load(pos + row * D + c);
+            }
+        }
+    };
+    if (l0 < lend) fetch(l0, xv, pv);
+    const bool b0 = lane & 1, b1 = lane & 2;
+    for (int l = l0; l < lend; ++l) {
+        if (l + 1 < lend) fetch(l + 1, nxv, npv);  // next row in flight while this one is reduced
         float part[GH];
 #pragma unroll
         for (int hh = 0; hh < GH; ++hh) part[hh] = 0.f;
@@ -41,23 +57,45 @@ __global__ __launch_bounds__(256) void gate_scores_kernel(const float* __restric
         for (int j = 0; j < NP; ++j) {
             const int c = (lane + 64 * j) * 4;
             if (c < D) {
-                Vec4<float> xv;
-                Vec4<T> pv;
-                xv.load(x + row * D + c);
-                pv.load(pos + row * D + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float t = xv.get(e) + pv.get(e);
+                    const float t = xv[j].get(e) + pv[j].get(e);
 #pragma unroll
                     for (int hh = 0; hh < GH; ++hh) part[hh] += t * ur[hh][j][e];
                 }
             }
         }
+        // 8 head sums over 64 lanes as ONE reduce-scatter butterfly: the xor-1 partners split the heads (each keeps four and
+        // adds the partner's four), the xor-2 partners split again (two each), then two values ride the remaining four steps
+        // — 14 exchanges instead of 8 x 6.  Lane q of quad 0 ends with heads {4*(q&1) + 2*(q>>1), +1}.
+        float h4[4], h2[2];
 #pragma unroll
-        for (int hh = 0; hh < GH; ++hh) {
-            const float s = wave_sum(part[hh]);
-            if (lane == 0 && hh < H) scores[((int64_t)b * H + hh) * L + l] = s;
+        for (int i = 0; i < 4; ++i) {
+            const float send = b0 ? part[i] : part[4 + i], keep = b0 ? part[4 + i] : part[i];
+            h4[i] = keep + dpp_f32<0xB1>(send);
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float send = b1 ? h4[i] : h4[2 + i], keep = b1 ? h4[2 + i] : h4[i];
+            h2[i] = keep + dpp_f32<0x4E>(send);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float v = h2[i];
+            v += dpp_f32<0x141>(v);
+            v += dpp_f32<0x140>(v);
+            const HalfPair r16 = swap_rows16(__builtin_bit_cast(unsigned, v));
+            v = __builtin_bit_cast(float, r16.lo) + __builtin_bit_cast(float, r16.hi);
+            const HalfPair r32 = swap_halves(__builtin_bit_cast(unsigned, v));
+            h2[i] = __builtin_bit_cast(float, r32.lo) + __builtin_bit_cast(float, r32.hi);
+        }
+        if (lane < 4) {
+            const int hh0 = 4 * (lane & 1) + 2 * (lane >> 1);
+            if (hh0 < H) scores[((int64_t)b * H + hh0) * L + l] = h2[0];
+            if (hh0 + 1 < H) scores[((int64_t)b * H + hh0 + 1) * L + l] = h2[1];
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { xv[j] = nxv[j]; pv[j] = npv[j]; }
     }
 }
 
@@ -282,8 +320,28 @@ __global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const float* __rest
                 dur[hh][j][e] = 0.f;
             }
         }
-    for (int l = l0; l < l0 + rpw && l < L; ++l) {
+    // The row loop is latency-bound (one dependent load -> compute -> store chain per wave, ~1.5 KB in flight): the NEXT row's
+    // operands are fetched before the current row is processed (rows are distinct, so hoisting the dx load over the dx store
+    // is safe — the compiler cannot know that)
+    const int lend = min(l0 + rpw, L);
+    Vec4<float> xv[NP], dv[NP], nxv[NP], ndv[NP];
+    Vec4<T> pv[NP], npv[NP];
+    auto fetch = [&](int l, Vec4<float> (&xr)[NP], Vec4<T> (&pr)[NP], Vec4<float> (&dr)[NP]) {
         const int64_t row = (int64_t)b * L + l;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            if (c < D) {
+                xr[j].load(x + row * D + c);
+                pr[j].load(pos + row * D + c);
+                dr[j].load(dx + row * D + c);
+            }
+        }
+    };
+    if (l0 < lend) fetch(l0, xv, pv, dv);
+    for (int l = l0; l < lend; ++l) {
+        const int64_t row = (int64_t)b * L + l;
+        if (l + 1 < lend) fetch(l + 1, nxv, npv, ndv);
         float ds[GH];
         const float dal = da[row] / (float)H;
 #pragma unroll
@@ -298,25 +356,22 @@ __global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const float* __rest
         for (int j = 0; j < NP; ++j) {
             const int c = (lane + 64 * j) * 4;
             if (c < D) {
-                Vec4<float> xv, dv;
-                Vec4<T> pv;
-                xv.load(x + row * D + c);
-                pv.load(pos + row * D + c);
-                dv.load(dx + row * D + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float t = xv.get(e) + pv.get(e);
+                    const float t = xv[j].get(e) + pv[j].get(e);
                     float add = 0.f;
 #pragma unroll
                     for (int hh = 0; hh < GH; ++hh) {
                         add += ds[hh] * ur[hh][j][e];
                         dur[hh][j][e] += ds[hh] * t;
                     }
-                    dv.set(e, dv.get(e) + add);
+                    dv[j].set(e, dv[j].get(e) + add);
                 }
-                dv.store(dx + row * D + c);
+                dv[j].store(dx + row * D + c);
             }
         }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { xv[j] = nxv[j]; pv[j] = npv[j]; dv[j] = ndv[j]; }
     }
     // du: fold the workgroup's four waves in LDS first (every wave of a batch element hits the same H*D addresses)
     __shared__ float red[GH * NP * 256];
