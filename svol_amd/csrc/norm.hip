@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = (dy32 + dy + dypos) * gamma (dropout mask applied first)
-template <typename T, typename TX>
+template <typename T, typename TX, int NP>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy32, const T* __restrict__ dy,
                                                      const T* __restrict__ dy2, const TX* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -83,18 +83,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     const int lane = threadIdx.x & 63;
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t r0 = wave_id * rows_per_wave;
-    float dg[LN_MAX_PASSES][4], db[LN_MAX_PASSES][4], dxs[LN_MAX_PASSES][4];
+    float dg[NP][4], db[NP][4], dxs[NP][4];
 #pragma unroll
-    for (int j = 0; j < LN_MAX_PASSES; ++j)
+    for (int j = 0; j < NP; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { dg[j][e] = 0.f; db[j][e] = 0.f; dxs[j][e] = 0.f; }
 
     for (int64_t row = r0; row < r0 + rows_per_wave && row < M; ++row) {
         const float mu = mean[row], rs = rstd[row];
-        float g[LN_MAX_PASSES][4], xh[LN_MAX_PASSES][4];
+        float g[NP][4], xh[NP][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < LN_MAX_PASSES; ++j) {
+        for (int j = 0; j < NP; ++j) {
             const int c = (lane + 64 * j) * 4;
             if (c < D) {
                 Vec4<T> a, b;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         s1 = wave_sum(s1) / (float)D;
         s2 = wave_sum(s2) / (float)D;
 #pragma unroll
-        for (int j = 0; j < LN_MAX_PASSES; ++j) {
+        for (int j = 0; j < NP; ++j) {
             const int c = (lane + 64 * j) * 4;
             if (c < D) {
                 Vec4<T> o;
@@ -141,12 +141,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
     // one set of atomics per WORKGROUP: the 4 waves' partial sums are combined in LDS first (every wave
     // of every workgroup adding to the same D addresses is the contended-atomic worst case)
-    __shared__ float red[3][LN_MAX_PASSES * 256];
+    __shared__ float red[3][NP * 256];
     const int wave = threadIdx.x >> 6;
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
-            for (int j = 0; j < LN_MAX_PASSES; ++j) {
+            for (int j = 0; j < NP; ++j) {
                 const int c = (lane + 64 * j) * 4;
                 if (c < D) {
 #pragma unroll
@@ -255,15 +255,24 @@ int svol_layernorm_bwd(const float* dy32, const void* dy, const void* dy2, const
     const int64_t waves = (M + rpw - 1) / rpw;
     const unsigned grid = (unsigned)((waves + 3) / 4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == SVOL_BF16 && x_f32)
-        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, dy32, (const bf16_t*)dy, (const bf16_t*)dy2,
-                           (const float*)x, gamma, mean, rstd, dx32, (bf16_t*)dx, dgamma, dbeta, dx_colsum, M, (int)D, dropout_p, inv_keep, seed, seed_offset_dev, (int)rpw);
-    else if (dtype == SVOL_BF16)
-        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, dy32, (const bf16_t*)dy, (const bf16_t*)dy2,
-                           (const bf16_t*)x, gamma, mean, rstd, dx32, (bf16_t*)dx, dgamma, dbeta, dx_colsum, M, (int)D, dropout_p, inv_keep, seed, seed_offset_dev, (int)rpw);
-    else
-        hipLaunchKernelGGL((ln_bwd_kernel<float, float>), dim3(grid), dim3(256), 0, s, dy32, (const float*)dy, (const float*)dy2,
-                           (const float*)x, gamma, mean, rstd, dx32, (float*)dx, dgamma, dbeta, dx_colsum, M, (int)D, dropout_p, inv_keep, seed, seed_offset_dev, (int)rpw);
+    // NP = passes of 256 columns per row: the accumulator / operand arrays are sized by it (NP = 1 at d = 256: 76 VGPRs
+    // instead of the 166 of the 4-pass instantiation; 46 us instead of 50 at [50176, 256] = 5.0 TB/s.  More waves or a next-row
+    // prefetch do not help further: the end-of-workgroup atomics, then HBM, bound it)
+#define SVOL_LNB(TT, TXX, NPP)                                                                                                      \
+    hipLaunchKernelGGL((ln_bwd_kernel<TT, TXX, NPP>), dim3(grid), dim3(256), 0, s, dy32, (const TT*)dy, (const TT*)dy2, (const TXX*)x, \
+                       gamma, mean, rstd, dx32, (TT*)dx, dgamma, dbeta, dx_colsum, M, (int)D, dropout_p, inv_keep, seed,              \
+                       seed_offset_dev, (int)rpw)
+#define SVOL_LNB_NP(TT, TXX)                  \
+    do {                                      \
+        if (D <= 256) SVOL_LNB(TT, TXX, 1);   \
+        else if (D <= 512) SVOL_LNB(TT, TXX, 2); \
+        else SVOL_LNB(TT, TXX, 4);            \
+    } while (0)
+    if (dtype == SVOL_BF16 && x_f32) SVOL_LNB_NP(bf16_t, float);
+    else if (dtype == SVOL_BF16) SVOL_LNB_NP(bf16_t, bf16_t);
+    else SVOL_LNB_NP(float, float);
+#undef SVOL_LNB_NP
+#undef SVOL_LNB
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }
