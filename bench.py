@@ -12,9 +12,11 @@ workload: BASELINE.json configs[1]  — B=8 videos per GPU, T=32 frames, P=196 t
           compute with an fp32 residual stream, train mode (input dropout on), synthetic data,
           weights: module default init.  One step = zero_grad, forward, criterion (all 6 layers matched on
           device), backward (+ bucketed RCCL gradient all-reduce overlapped with backward when N > 1), and
-          the AdamW step (so that the per-step fp32->bf16 weight refresh is inside the timed region).  Launches are
-          eager (host issue ~15 ms/step, hidden behind ~24 ms of GPU work) at every N, so the N = 1 and N > 1 numbers
-          are the same program; --graph replays the step as one hipGraph instead.
+          the AdamW step (torch.optim.AdamW's update as one kernel per gradient bucket, svol_amd.parallel.FlatAdamW; the
+          per-step fp32->bf16 weight refresh is inside the timed region too).  Launches are eager (host issue ~15 ms/step,
+          hidden behind ~23 ms of GPU work) at every N, so the N = 1 and N > 1 numbers are the same program; --graph
+          replays the step as one hipGraph instead.  --workload selects the other measured configurations (cfg4: ViT
+          extractor online, cfg5: long video, encdec: enc/dec Transformer head, resnet: ResNet extractors online).
 Prints ONE JSON line on rank 0.
 """
 import argparse
