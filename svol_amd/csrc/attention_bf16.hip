@@ -42,6 +42,7 @@ struct Args {
     float *ws_o, *ws_ml, *ws_dq;  // [ksplit][B*Lq][H*dh] unnormalised O | [ksplit][B][H][Lq][2] (m2, l) | [B*Lq][H*dh] dQ
     const int* tile_flags;        // [B][ceil(Lk/KT)] key-tile classes of the masked fast kernels (attn_tile_flags_bf16)
     int head_xcd, nxt;            // != 0: 1-D grid of B*H*nxt workgroups with the heads dealt to the 8 XCDs (block_coords)
+    int tail_last;                // != 0 (with head_xcd): every head's LAST x tile is dispatched after all the others
 };
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
@@ -629,8 +630,15 @@ __device__ __forceinline__ f32x16 rows16(const float* v, int sub, int h) {
 __device__ __forceinline__ void block_coords(const Args& p, int& xt, int& hh, int& b) {
     if (p.head_xcd) {
         const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
-        const int hl = slot / p.nxt;
-        xt = slot - hl * p.nxt;
+        int hl;
+        if (p.tail_last) {  // the short last tiles (dQ pass: half a workgroup of rows) fill the launch's last, partial round
+            const int nfull = p.nxt - 1, hpx = (p.B * p.H) >> 3;
+            if (slot < hpx * nfull) { hl = slot / nfull; xt = slot - hl * nfull; }
+            else { hl = slot - hpx * nfull; xt = nfull; }
+        } else {
+            hl = slot / p.nxt;
+            xt = slot - hl * p.nxt;
+        }
         const int head = hl * 8 + xcd;
         hh = head % p.H;
         b = head / p.H;
@@ -920,9 +928,13 @@ __device__ __forceinline__ void attn_bwd_dq_pre_body(const Args& p) {
     bool qvalid[2];
     uint4 qb[2][2], dob[2][2];
     f32x16 Cl[2], Cd[2], dQ[2];
+    // a workgroup with at most 128 rows left (the last tile of a head when Lq % 256 is in 1..128) gives every wave ONE
+    // 32-query block instead of two half-empty waves with two: it finishes in about half the time, and the launcher
+    // dispatches these tiles last, where they shorten the partial last round of workgroups
+    const bool single = p.Lq - xt * 256 <= 128;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        qrow[u] = xt * 256 + wave * 64 + u * 32 + r;
+        qrow[u] = single ? (u == 0 ? xt * 256 + wave * 32 + r : p.Lq) : xt * 256 + wave * 64 + u * 32 + r;
         qvalid[u] = qrow[u] < p.Lq;
         load_lane_block(qb[u], Q, p.ldq, qrow[u], qvalid[u], p.dh, h);
         load_lane_block(dob[u], dO, p.lddo, qrow[u], qvalid[u], p.dh, h);
@@ -977,20 +989,23 @@ __device__ __forceinline__ void attn_bwd_dq_pre_body(const Args& p) {
             read_rows(ka, kimg, sub * 32 + r, h);
             read_rows(va, vimg, sub * 32 + r, h);
             f32x16 S0 = mma_first_c(ka, qb[0], Cl[0]);
-            f32x16 S1 = mma_first_c(ka, qb[1], Cl[1]);
+            f32x16 S1, dP1;
+            if (!single) S1 = mma_first_c(ka, qb[1], Cl[1]);
             const f32x16 dP0 = mma_first_c(va, dob[0], Cd[0]);
-            const f32x16 dP1 = mma_first_c(va, dob[1], Cd[1]);
+            if (!single) dP1 = mma_first_c(va, dob[1], Cd[1]);
             read_tr(kt, kimg, sub, lane);
             if (MASKED && flag == 1) {
                 S0 = add_key_bias(S0, kb, t * KT + sub * 32 + r, p.Lk, h);
-                S1 = add_key_bias(S1, kb, t * KT + sub * 32 + r, p.Lk, h);
+                if (!single) S1 = add_key_bias(S1, kb, t * KT + sub * 32 + r, p.Lk, h);
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) S0[i] = __builtin_amdgcn_exp2f(S0[i]) * dP0[i];
             mma_second(dQ[0], kt, S0);
+            if (!single) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) S1[i] = __builtin_amdgcn_exp2f(S1[i]) * dP1[i];
-            mma_second(dQ[1], kt, S1);
+                for (int i = 0; i < 16; ++i) S1[i] = __builtin_amdgcn_exp2f(S1[i]) * dP1[i];
+                mma_second(dQ[1], kt, S1);
+            }
         }
         if (t + 1 < nt) {
             store_lds(sK + (cur ^ 1) * IMG, sk, tid);
@@ -1232,6 +1247,7 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
             pq.head_xcd = pk.head_xcd = 1;
             pq.nxt = (Lq + 255) / 256;
             pk.nxt = (Lk + 127) / 128;
+            pq.tail_last = (Lq % 256 >= 1 && Lq % 256 <= 128 && pq.nxt > 1) ? 1 : 0;
             gq2 = dim3((unsigned)(B * H * pq.nxt));
             gk2 = dim3((unsigned)(B * H * pk.nxt));
         }
