@@ -111,6 +111,93 @@ __device__ __forceinline__ MinKey wave_argmin(MinKey a) {
     return better(p0, p1);
 }
 
+// Register-resident solver for the common sizes (after scipy's transpose: nr <= 64 rows, nc <= 128 columns — the 100 object
+// queries against up to 64 boxes of a video).  The LDS version below walks four LDS arrays per column per step, every access a
+// dependent ~100-cycle round trip in a single wave; here lane l owns columns l and l + 64 (v, shortest-path cost, path, row4col,
+// scanned flag, position in scipy's `remaining` list) and row l (u, col4row, scanned flag) in registers, the list's swap-remove
+// is a position update in the two lanes involved, lookups by index are v_readlane, and only the cost row comes from LDS.
+// Arithmetic, visiting order and the tie rule are those of the LDS version (and of scipy): results are bit-identical.
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)b, l), hi = __builtin_amdgcn_readlane((unsigned)(b >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ bool lsap_reg(const float* __restrict__ Cs, int nr, int nc, int lane, int (&col4row_out)) {
+    const int j0 = lane, j1 = lane + 64;
+    const bool ok0 = j0 < nc, ok1 = j1 < nc;
+    double v0 = 0.0, v1 = 0.0, spc0 = INFINITY, spc1 = INFINITY, u = 0.0;
+    int path0 = -1, path1 = -1, r4c0 = -1, r4c1 = -1, pos0 = -1, pos1 = -1, c4r = -1;
+    bool sc0 = false, sc1 = false, sr = false;
+    for (int cur = 0; cur < nr; ++cur) {
+        pos0 = ok0 ? nc - 1 - j0 : -1;  // remaining[it] = nc - it - 1
+        pos1 = ok1 ? nc - 1 - j1 : -1;
+        sc0 = sc1 = sr = false;
+        spc0 = spc1 = INFINITY;
+        int num_remaining = nc, i = cur, sink = -1;
+        double min_val = 0.0;
+        while (sink == -1) {
+            if (lane == i) sr = true;
+            const double ui = readlane_f64(u, i);
+            MinKey mk;
+            mk.s = INFINITY;
+            mk.key = (int)0x80000000;
+            if (pos0 >= 0) {
+                const double r = min_val + (double)Cs[i * nc + j0] - ui - v0;
+                if (r < spc0) { path0 = i; spc0 = r; }
+                mk.s = spc0;
+                mk.key = r4c0 == -1 ? 0x40000000 + pos0 : 0x3fffffff - pos0;
+            }
+            if (pos1 >= 0) {
+                const double r = min_val + (double)Cs[i * nc + j1] - ui - v1;
+                if (r < spc1) { path1 = i; spc1 = r; }
+                MinKey m1;
+                m1.s = spc1;
+                m1.key = r4c1 == -1 ? 0x40000000 + pos1 : 0x3fffffff - pos1;
+                mk = better(mk, m1);
+            }
+            mk = wave_argmin(mk);
+            if (mk.s == INFINITY) return false;  // infeasible
+            min_val = mk.s;
+            const int index = mk.key >= 0x40000000 ? mk.key - 0x40000000 : 0x3fffffff - mk.key;
+            const unsigned long long m0 = __ballot(pos0 == index), m1b = __ballot(pos1 == index);
+            const int slot = m0 ? 0 : 1;
+            const int lj = __builtin_amdgcn_readfirstlane(m0 ? __builtin_ctzll(m0) : __builtin_ctzll(m1b));
+            const int j = lj + 64 * slot;
+            const int r4 = slot ? __builtin_amdgcn_readlane(r4c1, lj) : __builtin_amdgcn_readlane(r4c0, lj);
+            if (r4 == -1) sink = j; else i = r4;
+            const int last = num_remaining - 1;
+            // SC[j] = true; remaining[index] = remaining[last]; --num_remaining
+            if (lane == lj) { if (slot) sc1 = true; else sc0 = true; }
+            const bool rm0 = lane == lj && slot == 0, rm1 = lane == lj && slot == 1;
+            if (rm0) pos0 = -1; else if (pos0 == last) pos0 = index;
+            if (rm1) pos1 = -1; else if (pos1 == last) pos1 = index;
+            num_remaining = last;
+        }
+        // dual update
+        if (lane == cur) u += min_val;
+        {
+            const int c = c4r < 0 ? 0 : c4r;
+            const double s0 = __shfl(spc0, c & 63, 64), s1 = __shfl(spc1, c & 63, 64);
+            if (sr && lane != cur && lane < nr) u += min_val - ((c >> 6) ? s1 : s0);
+        }
+        if (sc0) v0 -= min_val - spc0;
+        if (sc1) v1 -= min_val - spc1;
+        // augment along the path
+        int j = sink;
+        for (;;) {
+            const int lj = j & 63, slot = j >> 6;
+            const int ii = slot ? __builtin_amdgcn_readlane(path1, lj) : __builtin_amdgcn_readlane(path0, lj);
+            if (lane == lj) { if (slot) r4c1 = ii; else r4c0 = ii; }
+            const int t = __builtin_amdgcn_readlane(c4r, ii);
+            if (lane == ii) c4r = j;
+            j = t;
+            if (ii == cur) break;
+        }
+    }
+    col4row_out = c4r;
+    return true;
+}
+
 __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost, const int64_t* __restrict__ cost_off,
                                                   const int32_t* __restrict__ pred_off, const int32_t* __restrict__ pred_cnt,
                                                   const int32_t* __restrict__ tgt_off, const int32_t* __restrict__ tgt_cnt,
@@ -157,6 +244,19 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost
     }
     if (__any(bad)) {
         if (lane == 0) status[p] = 1;
+        return;
+    }
+    if (staged && nr <= 64 && nc <= 128) {  // register-resident path (see lsap_reg)
+        __syncthreads();
+        int c4 = -1;
+        if (!lsap_reg(Cs, nr, nc, lane, c4)) {
+            if (lane == 0) status[p] = 2;
+            return;
+        }
+        if (lane < nr) {
+            if (tr) match[po + c4] = to + lane;
+            else match[po + lane] = to + c4;
+        }
         return;
     }
     for (int i = lane; i < nr; i += 64) { u[i] = 0.0; col4row[i] = -1; }
