@@ -77,7 +77,7 @@ __device__ __forceinline__ int wave_max_i(int x) {
 
 // (value, preference key) arg-min over the wave in ONE butterfly: smaller value wins, ties go to the LARGER key.  The four
 // intra-row steps are DPP lane permutations (quad xor 1 / xor 2, row_half_mirror, row_mirror: no LDS traffic, a few cycles
-// each), the xor-16 step is the one remaining ds_bpermute round trip and the xor-32 step is v_permlane32_swap; every lane
+// each), the row-pair step is v_permlane16_swap and the last step v_permlane32_swap (gfx950); every lane
 // ends up with the wave's winner.  (Three __shfl_xor reductions — a double min, an int max, an int min = 24 dependent
 // ds_bpermutes — were 0.3 ms of this kernel's 0.55 ms critical path at the benchmark size.)
 struct MinKey { double s; int key; };
@@ -97,10 +97,16 @@ __device__ __forceinline__ MinKey wave_argmin(MinKey a) {
     a = dpp_step<0x4E>(a);   // quad_perm [2,3,0,1]
     a = dpp_step<0x141>(a);  // row_half_mirror: quads 0<->1, 2<->3 (every lane of a quad already holds the quad's winner)
     a = dpp_step<0x140>(a);  // row_mirror: halves of the 16-lane row
-    MinKey o;
-    o.s = __shfl_xor(a.s, 16, 64);
-    o.key = __shfl_xor(a.key, 16, 64);
-    a = better(a, o);
+    {   // rows 0 <-> 1 and 2 <-> 3 of the wave: v_permlane16_swap (no LDS round trip)
+        const unsigned long long ab = __builtin_bit_cast(unsigned long long, a.s);
+        const HalfPair l16 = swap_rows16((unsigned)ab), h16 = swap_rows16((unsigned)(ab >> 32)), k16 = swap_rows16((unsigned)a.key);
+        MinKey e, o;
+        e.s = __builtin_bit_cast(double, ((unsigned long long)h16.lo << 32) | l16.lo);
+        e.key = (int)k16.lo;
+        o.s = __builtin_bit_cast(double, ((unsigned long long)h16.hi << 32) | l16.hi);
+        o.key = (int)k16.hi;
+        a = better(e, o);
+    }
     const unsigned long long bits = __builtin_bit_cast(unsigned long long, a.s);
     const HalfPair l = swap_halves((unsigned)bits), hw = swap_halves((unsigned)(bits >> 32)), k = swap_halves((unsigned)a.key);
     MinKey p0, p1;  // the winners of lanes 0-31 and of lanes 32-63, both visible in every lane
