@@ -249,6 +249,14 @@ int svol_vit_embed(const float* patch_proj, const float* cls_token, const float*
 int svol_im2col(const void* x, int64_t sn, int64_t sh, int64_t sw, int64_t sc, int src_dtype, void* cols, int64_t ldcols,
                 int64_t N, int64_t H, int64_t W, int64_t C, int64_t kh, int64_t kw, int64_t stride, int64_t pad, int dtype,
                 void* stream);
+/* Convolution without the im2col matrix (bf16, C % 32 == 0): y[(n,ho,wo), co] = act(sum x[n, ho*stride-pad+ky, wo*stride-pad+kx, c]
+ * * w[co, (ky*kw + kx)*C + c] + bias[co] (+ residual[(n,ho,wo), co])); x NHWC contiguous, w [Cout, >= kh*kw*C] with leading
+ * dimension ldw, y / residual [N*Ho*Wo, Cout] contiguous; act in {SVOL_ACT_NONE, SVOL_ACT_RELU, SVOL_ACT_RELU_RES}.  The GEMM
+ * tile kernel gathers its A operand from the activation tensor inside its LDS-DMA loads (zero padding = out-of-range buffer
+ * offsets).  Returns SVOL_E_UNSUPPORTED for shapes it does not take (the caller then uses svol_im2col + svol_gemm_nt). */
+int svol_conv_nhwc(const void* x, const void* w, int64_t ldw, void* y, const float* bias, int act, const void* residual,
+                   int64_t N, int64_t H, int64_t W, int64_t C, int64_t Cout, int64_t kh, int64_t kw, int64_t stride,
+                   int64_t pad, int dtype, void* stream);
 /* nn.MaxPool2d(k, stride, pad) on NHWC activations, C % 8 == 0 (resnet stem: 3, 2, 1). */
 int svol_maxpool_nhwc(const void* x, void* y, int64_t N, int64_t H, int64_t W, int64_t C, int64_t k, int64_t stride,
                       int64_t pad, int dtype, void* stream);

@@ -27,6 +27,10 @@ struct FastArgs {
     const float* bias; const float* colscale; bf16_t* pre; const void* res; const bf16_t* aux; float* colsum;
     int64_t lda, ldb, ldc, ldp, ldr, ldaux;
     int M, N, K, act, epi;
+    // implicit-GEMM convolution (CONV instantiation): A is an NHWC activation [n, cH, cW, cC]; row m of the GEMM is output pixel
+    // (n, ho, wo) and column k = (ky*ckw + kx)*cC + c is gathered on the fly — the im2col matrix never exists
+    int cH, cW, cC, ckw, cstride, cpad, cHo, cWo;
+    int64_t a_bytes;
 };
 
 constexpr int EP_STRIDE = 272;       // bytes per staged accumulator row (64 floats + 16 pad)
@@ -61,7 +65,7 @@ template <> struct Out4<bf16_t> {
     }
 };
 
-template <typename TC, int BK>
+template <typename TC, int BK, bool CONV = false>
 __device__ __forceinline__ void gemm_nt_bf16_body(const FastArgs& p) {
     constexpr int RB = BK * 2;                 // bytes per image row
     constexpr int CPR = RB / 16;               // chunks per row
@@ -78,26 +82,51 @@ __device__ __forceinline__ void gemm_nt_bf16_body(const FastArgs& p) {
 
     // buffer descriptors rooted at this workgroup's tile rows: out-of-range rows read as zero
     const int rowsA = min(128, p.M - bm), rowsB = min(128, p.N - bn);
-    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.A + (int64_t)bm * p.lda), 0, (int)(((int64_t)rowsA * p.lda) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = CONV
+        ? __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000)   // the whole activation tensor
+        : __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)bm * p.lda), 0, (int)(((int64_t)rowsA * p.lda) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.B + (int64_t)bn * p.ldb), 0, (int)(((int64_t)rowsB * p.ldb) * 2), 0x00020000);
     // the LDS side of an LDS-DMA is lane-linear (slot lane%CPR of row lane/CPR): permute the SOURCE chunk instead.
     // slot_of is an involution in ch for a fixed row, so the chunk stored in slot s is slot_of(row, s).
     int voffA[NI], voffB[NI];
+    int cvh[NI], cvw[NI], cvn[NI];  // CONV: input row / column of the window origin, image row base; cvn < 0: row past M
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int row = (wave * NI + i) * RPI + lane / CPR;
         const int lch = slot_of<BK>(row, lane % CPR);
-        voffA[i] = (int)(((int64_t)row * p.lda + lch * 8) * 2);
+        voffA[i] = CONV ? lch * 16 : (int)(((int64_t)row * p.lda + lch * 8) * 2);
         voffB[i] = (int)(((int64_t)row * p.ldb + lch * 8) * 2);
+        if (CONV) {
+            const int m = bm + row;
+            const int wo = m % p.cWo, t_ = m / p.cWo;
+            const int ho = t_ % p.cHo, n = t_ / p.cHo;
+            cvh[i] = ho * p.cstride - p.cpad;
+            cvw[i] = wo * p.cstride - p.cpad;
+            cvn[i] = m < p.M ? n * p.cH : -(1 << 28);
+        }
     }
     auto issue = [&](int stage, int k0) {
         char* sa = smem + stage * STAGE;
         char* sb = smem + (2 + stage) * STAGE;
+        int ky = 0, kx = 0, c0 = 0;
+        if (CONV) {  // a K step never straddles two (ky, kx) segments: cC % BK == 0
+            const int seg = k0 / p.cC;
+            c0 = k0 - seg * p.cC;
+            ky = seg / p.ckw;
+            kx = seg - ky * p.ckw;
+        }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(sa + (wave * NI + i) * 1024), 16, voffA[i], k0 * 2, 0, 0);
+            if (CONV) {
+                const int hi = cvh[i] + ky, wi = cvw[i] + kx;
+                const bool ok = cvn[i] >= 0 && (unsigned)hi < (unsigned)p.cH && (unsigned)wi < (unsigned)p.cW;
+                // padding / rows past M: an offset past the buffer's size reads as zero (hardware bounds check)
+                const int off = ok ? ((((cvn[i] + hi) * p.cW + wi) * p.cC + c0) * 2 + voffA[i]) : 0x7ffffff0;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(sa + (wave * NI + i) * 1024), 16, off, 0, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(sa + (wave * NI + i) * 1024), 16, voffA[i], k0 * 2, 0, 0);
+            }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_ptr)(sb + (wave * NI + i) * 1024), 16, voffB[i], k0 * 2, 0, 0);
         }
     };
@@ -241,6 +270,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_f32_k64(FastArgs p) { gem
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_b16_k64(FastArgs p) { gemm_nt_bf16_body<bf16_t, 64>(p); }
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_f32_k32(FastArgs p) { gemm_nt_bf16_body<float, 32>(p); }
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_b16_k32(FastArgs p) { gemm_nt_bf16_body<bf16_t, 32>(p); }
+__global__ __launch_bounds__(256, 2) void conv_nhwc_bf16_k64(FastArgs p) { gemm_nt_bf16_body<bf16_t, 64, true>(p); }
+__global__ __launch_bounds__(256, 2) void conv_nhwc_bf16_k32(FastArgs p) { gemm_nt_bf16_body<bf16_t, 32, true>(p); }
 
 // ---------------------------------------------------------------------------------------------------
 // Skinny-M variant (the query stream: M = B * num_queries = 800 rows at the benchmark size).  A 128x128
@@ -433,3 +464,33 @@ int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ld
     }
     return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
 }
+
+// Implicit-GEMM convolution on NHWC bf16 activations: y[(n,ho,wo), co] = act(sum_{ky,kx,c} x[n, ho*s-p+ky,
+// wo*s-p+kx, c] * w[co, (ky,kx,c)] + bias[co] (+ residual)), the 128x128 tile kernel above with the A operand gathered by the
+// LDS-DMA loads themselves (padding = out-of-range buffer offsets, which read as zero).  C % 32 == 0.
+extern "C" int svol_conv_nhwc(const void* x, const void* w, int64_t ldw, void* y, const float* bias, int act, const void* residual,
+                              int64_t N, int64_t H, int64_t W, int64_t C, int64_t Cout, int64_t kh, int64_t kw, int64_t stride,
+                              int64_t pad, int dtype, void* stream) {
+    if (!x || !w || !y || N < 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0)
+        return SVOL_E_INVALID;
+    if (dtype != SVOL_BF16) return SVOL_E_UNSUPPORTED;
+    const int64_t Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return SVOL_E_INVALID;
+    const int64_t M = N * Ho * Wo, K = kh * kw * C;
+    if (M == 0) return SVOL_OK;
+    if (C % 32 || ldw < K || ldw % 8 || Cout % 4 || !aligned16(x) || !aligned16(w) || !aligned16(y)) return SVOL_E_UNSUPPORTED;
+    if (residual && !aligned16(residual)) return SVOL_E_UNSUPPORTED;
+    const int64_t a_bytes = N * H * W * C * 2;
+    if (a_bytes >= 0x7ffffff0ll || M >= (1ll << 31) || (int64_t)128 * ldw * 2 >= (1ll << 31)) return SVOL_E_UNSUPPORTED;
+    if (act != SVOL_ACT_NONE && act != SVOL_ACT_RELU && act != SVOL_ACT_RELU_RES) return SVOL_E_UNSUPPORTED;
+    FastArgs p{(const bf16_t*)x, (const bf16_t*)w, y, bias, nullptr, nullptr, residual, nullptr, nullptr,
+               0, ldw, Cout, 0, Cout, 0, (int)M, (int)Cout, (int)K, act, 0,
+               (int)H, (int)W, (int)C, (int)kw, (int)stride, (int)pad, (int)Ho, (int)Wo, a_bytes};
+    dim3 grid((unsigned)((Cout + 127) / 128), (unsigned)((M + 127) / 128));
+    if (grid.y > 65535u) return SVOL_E_UNSUPPORTED;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (C % 64 == 0 && K >= 1024) hipLaunchKernelGGL(conv_nhwc_bf16_k64, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv_nhwc_bf16_k32, grid, dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
+}
+

@@ -6,7 +6,8 @@ maps into tokens (backbone.py:72-89).  This module keeps that Sequential's child
 layer1-4 — so the ``backbone.{video,sketch}_backbone.*`` keys of a reference checkpoint load unchanged, and uses
 ``nn.Conv2d`` / ``nn.BatchNorm2d`` purely as parameter containers.  Arithmetic (svol_amd/csrc/resnet.hip + the GEMMs):
 
-  conv + eval-mode BatchNorm (+ identity) (+ ReLU)  =  svol_im2col -> svol_gemm_nt with the BatchNorm scale folded into the
+  conv + eval-mode BatchNorm (+ identity) (+ ReLU)  =  svol_conv_nhwc (implicit GEMM: the tile kernel gathers its A operand from
+  the NHWC activation, no im2col matrix; the stem and odd widths: svol_im2col -> svol_gemm_nt) with the BatchNorm scale folded into the
   weights ([Cout, kh*kw*Cin], (ky,kx,c) order, K padded to 32), the BatchNorm shift as bias and the ReLU — for a block's second
   convolution the ReLU AFTER the identity add (SVOL_ACT_RELU_RES) — in the GEMM epilogue; 3x3 s2 max pooling and the sketch
   branch's global average pooling are their own kernels; activations are NHWC from the stem to the tokens.
@@ -108,18 +109,9 @@ class ResNetExtractor(nn.Module):
         C = w0.shape[0]
         y, H, W = ops.maxpool_nhwc(y, n, H, W, C, 3, 2, 1)
         for stride, planes, (w1, b1), (w2, b2), down in f['blocks']:
-            cols, Ho, Wo = ops.im2col(y, n, H, W, C, 3, 3, stride, 1, dt, ldcols=w1.shape[1])
-            t = ops.gemm_nt(cols, w1, b1, ops.ACT_RELU)
-            del cols
-            if down is not None:
-                cols, _, _ = ops.im2col(y, n, H, W, C, 1, 1, stride, 0, dt, ldcols=down[0].shape[1])
-                idt = ops.gemm_nt(cols, down[0], down[1])
-                del cols
-            else:
-                idt = y
-            cols, _, _ = ops.im2col(t, n, Ho, Wo, planes, 3, 3, 1, 1, dt, ldcols=w2.shape[1])
-            y = ops.gemm_nt(cols, w2, b2, ops.ACT_RELU_RES, residual=idt)
-            del cols
+            t, Ho, Wo = ops.conv_nhwc(y, w1, b1, ops.ACT_RELU, n, H, W, C, 3, 3, stride, 1)
+            idt = ops.conv_nhwc(y, down[0], down[1], ops.ACT_NONE, n, H, W, C, 1, 1, stride, 0)[0] if down is not None else y
+            y, _, _ = ops.conv_nhwc(t, w2, b2, ops.ACT_RELU_RES, n, Ho, Wo, planes, 3, 3, 1, 1, residual=idt)
             H, W, C = Ho, Wo, planes
         if self.avgpool:
             return ops.avgpool_nhwc(y, n, H * W, C)

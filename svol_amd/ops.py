@@ -9,6 +9,7 @@ non-CUDA tensor or a missing library raises.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -288,6 +289,26 @@ def im2col(x, N, H, W, C, kh, kw, stride, pad, dtype, strides=None, ldcols=None)
                                 _stream())
     _lib.check(rc, 'svol_im2col')
     return cols, Ho, Wo
+
+
+def conv_nhwc(x, w, bias, act, N, H, W, C, kh, kw, stride, pad, residual=None):
+    """convolution of an NHWC activation [N*H*W, C] with folded weights w [Cout, kh*kw*C (+pad)] -> (y [N*Ho*Wo, Cout], Ho, Wo).
+    The implicit-GEMM kernel when the shape fits it (bf16, C % 32 == 0), else im2col + gemm_nt."""
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    Cout = w.shape[0]
+    if x.dtype == torch.bfloat16 and C % 32 == 0 and _CONV_IMPLICIT:
+        y = torch.empty((N * Ho * Wo, Cout), dtype=x.dtype, device=x.device)
+        rc = _lib.lib().svol_conv_nhwc(_ptr(x), _ptr(w), w.stride(0), _ptr(y), _ptr(bias), act, _ptr(residual), N, H, W, C, Cout, kh,
+                                       kw, stride, pad, _dt(x), _stream())
+        if rc == 0:
+            return y, Ho, Wo
+        if rc != -2:  # SVOL_E_UNSUPPORTED falls through to the explicit path
+            _lib.check(rc, 'svol_conv_nhwc')
+    cols, Ho, Wo = im2col(x, N, H, W, C, kh, kw, stride, pad, x.dtype, ldcols=w.shape[1])
+    return gemm_nt(cols, w, bias, act, residual=residual), Ho, Wo
+
+
+_CONV_IMPLICIT = os.environ.get('SVOL_CONV_IM2COL') is None
 
 
 def maxpool_nhwc(x, N, H, W, C, k, stride, pad):

@@ -100,3 +100,33 @@ def test_resnet_backbone_through_build_model():
     assert float((s.float().cpu() - rs).abs().max()) / float(rs.abs().max()) < 3e-2
     out = model(sk.to(DEV), vid.to(DEV), torch.ones(1, 1, device=DEV), torch.ones(1, 2, device=DEV))
     assert out['pred_boxes'].shape == (1, 10, 4) and bool(torch.isfinite(out['pred_logits']).all())
+
+
+def test_implicit_conv_matches_im2col_path():
+    """svol_conv_nhwc (A operand gathered inside the GEMM's LDS-DMA loads) against torch's conv2d: 3x3 s1 / s2 with padding,
+    1x1 s2, ragged M (rows past the last tile), residual + ReLU-after-residual, K step 32 and 64."""
+    from svol_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for (N, H, W, C, Cout, k, s, p, act, res) in [(2, 14, 14, 64, 64, 3, 1, 1, 'relu', False), (3, 13, 9, 64, 128, 3, 2, 1, 'relu', False),
+                                                  (2, 12, 12, 128, 256, 1, 2, 0, 'none', False), (2, 10, 10, 128, 128, 3, 1, 1, 'relu_res', True),
+                                                  (1, 7, 7, 256, 512, 3, 1, 1, 'relu_res', True), (5, 9, 11, 32, 36, 3, 1, 1, 'none', False)]:
+        x = torch.randn(N, C, H, W, generator=g)
+        w = torch.randn(Cout, C, k, k, generator=g) / (C * k * k) ** 0.5
+        b = torch.randn(Cout, generator=g)
+        xb, wb = x.to(torch.bfloat16), w.to(torch.bfloat16)
+        ref = F.conv2d(xb.double(), wb.double(), b.double(), s, p)
+        Ho, Wo = ref.shape[2], ref.shape[3]
+        r = torch.randn(N, Cout, Ho, Wo, generator=g).to(torch.bfloat16) if res else None
+        if res:
+            ref = ref + r.double()
+        if act != 'none':
+            ref = torch.relu(ref)
+        nhwc = xb.permute(0, 2, 3, 1).contiguous().view(-1, C).to(DEV)
+        wf = wb.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(DEV)
+        rr = r.permute(0, 2, 3, 1).contiguous().view(-1, Cout).to(DEV) if res else None
+        code = {'none': ops.ACT_NONE, 'relu': ops.ACT_RELU, 'relu_res': ops.ACT_RELU_RES}[act]
+        y, ho, wo = ops.conv_nhwc(nhwc, wf, b.to(DEV), code, N, H, W, C, k, k, s, p, residual=rr)
+        assert (ho, wo) == (Ho, Wo)
+        got = y.float().cpu().view(N, Ho, Wo, Cout).permute(0, 3, 1, 2).double()
+        err = float((got - ref).abs().max()) / float(ref.abs().max())
+        assert err < 1.2e-2, (N, H, W, C, Cout, k, s, p, act, err)
