@@ -104,3 +104,39 @@ def test_cfg5_long_video_runs_streaming():
     assert torch.cuda.max_memory_allocated() < 16e9
     assert len(idx) == args.num_layers and len(idx[-1][0][0]) == min(args.num_queries, sum(
         len(v) for v in tg[0]['bboxes'].values()))
+
+
+def test_encdec_full_size_masked_keys_cannot_be_seen():
+    """The enc/dec head at the benchmark shapes (B = 2, L = 6272 + 1 sketch token, bf16): its encoder self-attention and decoder
+    cross-attention run on the tile-classified fast kernels (plain / mixed / skipped key tiles).  Size-independent property:
+    features under the key-padding mask are invisible — replacing them with garbage changes NOTHING (bit for bit), for the padded
+    video and for the other one — and a backward pass through the masked kernels yields finite gradients with exact zeros where
+    the mask says so."""
+    from svol_amd import synthetic as syn
+    from svol_amd.modeling.svanet_variants import build_svanet
+    args = syn.encdec_args(hidden_dim=256, nheads=8, num_queries=100, num_frames=32, enc_layers=2, dec_layers=2, dim_feedforward=1024,
+                           dropout=0.0, pre_norm=False, mode='append_to_seq', feat_dim=512, num_layers=2)
+    args.input_vid_dim = args.input_skch_dim = 512
+    torch.manual_seed(1)
+    model = build_svanet(args).cuda().eval()
+    B, T, P = 2, 32, 196
+    inp = {k: v.cuda() for k, v in syn.synth_inputs(args, B, T, P, seed=7, pad_frames=8).items()}  # video 1: last 8 frames padded
+    npad = 8 * P
+    assert float(inp['src_video_mask'][1, -npad:].sum()) == 0 and float(inp['src_video_mask'][0].sum()) == T * P
+    garbage = dict(inp)
+    gv = inp['src_video'].clone()
+    gv[1, -npad:] = 1e3 * torch.randn_like(gv[1, -npad:])
+    garbage['src_video'] = gv
+    with torch.no_grad():
+        a = model(inp['src_sketch'], inp['src_sketch_mask'], inp['src_video'], inp['src_video_mask'])
+        b = model(garbage['src_sketch'], garbage['src_sketch_mask'], garbage['src_video'], garbage['src_video_mask'])
+    assert torch.isfinite(a['pred_logits']).all() and torch.isfinite(a['pred_boxes']).all()
+    assert torch.equal(a['pred_logits'], b['pred_logits']) and torch.equal(a['pred_boxes'], b['pred_boxes'])
+    for x, y in zip(a['aux_outputs'], b['aux_outputs']):
+        assert torch.equal(x['pred_logits'], y['pred_logits']) and torch.equal(x['pred_boxes'], y['pred_boxes'])
+    # backward through the masked kernels: gradient w.r.t. the padded features is exactly zero
+    vid = inp['src_video'].clone().requires_grad_(True)
+    out = model(inp['src_sketch'], inp['src_sketch_mask'], vid, inp['src_video_mask'])
+    (out['pred_logits'].float().sum() + out['pred_boxes'].float().sum()).backward()
+    assert torch.isfinite(vid.grad).all()
+    assert float(vid.grad[1, -npad:].abs().max()) == 0.0 and float(vid.grad[1, :-npad].abs().max()) > 0.0
