@@ -1,0 +1,56 @@
+"""The whole loop learns: 60 optimisation steps on ONE fixed synthetic batch (SVANet head, bf16, criterion on the device, gradient
+buckets + sinks, FlatAdamW, per-step weight refresh) must drive the weighted loss down and keep everything finite; the same loop
+with torch.optim.AdamW on ordinary per-parameter gradients must land at (nearly) the same loss — the two optimiser / gradient
+plumbing variants are the same algorithm."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(flat, steps=60):
+    from svol_amd import parallel
+    from svol_amd import synthetic as syn
+    from svol_amd.modeling.loss import build_loss
+    from svol_amd.modeling.svanet import build_svanet
+    args = syn.head_args(hidden_dim=128, nheads=8, num_layers=2, num_queries=20, num_frames=8, input_vid_dim=64, input_skch_dim=64,
+                         input_dropout=0.0, matcher='video_matcher')
+    args.compute_dtype = 'bf16'
+    torch.manual_seed(1)
+    model = build_svanet(args).cuda().train()
+    crit = build_loss(args).cuda().train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    if flat:
+        red = parallel.BucketedGradAllReduce(params, skip=parallel.unused_parameters(model))
+        opt = parallel.FlatAdamW(red, lr=2e-3, weight_decay=1e-4)
+    else:
+        red = None
+        opt = torch.optim.AdamW(params, lr=2e-3, weight_decay=1e-4)
+    B, T, P = 2, 8, 32
+    inp = {k: v.cuda() for k, v in syn.synth_inputs(args, B, T, P, seed=3).items()}
+    tg = syn.synth_targets(B, T, seed=3)
+    losses = []
+    for _ in range(steps):
+        if flat:
+            red.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=True)
+        out = model(inp['src_sketch'], inp['src_sketch_mask'], inp['src_video'], inp['src_video_mask'])
+        crit(out, tg)
+        loss = crit.weighted_total()
+        loss.backward()
+        if flat:
+            red.finish()
+        opt.step()
+        losses.append(float(loss))
+    return losses
+
+
+def test_training_loop_learns_and_optimiser_variants_agree():
+    a = _run(flat=True)
+    b = _run(flat=False)
+    assert all(x == x and abs(x) < 1e4 for x in a + b)
+    assert a[-1] < 0.6 * a[0], (a[0], a[-1])
+    assert b[-1] < 0.6 * b[0], (b[0], b[-1])
+    assert abs(a[0] - b[0]) <= 1e-4 * abs(b[0])                 # identical initial state
+    assert abs(a[-1] - b[-1]) <= 0.15 * abs(b[-1]), (a[-1], b[-1])  # same trajectory up to bf16 / atomic-order noise
