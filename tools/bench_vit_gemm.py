@@ -21,3 +21,12 @@ for (N, K, act, name) in [(2304, 768, ops.ACT_NONE, 'qkv'), (768, 768, ops.ACT_N
     b = torch.zeros(N, device='cuda')
     t = timeit(lambda: ops.gemm_nt(A, W, b, act))
     print(f'{name:4s} M={M} N={N} K={K}: {t:.3f} ms  {2.0 * M * N * K / t / 1e9:.0f} TFLOP/s', flush=True)
+# the fp32-residual-stream variants (out-proj and fc2 write x32 + proj into the fp32 stream)
+for (N, K, name) in [(768, 768, 'out+res32'), (768, 3072, 'fc2+res32')]:
+    A = (torch.randn(M, K, device='cuda') * 0.5).to(torch.bfloat16)
+    W = (torch.randn(N, K, device='cuda') * 0.05).to(torch.bfloat16)
+    b = torch.zeros(N, device='cuda')
+    R = torch.randn(M, N, device='cuda')
+    t = timeit(lambda: ops.gemm_nt(A, W, b, ops.ACT_NONE, residual=R, out_f32=True))
+    gb = (M * K * 2 + 2 * M * N * 4) / 1e9
+    print(f'{name:10s} M={M} N={N} K={K}: {t:.3f} ms  {2.0 * M * N * K / t / 1e9:.0f} TFLOP/s  {gb / t * 1e3:.0f} GB/s algorithmic', flush=True)
