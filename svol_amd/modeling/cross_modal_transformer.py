@@ -87,25 +87,25 @@ class _GateVectorsFn(torch.autograd.Function):
         h = ctx.h
         d = skch.shape[1]
         dh = d // h
+        B = skch.shape[0]
         sW, sb = ctx.sinks
-        du = du * (dh ** -0.5)
+        sc = dh ** -0.5
         wk = W_in[d:2 * d].view(h, dh, d)
-        dq = torch.einsum('bhd,hed->bhe', du, wk).reshape(-1, d)           # [B,d]
-        dwk = torch.einsum('bhd,bhe->hed', du, q.view(-1, h, dh)).reshape(d, d)
-        dWq = dq.t() @ skch
-        dbq = dq.sum(0)
+        duh = du.transpose(0, 1)                                            # [h,B,d] (view)
+        dq = torch.bmm(duh, wk.transpose(1, 2)).transpose(0, 1).reshape(B, d).mul_(sc)  # sum_d du[b,h,d] wk[h,e,d] -> [B, h*dh]
+        qh = q.view(B, h, dh).permute(1, 2, 0)                              # [h,dh,B] (view)
         dskch = dq @ W_in[:d] if ctx.needs_input_grad[0] else None
-        if sW is not None:
-            sW.view[:d].add_(dWq)
-            sW.view[d:2 * d].add_(dwk)
+        if sW is not None:  # straight into the gradient bucket: two fused multiply-accumulates, no temporaries
+            sW.view[:d].addmm_(dq.t(), skch)
+            sW.view[d:2 * d].view(h, dh, d).baddbmm_(qh, duh, alpha=sc)
             dW = None
         else:
-            dW = torch.cat([dWq, dwk, torch.zeros_like(dwk)])
+            dW = torch.cat([dq.t() @ skch, torch.bmm(qh, duh).mul_(sc).reshape(d, d), torch.zeros((d, d), dtype=du.dtype, device=du.device)])
         if sb is not None:
-            sb.view[:d].add_(dbq)
+            sb.view[:d].add_(dq.sum(0))
             db = None
         else:
-            db = torch.cat([dbq, torch.zeros(2 * d, dtype=dbq.dtype, device=dbq.device)])
+            db = torch.cat([dq.sum(0), torch.zeros(2 * d, dtype=dq.dtype, device=dq.device)])
         return dskch, dW, db, None
 
 
