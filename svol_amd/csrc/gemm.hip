@@ -40,24 +40,29 @@ struct NtArgs {
 };
 
 // TC = element type of C and of the residual (T, or float for the fp32 residual stream)
-template <typename T, typename TC>
+// TILE = 128 (four waves of 64x64) or 64 (four waves of 32x32): the small tile for launches whose 128-tiling would leave most
+// CUs idle (the fp32 class / box heads: 4800 x 256 outputs = 76 workgroups -> 300)
+template <typename T, typename TC, int TILE = 128>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs p) {
+    constexpr int WT = TILE / 2;        // rows / columns per wave
+    constexpr int FT = WT / 16;         // 16x16 fragments per wave and direction
+    constexpr int LI = TILE * 8 / 256;  // 16-byte chunks per thread and operand per K step
     constexpr int EPC = Tr<T>::EPC;
     constexpr int BK = 8 * EPC;
-    __shared__ __attribute__((aligned(16))) char smem[2 * 128 * 128];
+    __shared__ __attribute__((aligned(16))) char smem[2 * TILE * 128];
     char* sA = smem;
-    char* sB = smem + 128 * 128;
+    char* sB = smem + TILE * 128;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int bm = blockIdx.y * 128, bn = blockIdx.x * 128;
+    const int bm = blockIdx.y * TILE, bn = blockIdx.x * TILE;
     const T* A = reinterpret_cast<const T*>((p.A2 != nullptr && bn >= p.n_split) ? p.A2 : p.A);
     const T* B = reinterpret_cast<const T*>(p.B);
 
-    uint4 ra[4], rb[4];
+    uint4 ra[LI], rb[LI];
     auto load_tile = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < LI; ++i) {
             const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
             const int kk = k0 + ch * EPC;
             const int gm = bm + row, gn = bn + row;
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs p) {
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < LI; ++i) {
             const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
             const int off = row * 128 + ((ch ^ (row & 7)) << 4);
             *reinterpret_cast<uint4*>(sA + off) = ra[i];
@@ -77,11 +82,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs p) {
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[FT][FT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fq = lane >> 4;
     load_tile(0);
@@ -91,18 +96,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs p) {
         if (k0 + BK < p.K) load_tile(k0 + BK);  // next tile's HBM latency hides under the MFMAs
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            uint4 af[4], bf[4];
+            uint4 af[FT], bf[FT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int rowA = wm * 64 + t * 16 + fr;
+            for (int t = 0; t < FT; ++t) {
+                const int rowA = wm * WT + t * 16 + fr;
                 af[t] = *reinterpret_cast<const uint4*>(sA + rowA * 128 + (((4 * g + fq) ^ (rowA & 7)) << 4));
-                const int rowB = wn * 64 + t * 16 + fr;
+                const int rowB = wn * WT + t * 16 + fr;
                 bf[t] = *reinterpret_cast<const uint4*>(sB + rowB * 128 + (((4 * g + fq) ^ (rowB & 7)) << 4));
             }
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < FT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) mma_chunk(acc[mt][nt], af[mt], bf[nt], T());
+                for (int nt = 0; nt < FT; ++nt) mma_chunk(acc[mt][nt], af[mt], bf[nt], T());
         }
         __syncthreads();
     }
@@ -112,16 +117,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs p) {
     T* pre = reinterpret_cast<T*>(p.pre);
     const TC* res = reinterpret_cast<const TC*>(p.res);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < FT; ++mt) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = bn + wn * 64 + nt * 16 + fr;
+        for (int nt = 0; nt < FT; ++nt) {
+            const int n = bn + wn * WT + nt * 16 + fr;
             if (n >= p.N) continue;
             const float bv = p.bias ? p.bias[n] : 0.f;
             const float cs = p.colscale ? p.colscale[n] : 1.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = bm + wm * 64 + mt * 16 + fq * 4 + r;
+                const int m = bm + wm * WT + mt * 16 + fq * 4 + r;
                 if (m >= p.M) continue;
                 float v = (acc[mt][nt][r] + bv) * cs;
                 if (pre) pre[(int64_t)m * p.ldp + n] = from_f32<T>(v);
@@ -455,9 +460,14 @@ int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, co
                                               0, nullptr, 0, colscale, M, N, K, s);
         if (rc != SVOL_E_UNSUPPORTED) return rc;
     }
+    // 64x64 tiles when the 128x128 tiling would leave most of the 256 CUs idle (the fp32 heads: M = 4800, N = 256 -> 76 workgroups)
+    const bool small = (int64_t)grid.x * grid.y < 256 && (M + 63) / 64 <= 65535;
+    const dim3 g64((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
     if (dtype == SVOL_BF16) {
         if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, p);
+    } else if (small) {
+        hipLaunchKernelGGL((gemm_nt_kernel<float, float, 64>), g64, dim3(256), 0, s, p);
     } else {
         hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, dim3(256), 0, s, p);
     }
