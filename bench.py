@@ -145,6 +145,7 @@ def main():
     inp = {k: v.to(dev) for k, v in syn.synth_inputs(args, B, T, P, seed=1 + rank).items()}
     tg = syn.synth_targets(B, T, seed=1 + rank)
     wd = crit.weight_dict
+    n_dec = args.dec_layers if a.workload == 'encdec' else args.num_layers  # decoder layers whose outputs the criterion matches
     backbone = None
     if a.workload == 'cfg4':
         # frozen, randomly initialised ViT-B/16 extractors (the pretrained weights cannot be downloaded here); synthetic
@@ -170,6 +171,7 @@ def main():
         reducer.zero_grad()
         if backbone is not None:
             inp['src_sketch'], inp['src_video'] = backbone(pix_sketch, pix_video)
+        crit.prepack(tg, n_dec, B, args.num_queries, dev)  # target flattening + H2D copies issued before the forward's kernels
         out = model(inp['src_sketch'], inp['src_sketch_mask'], inp['src_video'], inp['src_video_mask'])
         ld = crit(out, tg)
         loss = crit.weighted_total()  # = sum(ld[k] * wd[k] for k in ld if k in wd) (train.py:227-228), one multiply + one reduction

@@ -35,6 +35,7 @@ class SetCriterion(nn.Module):
         self.last_match = None
         self.last_packed = None
         self.last_losses = None
+        self._prepacked = None
         # optional StaticPackedTargets (svol_amd.graph): when set, `targets` passed to forward() are ignored and
         # the pre-loaded static buffers are used (hipGraph capture / replay)
         self.static_packed = None
@@ -61,7 +62,13 @@ class SetCriterion(nn.Module):
         NL, B, N = logits_all.shape[:3]
         m = self.matcher
         if packed is None:
-            packed = self.static_packed if self.static_packed is not None else m.pack(targets, NL, B, N, logits_all.device)
+            pre = self._prepacked
+            if self.static_packed is not None:
+                packed = self.static_packed
+            elif pre is not None and pre[0] is targets and pre[1] == (NL, B, N):
+                packed, self._prepacked = pre[2], None
+            else:
+                packed = m.pack(targets, NL, B, N, logits_all.device)
         losses, match = ops.SetCriterionFn.apply(logits_all, boxes_all, packed, m.cost_bbox, m.cost_giou,
                                                  m.cost_class, self.eos_coef)
         self.last_match, self.last_packed, self.last_losses = match, packed, losses
@@ -80,6 +87,12 @@ class SetCriterion(nn.Module):
             for col, name in names:
                 out[f'{name}_{i}'] = flat[i * 4 + col]
         return out, packed
+
+    def prepack(self, targets, n_layers, B, N, device):
+        """Flatten `targets` (the Python list of dicts) and stage them on the device NOW — call it before the model's forward so
+        that the host-side packing and the host->device copies run under the forward's kernels instead of between the last
+        forward kernel and the cost kernel.  The next ``forward(outputs, targets)`` with the same list object uses the result."""
+        self._prepacked = (targets, (n_layers, B, N), self.matcher.pack(targets, n_layers, B, N, device))
 
     def weighted_total(self):
         """sum(loss_dict[k] * weight_dict[k] for k in loss_dict if k in weight_dict) (train.py:227-228) of the LAST forward,
