@@ -181,11 +181,14 @@ int svol_gate_bwd(const float* dy32, const void* dy, const void* dy2, const floa
  * [pred_off[p], pred_off[p]+pred_cnt[p]) of logits[R,2]/boxes[R,4] (fp32, R = layers*B*N) and target
  * boxes [tgt_off[p], tgt_off[p]+tgt_cnt[p]) of tgt_boxes[sumM,4] (fp32 cxcywh).
  *   cost = w_bbox * L1 + w_giou * (-GIoU) + w_class * (-softmax(logits)[0])   (matcher.py:76-85)
- * written to cost[cost_off[p] + i*tgt_cnt[p] + j]. */
+ * written to cost[cost_off[p] + i*tgt_cnt[p] + j].
+ * box_status (int32 [n_problems], may be NULL): box_status[p] = 1 when a prediction or target box of problem p fails
+ * generalized_box_iou's early check x1 >= x0 and y1 >= y0 (box_utils.py:51-52; NaN coordinates fail it), else 0.
+ * The reference raises AssertionError there; the host side of this build raises it lazily from the flag. */
 int svol_match_cost(const float* logits, const float* boxes, const float* tgt_boxes, const int32_t* pred_off,
                     const int32_t* pred_cnt, const int32_t* tgt_off, const int32_t* tgt_cnt,
                     const int64_t* cost_off, float* cost, int32_t n_problems, float w_bbox, float w_giou,
-                    float w_class, void* stream);
+                    float w_class, int32_t* box_status, void* stream);
 /* Batched rectangular LSAP, bit-exact restatement of scipy.optimize.linear_sum_assignment
  * (Crouse 2016 shortest augmenting path, fp64 duals, tall blocks solved transposed, reverse column
  * scan, tie rule "lower, or equal and unassigned").  match[r] = matched target index (global row of
@@ -204,11 +207,14 @@ int svol_lsap_batched(const float* cost, const int64_t* cost_off, const int32_t*
  * rebase_vid_off (int32 [B], first global target row of each video) non-NULL reproduces
  * PerFrameMatcher's target-id re-basing (matcher.py:114-115 + loss.py:87): the loss target of a matched
  * query is row vid_off[b] + (match - min matched id of video b); rows_per_video = N.  NULL for
- * HungarianMatcher. */
+ * HungarianMatcher.
+ * status / box_status (the outputs of svol_lsap_batched / svol_match_cost, layer-major with problems_per_layer entries
+ * per layer; either may be NULL): a layer with any non-zero flag gets NaN in its four losses — where the reference
+ * raises (scipy ValueError, box_utils AssertionError) this build stays asynchronous but cannot pass for a healthy step. */
 int svol_set_loss(const float* logits, const float* boxes, const float* tgt_boxes, const int32_t* match,
                   float* losses, float* g_label, float* g_bbox, float* g_giou, int32_t n_layers,
                   int32_t rows_per_layer, float eos_coef, const int32_t* rebase_vid_off, int32_t rows_per_video,
-                  void* stream);
+                  const int32_t* status, const int32_t* box_status, int32_t problems_per_layer, void* stream);
 
 /* ---- post-processing + evaluation (the step after the hot path: test.py:133-169, lib/evaluate/eval.py,
  * lib/evaluate/utils.py) ------------------------------------------------------------------

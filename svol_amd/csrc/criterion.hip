@@ -36,11 +36,28 @@ __global__ __launch_bounds__(256) void match_cost_kernel(const float* __restrict
                                                          const int32_t* __restrict__ tgt_off,
                                                          const int32_t* __restrict__ tgt_cnt,
                                                          const int64_t* __restrict__ cost_off, float* __restrict__ cost,
-                                                         float w_bbox, float w_giou, float w_class) {
+                                                         float w_bbox, float w_giou, float w_class,
+                                                         int32_t* __restrict__ box_status) {
     const int p = blockIdx.x;
     const int np = pred_cnt[p], nt = tgt_cnt[p];
     const int po = pred_off[p], to = tgt_off[p];
     float* C = cost + cost_off[p];
+    if (box_status) {
+        // generalized_box_iou's early check (box_utils.py:51-52): every box must satisfy x1 >= x0 and y1 >= y0 (a NaN
+        // coordinate fails it too).  The reference asserts on the host; here the problem is flagged and the host raises
+        // the AssertionError lazily (PackedTargets.check_status) — the criterion itself never synchronises.
+        int bad = 0;
+        for (int i = threadIdx.x; i < np; i += blockDim.x) {
+            const Box b = to_xyxy(boxes + (int64_t)(po + i) * 4);
+            bad |= !(b.x1 >= b.x0) || !(b.y1 >= b.y0);
+        }
+        for (int j = threadIdx.x; j < nt; j += blockDim.x) {
+            const Box b = to_xyxy(tgt + (int64_t)(to + j) * 4);
+            bad |= !(b.x1 >= b.x0) || !(b.y1 >= b.y0);
+        }
+        bad = __syncthreads_or(bad);
+        if (threadIdx.x == 0) box_status[p] = bad ? 1 : 0;
+    }
     for (int e = threadIdx.x; e < np * nt; e += blockDim.x) {
         const int i = e / nt, j = e - i * nt;
         const float* lg = logits + (int64_t)(po + i) * 2;
@@ -394,7 +411,9 @@ __global__ __launch_bounds__(256) void set_loss_kernel(const float* __restrict__
                                                        const float* __restrict__ tgt, const int32_t* __restrict__ match,
                                                        float* __restrict__ losses, float* __restrict__ g_label,
                                                        float* __restrict__ g_bbox, float* __restrict__ g_giou, int rows,
-                                                       float eos, const int32_t* __restrict__ vid_off, int rows_per_video) {
+                                                       float eos, const int32_t* __restrict__ vid_off, int rows_per_video,
+                                                       const int32_t* __restrict__ status,
+                                                       const int32_t* __restrict__ box_status, int problems_per_layer) {
     __shared__ double red[4];
     extern __shared__ int vmin[];  // per-video minimum matched target id (PerFrameMatcher re-basing quirk)
     const int layer = blockIdx.x;
@@ -453,7 +472,19 @@ __global__ __launch_bounds__(256) void set_loss_kernel(const float* __restrict__
     const double t_l1 = block_sum_d(s_l1, red);
     const double t_g = block_sum_d(s_g, red);
     const double t_ok = block_sum_d(s_ok, red);
-    if (threadIdx.x == 0) {
+    // a layer whose matching is not scipy's (NaN / -inf costs: scipy raises ValueError; infeasible) or whose boxes fail
+    // generalized_box_iou's check (the reference raises AssertionError) must not look like a healthy step: its losses
+    // become NaN, which every training loop's finite-loss check sees without a host sync here
+    int flagged = 0;
+    for (int q = threadIdx.x; q < problems_per_layer; q += 256) {
+        const int p = layer * problems_per_layer + q;
+        flagged |= (status && status[p] != 0) || (box_status && box_status[p] != 0);
+    }
+    flagged = __syncthreads_or(flagged);
+    if (threadIdx.x == 0 && flagged) {
+        const float qnan = __builtin_nanf("");
+        losses[layer * 4 + 0] = losses[layer * 4 + 1] = losses[layer * 4 + 2] = losses[layer * 4 + 3] = qnan;
+    } else if (threadIdx.x == 0) {
         losses[layer * 4 + 0] = (float)(t_nll / (double)rows);
         losses[layer * 4 + 1] = K > 0 ? (float)(t_l1 / (4.0 * K)) : 0.f;
         losses[layer * 4 + 2] = K > 0 ? (float)(t_g / K) : 0.f;
@@ -467,14 +498,15 @@ extern "C" {
 
 int svol_match_cost(const float* logits, const float* boxes, const float* tgt_boxes, const int32_t* pred_off,
                     const int32_t* pred_cnt, const int32_t* tgt_off, const int32_t* tgt_cnt, const int64_t* cost_off,
-                    float* cost, int32_t n_problems, float w_bbox, float w_giou, float w_class, void* stream) {
+                    float* cost, int32_t n_problems, float w_bbox, float w_giou, float w_class, int32_t* box_status,
+                    void* stream) {
     if (!logits || !boxes || !tgt_boxes || !pred_off || !pred_cnt || !tgt_off || !tgt_cnt || !cost_off || !cost)
         return SVOL_E_INVALID;
     if (n_problems < 0) return SVOL_E_INVALID;
     if (n_problems == 0) return SVOL_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(match_cost_kernel, dim3((unsigned)n_problems), dim3(256), 0, s, logits, boxes, tgt_boxes, pred_off,
-                       pred_cnt, tgt_off, tgt_cnt, cost_off, cost, w_bbox, w_giou, w_class);
+                       pred_cnt, tgt_off, tgt_cnt, cost_off, cost, w_bbox, w_giou, w_class, box_status);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }
@@ -501,9 +533,11 @@ int svol_lsap_batched(const float* cost, const int64_t* cost_off, const int32_t*
 
 int svol_set_loss(const float* logits, const float* boxes, const float* tgt_boxes, const int32_t* match, float* losses,
                   float* g_label, float* g_bbox, float* g_giou, int32_t n_layers, int32_t rows_per_layer, float eos_coef,
-                  const int32_t* rebase_vid_off, int32_t rows_per_video, void* stream) {
+                  const int32_t* rebase_vid_off, int32_t rows_per_video, const int32_t* status, const int32_t* box_status,
+                  int32_t problems_per_layer, void* stream) {
     if (!logits || !boxes || !tgt_boxes || !match || !losses || !g_label || !g_bbox || !g_giou) return SVOL_E_INVALID;
     if (n_layers <= 0 || rows_per_layer <= 0) return SVOL_E_INVALID;
+    if ((status || box_status) && problems_per_layer <= 0) return SVOL_E_INVALID;
     size_t lds = 0;
     if (rebase_vid_off) {
         if (rows_per_video <= 0 || rows_per_layer % rows_per_video) return SVOL_E_INVALID;
@@ -512,7 +546,8 @@ int svol_set_loss(const float* logits, const float* boxes, const float* tgt_boxe
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(set_loss_kernel, dim3((unsigned)n_layers), dim3(256), lds, s, logits, boxes, tgt_boxes, match, losses,
-                       g_label, g_bbox, g_giou, (int)rows_per_layer, eos_coef, rebase_vid_off, (int)rows_per_video);
+                       g_label, g_bbox, g_giou, (int)rows_per_layer, eos_coef, rebase_vid_off, (int)rows_per_video, status,
+                       box_status, (int)problems_per_layer);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }

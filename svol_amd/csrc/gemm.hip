@@ -428,7 +428,7 @@ int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ld
 
 extern "C" {
 
-int svol_abi_version(void) { return 1; }
+int svol_abi_version(void) { return 2; }
 
 const char* svol_strerror(int code) {
     switch (code) {

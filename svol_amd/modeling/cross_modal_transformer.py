@@ -52,11 +52,6 @@ def _side_stream(dev):
     s = _SIDE.get(dev)
     if s is None:
         s = _SIDE[dev] = torch.cuda.Stream(device=dev)
-        # parameters of the query half get their gradients from side-stream nodes by design
-        try:
-            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-        except AttributeError:  # pragma: no cover  (older torch)
-            pass
     return s
 
 

@@ -35,6 +35,7 @@ class SetCriterion(nn.Module):
         self.last_match = None
         self.last_packed = None
         self.last_losses = None
+        self._loss_table = None
         self._prepacked = None
         # optional StaticPackedTargets (svol_amd.graph): when set, `targets` passed to forward() are ignored and
         # the pre-loaded static buffers are used (hipGraph capture / replay)
@@ -71,7 +72,11 @@ class SetCriterion(nn.Module):
                 packed = m.pack(targets, NL, B, N, logits_all.device)
         losses, match = ops.SetCriterionFn.apply(logits_all, boxes_all, packed, m.cost_bbox, m.cost_giou,
                                                  m.cost_class, self.eos_coef)
-        self.last_match, self.last_packed, self.last_losses = match, packed, losses
+        # logging copy WITHOUT the autograd graph: keeping the graph-carrying table until the next call would pin the
+        # step's saved activations and AccumulateGrad nodes (and their creation streams) across iterations.  The one
+        # graph-carrying reference is consumed (and dropped) by weighted_total().
+        self.last_match, self.last_packed, self.last_losses = match, packed, losses.detach()
+        self._loss_table = losses
         out = {}
         names = []
         if 'labels' in self.losses:
@@ -98,7 +103,9 @@ class SetCriterion(nn.Module):
         """sum(loss_dict[k] * weight_dict[k] for k in loss_dict if k in weight_dict) (train.py:227-228) of the LAST forward,
         as one multiply + one reduction over the [n_layers, 4] loss table instead of a Python sum over 3 * n_layers
         0-d tensors (18 multiplies + 18 adds, and as many backward kernels, at 6 layers)."""
-        losses = self.last_losses
+        losses, self._loss_table = self._loss_table, None
+        if losses is None:
+            raise RuntimeError('weighted_total(): call forward() first (the loss table of a forward is consumed once)')
         NL = losses.shape[0]
         w = getattr(self, '_wtab', None)
         if w is None or w.shape[0] != NL or w.device != losses.device:

@@ -74,7 +74,8 @@ class PackedTargets:
         self.pred_off, self.pred_cnt, self.tgt_off, self.tgt_cnt = i32_d[0], i32_d[1], i32_d[2], i32_d[3]
         self.cost_off = torch.from_numpy(cost_off).to(device, non_blocking=True)
         self.tgt_boxes = tgt.to(device, non_blocking=True).contiguous()
-        self.status = torch.zeros((self.n_problems,), dtype=torch.int32, device=device)
+        self._flags = torch.zeros((2, self.n_problems), dtype=torch.int32, device=device)
+        self.status, self.box_status = self._flags[0], self._flags[1]  # LSAP status | degenerate-box flag, per problem
         self.vid_off = vid_off
         # PerFrameMatcher hands the criterion re-based target ids (matcher.py:114-115); the loss kernel
         # reproduces that with the per-video first-box offsets
@@ -83,11 +84,20 @@ class PackedTargets:
         self.last_cost = None
 
     def check_status(self):
-        """Raise like scipy does (ValueError) if any block had NaN/-inf costs.  Synchronises."""
-        st = self.status.cpu()
-        if int(st.max()) == 1:
+        """Raise what the reference raises, from the flags the kernels left (synchronises; one copy):
+        AssertionError when a prediction or target box fails generalized_box_iou's early check x1 >= x0, y1 >= y0
+        (box_utils.py:51-52 — the reference hits it while building the cost matrix, i.e. BEFORE scipy runs, so it
+        takes precedence), then scipy's ValueError for NaN / -inf costs or an infeasible block."""
+        fl = self._flags.cpu()
+        if self.n_problems == 0:
+            return
+        if int(fl[1].max()) != 0:
+            raise AssertionError('degenerate boxes: generalized_box_iou needs x1 >= x0 and y1 >= y0 for every '
+                                 'prediction and target box (NaN coordinates fail the check too)')
+        st = int(fl[0].max())
+        if st == 1:
             raise ValueError('matrix contains invalid numeric entries')
-        if int(st.max()) == 2:
+        if st == 2:
             raise ValueError('cost matrix is infeasible')
 
     def indices_from_match(self, match: torch.Tensor, layer: int):
@@ -132,7 +142,8 @@ class StaticPackedTargets:
         self.pred_off, self.pred_cnt, self.tgt_off, self.tgt_cnt = self._i32[0], self._i32[1], self._i32[2], self._i32[3]
         self.cost_off = torch.zeros((self.n_problems,), dtype=torch.int64, device=device)
         self.tgt_boxes = torch.zeros((B * self.cap_video, 4), dtype=torch.float32, device=device)
-        self.status = torch.zeros((self.n_problems,), dtype=torch.int32, device=device)
+        self._flags = torch.zeros((2, self.n_problems), dtype=torch.int32, device=device)
+        self.status, self.box_status = self._flags[0], self._flags[1]
         self.rebase_vid_off = (torch.zeros((B,), dtype=torch.int32, device=device)
                                if matcher == 'per_frame_matcher' else None)
         self.vid_off = np.zeros(B, np.int64)

@@ -930,7 +930,8 @@ class SetCriterionFn(torch.autograd.Function):
         g_giou = torch.empty_like(bx)
         rc = _lib.lib().svol_set_loss(_ptr(lg), _ptr(bx), _ptr(packed.tgt_boxes), _ptr(match), _ptr(losses),
                                       _ptr(g_label), _ptr(g_bbox), _ptr(g_giou), NL, rows, float(eos_coef),
-                                      _ptr(packed.rebase_vid_off), logits.shape[2], _stream())
+                                      _ptr(packed.rebase_vid_off), logits.shape[2], _ptr(packed.status),
+                                      _ptr(packed.box_status), packed.problems_per_layer, _stream())
         _lib.check(rc, 'svol_set_loss')
         ctx.save_for_backward(g_label, g_bbox, g_giou)
         ctx.mark_non_differentiable(match)
@@ -954,7 +955,8 @@ def match_all(lg, bx, packed, w_bbox, w_giou, w_class):
     L = _lib.lib()
     rc = L.svol_match_cost(_ptr(lg), _ptr(bx), _ptr(packed.tgt_boxes), _ptr(packed.pred_off), _ptr(packed.pred_cnt),
                            _ptr(packed.tgt_off), _ptr(packed.tgt_cnt), _ptr(packed.cost_off), _ptr(cost),
-                           packed.n_problems, float(w_bbox), float(w_giou), float(w_class), _stream())
+                           packed.n_problems, float(w_bbox), float(w_giou), float(w_class), _ptr(packed.box_status),
+                           _stream())
     _lib.check(rc, 'svol_match_cost')
     rc = L.svol_lsap_batched(_ptr(cost), _ptr(packed.cost_off), _ptr(packed.pred_off), _ptr(packed.pred_cnt),
                              _ptr(packed.tgt_off), _ptr(packed.tgt_cnt), _ptr(match), _ptr(packed.status),
