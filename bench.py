@@ -92,6 +92,22 @@ def main():
                          '(frozen ResNet-34 on the frames -> 49 tokens each, ResNet-18 on the sketch) online in front of the head')
     a = ap.parse_args()
 
+    if a.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, through
+        # torch.distributed.run as a CHILD process.  Nothing in this parent has touched the GPU (no HIP call, no
+        # torch.cuda.is_available()), it never re-execs, it only forwards the child's output and exit code.
+        import socket
+        import subprocess
+        s_ = socket.socket()
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        rc = subprocess.run(cmd, env=env).returncode
+        sys.exit(rc if rc else 0)
+
     import torch
     import torch.distributed as dist
     from svol_amd import ops, parallel
@@ -116,6 +132,12 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+    n_ranks_seen = 1
+    if world > 1:  # every rank of the job really is in the communicator (RCCL / gloo): sum of ones
+        ones = torch.ones((1,), device=dev)
+        dist.all_reduce(ones)
+        n_ranks_seen = int(ones.item())
+        assert n_ranks_seen == world, (n_ranks_seen, world)
 
     T, P = (128, 256) if a.workload == 'cfg5' else (32, 49 if a.workload == 'resnet' else 196)
     B = a.batch if a.batch is not None else (1 if a.workload == 'cfg5' else 8)
@@ -134,13 +156,14 @@ def main():
     torch.manual_seed(1)  # reference default seed (configs.py:17): identical initial weights on every rank
     model = build_svanet(args).to(dev).train()
     crit = build_loss(args).to(dev).train()
-    params = [p for p in model.parameters() if p.requires_grad]
-    reducer = parallel.BucketedGradAllReduce(params, skip=parallel.unused_parameters(model))
+    params = [p for p in model.parameters() if p.requires_grad]   # the optimizer's list, reference order (train.py:72)
+    # gradient buckets in the order backward produces them (heads, layers 5..0, query embedding + input projections last)
+    reducer = parallel.BucketedGradAllReduce(parallel.arrival_order(model), skip=parallel.unused_parameters(model), ordered=True)
     use_graph = world == 1 and a.graph and not a.no_graph
     if use_graph:  # (the captured step keeps torch's capturable optimizer: its step counter lives on the device)
         opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, fused=True, capturable=True)  # train.py:98-99
     else:  # the same update as one streaming kernel per gradient bucket (svol_amd.parallel.FlatAdamW)
-        opt = parallel.FlatAdamW(reducer, lr=1e-4, weight_decay=1e-4)
+        opt = parallel.FlatAdamW(reducer, lr=1e-4, weight_decay=1e-4, params=params)
     # weak scaling: every rank gets its own B videos (different seeds = a properly sharded global batch)
     inp = {k: v.to(dev) for k, v in syn.synth_inputs(args, B, T, P, seed=1 + rank).items()}
     tg = syn.synth_targets(B, T, seed=1 + rank)
@@ -285,6 +308,7 @@ def main():
                                        '; ViT-B/16 extractor (random init, frozen) on all %d frames + %d sketches inside the step' % (B * T, B)
                                        if a.workload == 'cfg4' else ('; frozen ResNet-34 (frames, 7x7 tokens) + ResNet-18 (sketch) extractors inside the step' if a.workload == 'resnet' else '')),
                        'global_batch': B * world, 'parallelism': f'dp{world}'},
+            'n_ranks_seen': n_ranks_seen, 'dist_backend': backend if world > 1 else None,
             'final_loss': final_loss,
             'launch_mode': 'hipGraph replay (whole step captured)' if use_graph else 'eager',
         }

@@ -11,13 +11,15 @@ batch / matched pairs, i.e. mean-of-means — SURVEY.md §8e), parameters that r
 MI355X-first differences:
 * gradients live in a few large flat fp32 buckets (``param.grad`` is a VIEW into its bucket), so a
   bucket is reduced in place with no gather/scatter copies;
-* buckets are filled in reverse parameter order (= backward order: heads and the last layer first) and
-  each bucket's all-reduce is issued on a side stream the moment its last gradient has been accumulated,
-  so the exchange of layer k overlaps the backward kernels of layers < k;
+* buckets are filled in the order backward PRODUCES gradients (``arrival_order``: box / class heads, then
+  the transformer layers last to first, then the query embedding and the input projections, whose
+  gradients only exist at the very end of backward) and each bucket's all-reduce is issued on a side
+  stream the moment its last gradient has been accumulated, so the exchange of layer k overlaps the
+  backward kernels of layers < k and only the last, small bucket is exposed;
 * xGMI is point-to-point (7 links x ~153 GB/s per GPU): the 74.4 MiB fp32 gradient of the benchmark
   head is cut into ~16 MiB buckets — large enough that each ring step is bandwidth- not latency-bound
-  (per-link ring time ~ 2*(7/8)*16 MiB / 153 GB/s ~ 0.19 ms), small enough that the last bucket (the
-  input projections, ready only at the very end of backward) exposes little un-overlapped time.
+  (per-link ring time ~ 2*(7/8)*16 MiB / 153 GB/s ~ 0.19 ms), small enough that the last bucket exposes
+  little un-overlapped time.
 """
 from __future__ import annotations
 
@@ -26,10 +28,34 @@ from typing import Iterable, List, Optional
 import torch
 import torch.distributed as dist
 
+_LATE = ('query_embed', 'input_', 'backbone', 'pos_embed', 'position_embedding')   # first used in forward = last in backward
+_EARLY = ('bbox_embed', 'class_embed')                                            # the heads: last in forward
+
+
+def arrival_order(model: torch.nn.Module) -> List[torch.nn.Parameter]:
+    """The trainable parameters of ``model`` in the order backward is expected to produce their gradients:
+    reverse registration order (layers L-1 .. 0, inside a layer the last sub-block first), except that the heads
+    (registered before the transformer in SVANet, svanet.py:42-44, but applied last) come first and what the forward
+    touches first although it is registered last (input projections svanet.py:49-60, query embedding, backbones) comes
+    last.  A wrong guess costs overlap, never correctness."""
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+
+    def rank(name):
+        if any(t in name for t in _EARLY):
+            return 0
+        if any(t in name for t in _LATE):
+            return 2
+        return 1
+    idx = sorted(range(len(named)), key=lambda i: (rank(named[i][0]), -i))
+    return [named[i][1] for i in idx]
+
 
 class BucketedGradAllReduce:
+    """``params`` is taken in the order given — pass ``arrival_order(model)`` (a plain ``model.parameters()`` list is
+    re-ordered by ``reversed`` as a fallback guess when ``ordered=False``)."""
+
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 16 << 20,
-                 skip: Optional[Iterable[torch.nn.Parameter]] = None, process_group=None):
+                 skip: Optional[Iterable[torch.nn.Parameter]] = None, process_group=None, ordered: bool = False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         skip_ids = {id(p) for p in (skip or [])}
@@ -38,8 +64,7 @@ class BucketedGradAllReduce:
             raise ValueError('no parameters to reduce')
         self.device = plist[0].device
         self.on_gpu = self.device.type == 'cuda'
-        # reverse order ~ the order in which backward produces gradients
-        order = list(reversed(plist))
+        order = plist if ordered else list(reversed(plist))
         self.buckets: List[dict] = []
         cur, cur_bytes = [], 0
         for p in order:
@@ -53,7 +78,11 @@ class BucketedGradAllReduce:
             self._make_bucket(cur)
         self._handles = []
         self._hooks = []
+        self.fire_order: List[int] = []   # diagnostics: bucket index of every hook of the current step, in firing order
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        # the stream the caller computes on (the video half of the model, the criterion, the optimizer); re-read
+        # at every zero_grad() on the caller's thread — hooks run on the autograd thread under the NODE's stream
+        self.main_stream = torch.cuda.current_stream(self.device) if self.on_gpu else None
         from .ops import GradSink
         for bi, b in enumerate(self.buckets):
             for p in b['params']:
@@ -78,20 +107,35 @@ class BucketedGradAllReduce:
     def _make_hook(self, bi):
         def hook(_p):
             b = self.buckets[bi]
+            self.fire_order.append(bi)
             b['pending'] -= 1
             if b['pending'] == 0:
                 self._launch(b)
         return hook
 
+    def _producer_streams(self):
+        """every stream a gradient of a bucket can have been written on: the caller's compute stream (video half,
+        heads, input projections), the model's side stream (query half: gradient-sink kernels and AccumulateGrad nodes
+        created under ``torch.cuda.stream(side)``), and the stream of the node whose hook is running."""
+        from .modeling import cross_modal_transformer as cmt
+        ss = [self.main_stream, torch.cuda.current_stream(self.device)] + list(cmt.side_streams(self.device))
+        out = []
+        for s in ss:
+            if s is not None and all(s != t for t in out):
+                out.append(s)
+        return out
+
     def _launch(self, b):
         if self.world == 1:
             return
         if self.on_gpu:
-            # the bucket's gradients were produced on the current (compute) stream — or, for the parameters of the
-            # query half, by gradient-sink kernels on the model's side stream (cross_modal_transformer.py)
-            from .modeling import cross_modal_transformer as cmt
-            self.comm_stream.wait_stream(torch.cuda.current_stream())
-            for s in cmt.side_streams(self.device):
+            # The hook runs on the autograd thread under the stream guard of the LAST-arriving parameter's node.  That
+            # can be the side stream (query half), which runs far ahead of the main stream: waiting only on it would
+            # start the all-reduce before the main stream has written the video-half gradients of the same bucket.
+            # By the time the last hook of a bucket fires every producing kernel of the bucket has been ENQUEUED on
+            # its stream (autograd issues nodes in order on the host), so waiting on all producer streams here is
+            # sufficient.
+            for s in self._producer_streams():
                 self.comm_stream.wait_stream(s)
             with torch.cuda.stream(self.comm_stream):
                 h = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -101,6 +145,9 @@ class BucketedGradAllReduce:
 
     def zero_grad(self):
         """Zero the flat buckets (replaces optimizer.zero_grad(); keeps the grad views alive)."""
+        if self.on_gpu:
+            self.main_stream = torch.cuda.current_stream(self.device)
+        self.fire_order = []
         for b in self.buckets:
             b['flat'].zero_()
             b['pending'] = b['n']
@@ -133,6 +180,15 @@ class BucketedGradAllReduce:
                 b['flat'].mul_(inv)
         self._handles.clear()
 
+    def bucket_fire_spans(self):
+        """diagnostics after a backward: per bucket (first, last) position of its hooks in the step's firing order —
+        with a good ``arrival_order`` the spans do not interleave and bucket k completes before bucket k+1 starts."""
+        spans = {}
+        for pos, bi in enumerate(self.fire_order):
+            lo, _ = spans.get(bi, (pos, pos))
+            spans[bi] = (lo, pos)
+        return [spans.get(bi) for bi in range(len(self.buckets))]
+
     def remove(self):
         for h in self._hooks:
             h.remove()
@@ -143,51 +199,138 @@ class BucketedGradAllReduce:
                     del p._svol_sink
 
 
-class FlatAdamW:
+class FlatAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW (decoupled weight decay, amsgrad off; the reference's optimizer, train.py:98-99) over the reducer's
     flat buckets: the parameters of a bucket are re-homed into ONE flat fp32 buffer (``param.data`` becomes a view, like
     ``param.grad`` already is), the moments are flat too, and a step is one streaming kernel per bucket (``svol_adamw_flat``:
     28 bytes per parameter) instead of torch's multi-tensor launches over ~150 separate tensors (0.44 ms -> 0.15 ms at the
     benchmark size).  Parameters the reducer skips (they never receive a gradient) are not touched, as in torch.
 
-    ``lr`` may be changed between steps (``opt.lr = ...``: what torch's StepLR does to ``param_groups``)."""
+    It IS a ``torch.optim.Optimizer``: one ``param_groups`` entry whose ``lr`` / ``betas`` / ``eps`` / ``weight_decay`` the step
+    reads (so ``StepLR`` / ``MultiStepLR`` of the reference loop, train.py:127-130, wrap it), and ``state_dict()`` /
+    ``load_state_dict()`` speak torch AdamW's schema — ``{'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups':
+    [...]}`` with ``i`` indexing ``params`` — so a checkpoint written by the reference (train.py:267-284) resumes here and vice
+    versa.  ``params``: the optimizer's parameter list in the REFERENCE's order (train.py:72: every trainable parameter in
+    ``named_parameters()`` order, including the ones that never get a gradient and therefore have no state entry); defaults
+    to the reducer's own parameters in bucket order."""
 
-    def __init__(self, reducer: 'BucketedGradAllReduce', lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, reducer: 'BucketedGradAllReduce', lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                 params: Optional[Iterable[torch.nn.Parameter]] = None):
+        owned = [p for b in reducer.buckets for p in b['params']]
+        plist = list(params) if params is not None else owned
+        known = {id(p) for p in plist}
+        missing = [p for p in owned if id(p) not in known]
+        if missing:
+            raise ValueError(f'{len(missing)} parameter(s) of the gradient buckets are not in `params`')
+        defaults = dict(lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps),
+                        weight_decay=float(weight_decay), amsgrad=False, maximize=False, foreach=None, capturable=False,
+                        differentiable=False, fused=None)
+        super().__init__(plist, defaults)
         self.reducer = reducer
-        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
         self.t = 0
-        self.state = []
-        for b in reducer.buckets:
+        self.flat = []      # per bucket: flat parameters / first / second moments
+        self._slot = {}     # id(param) -> (bucket index, offset, numel)
+        for bi, b in enumerate(reducer.buckets):
             flat_g = b['flat']
             flat_p = torch.zeros_like(flat_g)
             for p, off in zip(b['params'], b['offsets']):
                 n = p.numel()
                 flat_p[off:off + n].copy_(p.data.reshape(-1))
                 p.data = flat_p[off:off + n].view_as(p)  # same layout as the gradient views of the bucket
-            self.state.append({'p': flat_p, 'm': torch.zeros_like(flat_p), 'v': torch.zeros_like(flat_p)})
+                self._slot[id(p)] = (bi, off, n)
+            self.flat.append({'p': flat_p, 'm': torch.zeros_like(flat_p), 'v': torch.zeros_like(flat_p)})
+
+    # the hyper-parameters live in param_groups[0] (what torch's schedulers edit); attribute access kept for callers
+    lr = property(lambda self: self.param_groups[0]['lr'], lambda self, v: self.param_groups[0].__setitem__('lr', float(v)))
+    betas = property(lambda self: self.param_groups[0]['betas'])
+    eps = property(lambda self: self.param_groups[0]['eps'])
+    weight_decay = property(lambda self: self.param_groups[0]['weight_decay'])
 
     @torch.no_grad()
-    def step(self):
+    def step(self, closure=None):
         from . import _lib
         from .ops import _ptr, _stream
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
         self.t += 1
-        for b, st in zip(self.reducer.buckets, self.state):
-            rc = _lib.lib().svol_adamw_flat(_ptr(st['p']), _ptr(b['flat']), _ptr(st['m']), _ptr(st['v']), st['p'].numel(), self.lr,
-                                            self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t, 1.0, _stream())
+        for b, st in zip(self.reducer.buckets, self.flat):
+            rc = _lib.lib().svol_adamw_flat(_ptr(st['p']), _ptr(b['flat']), _ptr(st['m']), _ptr(st['v']), st['p'].numel(),
+                                            float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
+                                            float(g['weight_decay']), self.t, 1.0, _stream())
             _lib.check(rc, 'svol_adamw_flat')
+        return loss
 
     def zero_grad(self, set_to_none=False):
         self.reducer.zero_grad()
 
+    def _views(self, p):
+        bi, off, n = self._slot[id(p)]
+        st = self.flat[bi]
+        return st['m'][off:off + n].view_as(p), st['v'][off:off + n].view_as(p)
+
     def state_dict(self):
-        return {'t': self.t, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': self.weight_decay,
-                'm': [st['m'].clone() for st in self.state], 'v': [st['v'].clone() for st in self.state]}
+        """torch.optim.AdamW's schema.  A parameter has a state entry iff it has a slot in a gradient bucket and at least
+        one step was taken (torch creates the entry at the first step of a parameter that has a gradient)."""
+        plist = self.param_groups[0]['params']
+        state = {}
+        if self.t > 0:
+            for i, p in enumerate(plist):
+                if id(p) in self._slot:
+                    m, v = self._views(p)
+                    state[i] = {'step': torch.tensor(float(self.t)), 'exp_avg': m.clone(), 'exp_avg_sq': v.clone()}
+        group = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
+        group['params'] = list(range(len(plist)))
+        return {'state': state, 'param_groups': [group]}
 
     def load_state_dict(self, sd):
-        self.t, self.lr = int(sd['t']), float(sd['lr'])
-        for st, m, v in zip(self.state, sd['m'], sd['v']):
-            st['m'].copy_(m)
-            st['v'].copy_(v)
+        if 't' in sd and 'm' in sd:   # round-1 files of this build: flat moments per bucket, layout-dependent
+            if len(sd['m']) != len(self.flat) or any(a.numel() != st['m'].numel() for a, st in zip(sd['m'], self.flat)):
+                raise ValueError('flat optimizer state does not match this bucket layout')
+            self.t, self.lr = int(sd['t']), float(sd['lr'])
+            for st, m, v in zip(self.flat, sd['m'], sd['v']):
+                st['m'].copy_(m)
+                st['v'].copy_(v)
+            return
+        groups = sd['param_groups']
+        plist = self.param_groups[0]['params']
+        ids = [i for g in groups for i in g['params']]
+        if len(ids) != len(plist):
+            raise ValueError(f'loaded state dict holds {len(ids)} parameters, the optimizer {len(plist)}')
+        g0 = groups[0]
+        for g in groups[1:]:
+            if any(g.get(k) != g0.get(k) for k in ('lr', 'betas', 'eps', 'weight_decay')):
+                raise ValueError('FlatAdamW keeps one parameter group: the loaded groups differ in their hyper-parameters')
+        if g0.get('amsgrad') or g0.get('maximize'):
+            raise ValueError('amsgrad / maximize are not supported')
+        steps = set()
+        todo = []
+        for pos, i in enumerate(ids):
+            ent = sd['state'].get(i)
+            p = plist[pos]
+            if ent is None:
+                continue
+            if id(p) not in self._slot:
+                raise ValueError(f'parameter {pos} has optimizer state but no gradient bucket here')
+            if ent['exp_avg'].numel() != p.numel() or ent['exp_avg_sq'].numel() != p.numel():
+                raise ValueError(f'parameter {pos}: state of {ent["exp_avg"].numel()} elements for {p.numel()} weights')
+            steps.add(int(float(ent['step'])))
+            todo.append((p, ent))
+        if len(steps) > 1:
+            raise ValueError(f'per-parameter step counts differ ({sorted(steps)}); FlatAdamW keeps one')
+        for st in self.flat:
+            st['m'].zero_()
+            st['v'].zero_()
+        for p, ent in todo:
+            m, v = self._views(p)
+            m.copy_(ent['exp_avg'].reshape(p.shape))
+            v.copy_(ent['exp_avg_sq'].reshape(p.shape))
+        self.t = steps.pop() if steps else 0
+        grp = self.param_groups[0]
+        for k in ('lr', 'eps', 'weight_decay', 'initial_lr'):
+            if k in g0:
+                grp[k] = float(g0[k])
+        if 'betas' in g0:
+            grp['betas'] = (float(g0['betas'][0]), float(g0['betas'][1]))
 
 
 def unused_parameters(model: torch.nn.Module):

@@ -12,11 +12,24 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def test_two_ranks_on_one_gpu():
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize('case', ['small', 'full'])
+def test_two_ranks_on_one_gpu(case):
+    """small: fp32 toy model, 64 KiB buckets.  full: the benchmark's model (L = 6272, 6 layers, bf16, 16 MiB buckets, B = 1 per
+    rank) — the GPU lags the host and a bucket boundary falls inside a query half (the all-reduce launched from a
+    side-stream hook must also wait for the main stream)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', SVOL_DP_CASE=case)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29531', os.path.join(HERE, 'dp_gpu_worker.py')]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+           '--master-port', str(_free_port()), os.path.join(HERE, 'dp_gpu_worker.py')]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert p.stdout.count('reducer == mean of per-rank gradients') == 2, p.stdout[-2000:]
 
@@ -49,3 +62,109 @@ def test_flat_adamw_matches_torch_adamw():
     for i, (a, b) in enumerate(zip(pa, pb)):
         assert float((a.detach() - b.detach()).abs().max()) <= 2e-6 * max(1.0, float(b.detach().abs().max())), i
     assert torch.equal(pa[2].detach(), pb[2].detach())
+
+
+@pytest.mark.gpu
+def test_flat_adamw_checkpoints_interoperate_with_torch_adamw():
+    """FlatAdamW speaks torch.optim.AdamW's state-dict schema.  torch AdamW, 2 steps -> state_dict ->
+    FlatAdamW.load_state_dict -> 2 more steps on both == same weights; and back: FlatAdamW.state_dict() resumes a fresh
+    torch AdamW.  The parameter list is in the reference's order (every trainable parameter, train.py:72), one of them never
+    gets a gradient (no state entry), and a StepLR drives both."""
+    import torch
+    from svol_amd import parallel
+    torch.manual_seed(1)
+    shapes = [(64, 33), (33,), (7,), (128, 128), (5, 3, 2), (1,)]
+    dead = 2
+    mk = lambda src: [torch.nn.Parameter(p.detach().clone()) for p in src]
+    p0 = [torch.nn.Parameter(torch.randn(s, device='cuda')) for s in shapes]
+    kw = dict(lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05)
+
+    def grads(step):
+        g = torch.Generator(device='cuda').manual_seed(100 + step)
+        return [torch.randn(s, device='cuda', generator=g) * (1.0 + step) for s in shapes]
+
+    def torch_steps(params, opt, sched, steps):
+        for st in steps:
+            opt.zero_grad()
+            for i, (p, g) in enumerate(zip(params, grads(st))):
+                if i != dead:
+                    p.grad = g.clone()
+            opt.step()
+            sched.step()
+
+    def flat_steps(params, red, opt, sched, steps):
+        for st in steps:
+            opt.zero_grad()
+            for i, (p, g) in enumerate(zip(params, grads(st))):
+                if i != dead:
+                    p.grad.copy_(g)
+            opt.step()
+            sched.step()
+
+    # reference run: torch AdamW for 4 steps
+    pr = mk(p0)
+    o_r = torch.optim.AdamW(pr, **kw)
+    s_r = torch.optim.lr_scheduler.StepLR(o_r, step_size=3, gamma=0.5)
+    torch_steps(pr, o_r, s_r, range(4))
+
+    # torch (2 steps) -> FlatAdamW (2 steps)
+    pa = mk(p0)
+    o_a = torch.optim.AdamW(pa, **kw)
+    s_a = torch.optim.lr_scheduler.StepLR(o_a, step_size=3, gamma=0.5)
+    torch_steps(pa, o_a, s_a, range(2))
+    sd_opt, sd_sched = o_a.state_dict(), s_a.state_dict()
+    assert dead not in sd_opt['state'] and len(sd_opt['state']) == len(shapes) - 1
+    pb = mk(pa)
+    red = parallel.BucketedGradAllReduce(pb, bucket_bytes=40000, skip=[pb[dead]])
+    o_b = parallel.FlatAdamW(red, params=pb, lr=1.0, betas=(0.5, 0.5), eps=1.0, weight_decay=0.0)  # all overwritten by the load
+    s_b = torch.optim.lr_scheduler.StepLR(o_b, step_size=3, gamma=0.5)
+    o_b.load_state_dict(sd_opt)
+    s_b.load_state_dict(sd_sched)
+    assert o_b.t == 2 and o_b.betas == (0.9, 0.99) and o_b.weight_decay == 0.05
+    flat_steps(pb, red, o_b, s_b, range(2, 4))
+    for i, (a, b) in enumerate(zip(pb, pr)):
+        assert float((a.detach() - b.detach()).abs().max()) <= 2e-6 * max(1.0, float(b.detach().abs().max())), i
+    assert abs(o_b.lr - o_r.param_groups[0]['lr']) < 1e-12 and o_b.lr == 1.5e-3   # StepLR halved it after step 3
+
+    # FlatAdamW state -> fresh torch AdamW, one more step on both
+    sd_b = o_b.state_dict()
+    assert sorted(sd_b['state']) == [i for i in range(len(shapes)) if i != dead]
+    assert sd_b['param_groups'][0]['params'] == list(range(len(shapes)))
+    pc = mk(pb)
+    o_c = torch.optim.AdamW(pc, **kw)
+    o_c.load_state_dict(sd_b)
+    s_c = torch.optim.lr_scheduler.StepLR(o_c, step_size=3, gamma=0.5)
+    s_c.load_state_dict(s_b.state_dict())
+    torch_steps(pc, o_c, s_c, [4])
+    torch_steps(pr, o_r, s_r, [4])
+    for i, (a, b) in enumerate(zip(pc, pr)):
+        assert float((a.detach() - b.detach()).abs().max()) <= 4e-6 * max(1.0, float(b.detach().abs().max())), i
+
+    # a state dict that does not fit is refused, not silently mis-aligned
+    bad = o_a.state_dict()
+    bad['state'][0]['exp_avg'] = bad['state'][0]['exp_avg'][:10]
+    with pytest.raises(ValueError):
+        o_b.load_state_dict(bad)
+
+
+@pytest.mark.gpu
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts the ranks itself before
+    touching the GPU, rank 0 prints the one JSON line with the rank count the communicator really had, a failing child makes
+    the parent fail.  gloo lets both ranks share the test box's single card (RCCL wants one GPU per rank)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0', SVOL_DIST_BACKEND='gloo')
+    root = os.path.dirname(HERE)
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l_ for l_ in p.stdout.splitlines() if l_.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['n_ranks_seen'] == 2 and res['config']['global_batch'] == 16
+    assert res['value'] > 0 and res['scaling'] == 'weak' and res['dist_backend'] == 'gloo'
+    # a failing child (a batch size no rank can build) must fail the parent too
+    q = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--batch', '-1'], env=env,
+                       capture_output=True, text=True, timeout=300, cwd=root)
+    assert q.returncode != 0

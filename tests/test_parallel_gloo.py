@@ -113,3 +113,82 @@ def test_single_process_reducer_is_identity():
             assert float(grads_red[k].abs().max()) == 0.0  # never touched: stays at the zeroed bucket value
         else:
             torch.testing.assert_close(grads_red[k], g, rtol=1e-6, atol=1e-8)
+
+
+def test_arrival_order_puts_heads_first_and_input_projections_last():
+    """buckets must follow the order in which backward produces gradients, or the first (largest) bucket's
+    all-reduce only starts after backward has finished."""
+    from svol_amd.modeling.svanet import build_svanet
+    args = syn.head_args(hidden_dim=32, nheads=4, num_layers=3, num_queries=8, num_frames=4, input_vid_dim=32, input_skch_dim=32)
+    model = build_svanet(args)
+    names = {id(p): n for n, p in model.named_parameters()}
+    order = [names[id(p)] for p in parallel.arrival_order(model)]
+    assert sorted(order) == sorted(n for n, p in model.named_parameters() if p.requires_grad)
+    k_heads = max(i for i, n in enumerate(order) if 'bbox_embed' in n or 'class_embed' in n)
+    k_first_layer = min(i for i, n in enumerate(order) if 'transformer.layers.' in n)
+    k_last_layer = max(i for i, n in enumerate(order) if 'transformer.layers.' in n)
+    k_late = min(i for i, n in enumerate(order) if 'query_embed' in n or 'input_' in n)
+    assert k_heads < k_first_layer and k_last_layer < k_late
+    layer_of = [int(n.split('transformer.layers.')[1].split('.')[0]) for n in order if 'transformer.layers.' in n]
+    assert layer_of == sorted(layer_of, reverse=True)            # last layer first
+    l2 = [n for n in order if 'transformer.layers.2.' in n]
+    assert 'norm6' in l2[0] and 'sketch_video_cross_attn' in l2[-1]  # inside a layer: last sub-block first
+    # the reducer keeps that order when told so
+    red = parallel.BucketedGradAllReduce(parallel.arrival_order(model), bucket_bytes=16 << 10,
+                                         skip=parallel.unused_parameters(model), ordered=True)
+    flat_names = [names[id(p)] for b in red.buckets for p in b['params']]
+    assert flat_names == [n for n in order if 'class_head' not in n and 'sketch_video_cross_attn.out_proj' not in n]
+    red.remove()
+
+
+def test_flat_adamw_speaks_the_torch_adamw_schema_on_load_and_save():
+    """CPU half of the optimizer-checkpoint interop (the update kernel itself is GPU-only: tests/test_gpu_parallel.py)."""
+    torch.manual_seed(0)
+    shapes = [(6, 5), (5,), (3,), (4, 4)]
+    dead = 2
+    pt = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    opt = torch.optim.AdamW(pt, lr=2e-3, betas=(0.8, 0.95), eps=1e-7, weight_decay=0.03)
+    for step in range(3):
+        opt.zero_grad()
+        for i, p in enumerate(pt):
+            if i != dead:
+                p.grad = torch.randn(p.shape)
+        opt.step()
+    sd = opt.state_dict()
+    pf = [torch.nn.Parameter(p.detach().clone()) for p in pt]
+    red = parallel.BucketedGradAllReduce(pf, bucket_bytes=64, skip=[pf[dead]])
+    assert len(red.buckets) > 1
+    fo = parallel.FlatAdamW(red, params=pf, lr=1.0)
+    assert isinstance(fo, torch.optim.Optimizer) and fo.state_dict()['state'] == {}
+    for a, b in zip(pf, pt):                       # re-homed into the flat buffers, values unchanged
+        assert torch.equal(a.detach(), b.detach())
+    fo.load_state_dict(sd)
+    assert fo.t == 3 and fo.lr == 2e-3 and fo.betas == (0.8, 0.95) and fo.eps == 1e-7 and fo.weight_decay == 0.03
+    out = fo.state_dict()
+    assert sorted(out['state']) == sorted(sd['state']) == [0, 1, 3]
+    for i in out['state']:
+        assert float(out['state'][i]['step']) == float(sd['state'][i]['step']) == 3.0
+        assert torch.equal(out['state'][i]['exp_avg'], sd['state'][i]['exp_avg'])
+        assert torch.equal(out['state'][i]['exp_avg_sq'], sd['state'][i]['exp_avg_sq'])
+        assert out['state'][i]['exp_avg'].shape == pt[i].shape
+    assert out['param_groups'][0]['params'] == [0, 1, 2, 3]
+    fresh = torch.optim.AdamW([torch.nn.Parameter(p.detach().clone()) for p in pt], lr=1.0)
+    fresh.load_state_dict(out)                     # torch accepts what FlatAdamW writes
+    assert fresh.param_groups[0]['lr'] == 2e-3 and fresh.param_groups[0]['betas'] == (0.8, 0.95)
+    # torch's schedulers wrap it and drive the learning rate the step kernel reads
+    sched = torch.optim.lr_scheduler.StepLR(fo, step_size=1, gamma=0.1)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')            # "lr_scheduler.step() before optimizer.step()"
+        sched.step()
+    assert abs(fo.lr - 2e-4) < 1e-12
+    # a mismatching file is refused
+    bad = opt.state_dict()
+    bad['param_groups'][0]['params'] = [0, 1, 2]
+    with pytest.raises(ValueError):
+        fo.load_state_dict(bad)
+    bad = opt.state_dict()
+    bad['state'][3]['exp_avg_sq'] = torch.zeros(3)
+    with pytest.raises(ValueError):
+        fo.load_state_dict(bad)
+    red.remove()
