@@ -45,6 +45,13 @@ class MLP(nn.Module):
 
 
 OVERLAP_QUERY_STREAM = os.environ.get('SVOL_NO_STREAM_OVERLAP') is None
+# bf16 mode: the N object queries (a few hundred rows: < 1 % of the step's FLOPs) run their projections, MLP2, query
+# self-attention, residuals and norms in exact fp32 GEMMs; only the K / V projections of the L video tokens and the
+# query -> video attention core stay on the bf16 MFMA path (ops.AttnLNFn "mixed").  The final logits / boxes are linear
+# heads of the query stream, so its bf16 operand roundings were the larger half of the output error: measured on the
+# reference goldens 1.0e-2 -> ~5e-3 max |logit error| (profiles/round2_bf16_output_error.md).  SVOL_QUERY_BF16=1 restores
+# the all-bf16 query stream (A/B).
+QUERY_FP32 = os.environ.get('SVOL_QUERY_BF16') is None
 _SIDE = {}
 
 
@@ -175,7 +182,7 @@ class CrossModalTransformer(nn.Module):
         src_skch32 [B,d] fp32, kbias [B,L] fp32 additive key mask, vid_pos [B,L,d] compute dtype,
         query_embed [N,d] fp32 parameter.  Returns hs [num_layers,B,N,d] fp32."""
         B = src_vid32.shape[0]
-        dt = vid_pos.dtype
+        dt = torch.float32 if QUERY_FP32 else vid_pos.dtype   # element type of the QUERY stream's GEMM operands
         qpos = ops.cast_ag(query_embed, dt)
         N, d = qpos.shape
         out = (torch.zeros((B, N, d), dtype=torch.float32, device=vid_pos.device),  # reference :56

@@ -666,31 +666,44 @@ class AttnLNFn(torch.autograd.Function):
         dt = xq.dtype
         Lk = Lq if self_attn else xv.shape[1]
         dh = d // H
-        Wc, WcT = weights.get(W_in, dt)
+        # MIXED cross-attention (the bf16 model's query -> video attention): the few object queries travel in fp32
+        # (xq / xq_pos fp32: q-projection, out-projection, residual and norm in exact fp32 GEMMs — a few hundred rows),
+        # the L video tokens in bf16 (K / V projections and the attention core on the MFMA bf16 path).  q and O cross
+        # the boundary through one rounding each.
+        mixed = (not self_attn) and dt == torch.float32 and xv.dtype == torch.bfloat16
+        dkv = xv.dtype if mixed else dt
+        Wc, WcT = weights.get(W_in, dkv)
         Woc, WoT = weights.get(W_o, dt)
         # bf16: the projection GEMM emits q already multiplied by d_h^-1/2 * log2(e) (rounded once, in the fp32
         # epilogue), which lets the attention kernels exponentiate raw MFMA results
-        premul = (LOG2E / math.sqrt(dh)) if dt == torch.bfloat16 else 0.0
+        premul = (LOG2E / math.sqrt(dh)) if dkv == torch.bfloat16 else 0.0
         qscale = _qscale(d, premul, xq.device) if premul else None
         a_qp = xq_pos.reshape(B * Lq, d)
         a_q = xq.reshape(B * Lq, d)
         a_kp = a_qp if self_attn else xk_pos.reshape(B * Lk, d)
         a_v = a_q if self_attn else xv.reshape(B * Lk, d)
+        Wq32T = None
         if self_attn:
             qkv = torch.empty((B * Lq, 3 * d), dtype=dt, device=xq.device)
             gemm_nt(a_qp, Wc[:2 * d], b_in[:2 * d], out=qkv[:, :2 * d], colscale=qscale)
             gemm_nt(a_q, Wc[2 * d:], b_in[2 * d:], out=qkv[:, 2 * d:])
             q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         else:
-            q = gemm_nt(a_qp, Wc[:d], b_in[:d], colscale=qscale[:d] if qscale is not None else None)
-            kv = torch.empty((B * Lk, 2 * d), dtype=dt, device=xq.device)
+            if mixed:
+                W32, W32T = weights.get(W_in, torch.float32)
+                Wq32T = W32T[:, :d]
+                q = cast(gemm_nt(a_qp, W32[:d], b_in[:d], colscale=qscale[:d]), dkv)
+            else:
+                q = gemm_nt(a_qp, Wc[:d], b_in[:d], colscale=qscale[:d] if qscale is not None else None)
+            kv = torch.empty((B * Lk, 2 * d), dtype=dkv, device=xq.device)
             gemm_nt(a_kp, Wc[d:2 * d], b_in[d:2 * d], out=kv[:, :d])
             gemm_nt(a_v, Wc[2 * d:], b_in[2 * d:], out=kv[:, d:])
             k, v = kv[:, :d], kv[:, d:]
         o, lse2 = attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias, premul)
         att = attn_weights_mean(q, k, lse2, B, H, Lq, Lk, dh, kbias, premul) if need_weights else None
-        s32 = gemm_nt(o, Woc, b_o, residual=xq32.reshape(B * Lq, d), out_f32=True)
+        s32 = gemm_nt(cast(o, dt) if mixed else o, Woc, b_o, residual=xq32.reshape(B * Lq, d), out_f32=True)
         ctx.WcT, ctx.WoT, ctx.dims, ctx.self_attn, ctx.premul = WcT, WoT, (B, H, Lq, Lk, dh, d), self_attn, premul
+        ctx.mixed, ctx.Wq32T = mixed, Wq32T
         ctx.pos_shape = pos_out.shape if pos_out is not None else None
         ctx.has_ln = gamma is not None
         nig = ctx.needs_input_grad
@@ -741,8 +754,11 @@ class AttnLNFn(torch.autograd.Function):
             gbuf = torch.zeros((3 * d * d + 3 * d + d * d,), dtype=torch.float32, device=g.device)  # one memset
             dW_in, db_in = gbuf[:3 * d * d].view(3 * d, d), gbuf[3 * d * d:3 * d * d + 3 * d]
             dWo = gbuf[3 * d * d + 3 * d:].view(d, d)
-        gemm_tn(g, o, out=dWo)
+        mixed = ctx.mixed
+        gemm_tn(g, cast(o, dt) if mixed else o, out=dWo)
         do = gemm_nt(g, WoT)
+        if mixed:
+            do = cast(do, o.dtype)
         shq = (B, Lq, d)
         if ctx.self_attn:
             dqkv = torch.empty((B * Lq, 3 * d), dtype=dt, device=g.device)
@@ -756,14 +772,16 @@ class AttnLNFn(torch.autograd.Function):
                 dW_in = db_in = dWo = dbo = dg = dbt = None
             return (ds32.view(shq), dxq.view(shq), dxq_pos.view(shq), None, None, dW_in, db_in, dWo, dbo, dg, dbt,
                     dpos, None, None, None, None)
-        dq = torch.empty((B * Lq, d), dtype=dt, device=g.device)
-        dkv = torch.empty((B * Lk, 2 * d), dtype=dt, device=g.device)
+        dq = torch.empty((B * Lq, d), dtype=q.dtype, device=g.device)
+        dkv = torch.empty((B * Lk, 2 * d), dtype=k.dtype, device=g.device)
         dk, dv = dkv[:, :d], dkv[:, d:]
         attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias, ctx.premul)
+        if mixed:
+            dq = cast(dq, dt)
         gemm_tn(dq, a_qp, out=dW_in[:d], colsum=db_in[:d])
         gemm_tn(dk, a_kp, out=dW_in[d:2 * d], colsum=db_in[d:2 * d])
         gemm_tn(dv, a_v, out=dW_in[2 * d:], colsum=db_in[2 * d:])
-        dxq_pos = gemm_nt(dq, WcT[:, :d])
+        dxq_pos = gemm_nt(dq, ctx.Wq32T if mixed else WcT[:, :d])
         dxk_pos = gemm_nt(dk, WcT[:, d:2 * d])
         dxv = gemm_nt(dv, WcT[:, 2 * d:])
         shk = (B, Lk, d)

@@ -138,9 +138,9 @@ def synth_state_dict(args, seed: int = 1) -> "OrderedDict[str, torch.Tensor]":
     return sd
 
 
-def synth_inputs(args, B: int, T: int, P: int, seed: int = 1, pad_frames: int = 0):
+def synth_inputs(args, B: int, T: int, P: int, seed: int = 1, pad_frames: int = 0, pad_all: bool = False):
     """Head-boundary inputs. ``pad_frames``: number of trailing frames marked
-    padding (mask 0) in every odd batch element (exercises key_padding_mask)."""
+    padding (mask 0) in every odd batch element — in EVERY element with ``pad_all`` — (exercises key_padding_mask)."""
     r = _rs('inputs', seed)
     L = T * P
     src_video = r.standard_normal((B, L, args.input_vid_dim)).astype(np.float32)
@@ -148,7 +148,7 @@ def synth_inputs(args, B: int, T: int, P: int, seed: int = 1, pad_frames: int = 
     vmask = np.ones((B, L), np.float32)
     if pad_frames:
         for b in range(B):
-            if b % 2 == 1:
+            if b % 2 == 1 or pad_all:
                 vmask[b, (T - pad_frames) * P:] = 0.0
     smask = np.ones((B, 1), np.float32)
     return dict(src_sketch=torch.from_numpy(src_sketch),

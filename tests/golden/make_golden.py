@@ -48,7 +48,7 @@ FULL_GRAD_MAX = 4096
 SAMPLE = 256
 
 HEAD_CASES = {
-    # name: (args overrides, B, T, P, pad_frames)
+    # name: (args overrides, B, T, P, pad_frames[, pad_all])
     'tiny_video': (dict(hidden_dim=32, nheads=4, num_layers=2, num_queries=8, num_queries_per_frame=2,
                         num_frames=4, input_vid_dim=32, input_skch_dim=32, matcher='video_matcher'), 2, 4, 6, 1),
     'tiny_frame': (dict(hidden_dim=32, nheads=4, num_layers=2, num_queries=8, num_queries_per_frame=2,
@@ -61,6 +61,13 @@ HEAD_CASES = {
                        num_frames=8, input_vid_dim=64, input_skch_dim=48, matcher='video_matcher'), 2, 8, 16, 2),
     'mid32_video': (dict(hidden_dim=256, nheads=8, num_layers=2, num_queries=100, num_queries_per_frame=10,
                          num_frames=8, input_vid_dim=64, input_skch_dim=64, matcher='video_matcher'), 2, 8, 24, 2),
+    # BASELINE configs[1] at full depth / width / sequence length, one video (the reference materialises 1.26 GB of attention
+    # weights per layer for it: ~15 GB resident, a minute on 8 cores): value-level parity at the shapes the bench launches
+    'cfg2_b1_video': (dict(hidden_dim=256, nheads=8, num_layers=6, num_queries=100, num_queries_per_frame=10,
+                           num_frames=32, matcher='video_matcher'), 1, 32, 196, 0),
+    # the same with the last 8 of the 32 frames padded: 4704 valid keys = 36.75 key tiles, the key-padding mask at L = 6272
+    'cfg2_b1_video_pad': (dict(hidden_dim=256, nheads=8, num_layers=6, num_queries=100, num_queries_per_frame=10,
+                               num_frames=32, matcher='video_matcher'), 1, 32, 196, 8, True),
 }
 
 CRIT_CASES = {
@@ -101,7 +108,7 @@ def grad_record(out, key, g):
         out[f'gsample/{key}'] = flat[::step][:SAMPLE].astype(np.float32)
 
 
-def run_head_case(name, over, B, T, P, pad):
+def run_head_case(name, over, B, T, P, pad, pad_all=False):
     args = syn.head_args(**over)
     torch.manual_seed(1)
     model = build_svanet(args)
@@ -115,7 +122,7 @@ def run_head_case(name, over, B, T, P, pad):
     criterion = build_loss(args)
     criterion.eval()
 
-    inp = syn.synth_inputs(args, B, T, P, seed=1, pad_frames=pad)
+    inp = syn.synth_inputs(args, B, T, P, seed=1, pad_frames=pad, pad_all=pad_all)
     targets = syn.synth_targets(B, T, seed=1)
     outputs = model(inp['src_sketch'], inp['src_sketch_mask'], inp['src_video'], inp['src_video_mask'])
     loss_dict = criterion(outputs, targets)
@@ -124,7 +131,7 @@ def run_head_case(name, over, B, T, P, pad):
     total.backward()
 
     rec = {}
-    rec['meta'] = np.asarray(json.dumps(dict(args=vars(args), B=B, T=T, P=P, pad_frames=pad,
+    rec['meta'] = np.asarray(json.dumps(dict(args=vars(args), B=B, T=T, P=P, pad_frames=pad, pad_all=pad_all,
                                              torch=torch.__version__)))
     rec['keys'] = np.asarray('\n'.join(ref_keys))
     rec['pred_logits'] = outputs['pred_logits'].detach().numpy()
@@ -240,12 +247,15 @@ def run_posenc():
 
 
 if __name__ == '__main__':
-    torch.set_num_threads(4)
+    torch.set_num_threads(int(os.environ.get('SVOL_GOLDEN_THREADS', '4')))
     torch.use_deterministic_algorithms(False)
+    only = sys.argv[1:]   # optional: names of head cases to (re)generate; default = everything
     for n, c in HEAD_CASES.items():
-        run_head_case(n, *c)
-    for n, c in CRIT_CASES.items():
-        run_crit_case(n, *c)
-    run_lsap()
-    run_posenc()
-    run_configs()
+        if not only or n in only:
+            run_head_case(n, *c)
+    if not only:
+        for n, c in CRIT_CASES.items():
+            run_crit_case(n, *c)
+        run_lsap()
+        run_posenc()
+        run_configs()

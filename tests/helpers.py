@@ -21,7 +21,8 @@ def head_case(name, dtype=torch.float32):
     z, meta = load_golden('head_' + name)
     args = syn.head_args(**meta['args'])
     sd = syn.synth_state_dict(args, seed=1)
-    inp = syn.synth_inputs(args, meta['B'], meta['T'], meta['P'], seed=1, pad_frames=meta['pad_frames'])
+    inp = syn.synth_inputs(args, meta['B'], meta['T'], meta['P'], seed=1, pad_frames=meta['pad_frames'],
+                           pad_all=meta.get('pad_all', False))
     tg = syn.synth_targets(meta['B'], meta['T'], seed=1)
     if dtype != torch.float32:
         sd = {k: v.to(dtype) for k, v in sd.items()}
