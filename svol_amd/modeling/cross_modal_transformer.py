@@ -59,6 +59,13 @@ def _side_stream(dev):
     s = _SIDE.get(dev)
     if s is None:
         s = _SIDE[dev] = torch.cuda.Stream(device=dev)
+        # parameters of the query half get their gradients from side-stream nodes by design; a caller that still holds
+        # last step's outputs keeps that step's AccumulateGrad nodes (and their streams) alive, which is harmless here
+        # (BucketedGradAllReduce / the next forward join the streams) but makes torch warn on every backward
+        try:
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        except AttributeError:  # pragma: no cover  (older torch)
+            pass
     return s
 
 

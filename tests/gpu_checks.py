@@ -540,12 +540,14 @@ def run_head_case(name, dtype, sinks=False):
 def check_head_case(name, dtype, sinks=False):
     """Whole hot path through the product modules vs the reference's golden vectors.
 
-    * final-layer outputs (pred_logits / pred_boxes — the outputs north_star names): |diff| <= 1e-3 fp32 /
-      1e-2 bf16, for the logits relative to the largest reference logit when that exceeds 1 (measured bf16: 1.04e-2
-      absolute on logits up to 1.34 in the worst case, i.e. 0.8 %).  Auxiliary (intermediate-layer) outputs: 1e-3 fp32 / 1.5e-2 bf16 — bf16 rounding noise on
-      the logits is 5e-3..1e-2 by itself at these widths (measured, and reproduced by a CPU emulation of the
-      rounding sites: GEMM/attention operands in bf16, everything else fp32), so 1e-2 is a coin flip on the
-      max over thousands of logits; the d=32 toy cases get 1.5e-2 throughout for the same reason.
+    * outputs (pred_logits / pred_boxes, final and auxiliary layers — the outputs north_star names): ABSOLUTE
+      |diff| <= 1e-3 fp32 / 1e-2 bf16, every case up to mid32 (measured bf16 worst case 6.6e-3, profiles/round2_bf16_output_error.md;
+      the object-query stream runs in fp32 in bf16 mode, which halved the round-1 errors).  ONE relaxed case, justified in
+      DESIGN.md §3: the full-depth cfg2 goldens (6 layers, L = 6272) in bf16 — boxes still 1e-2 (measured 1.1e-3), logits
+      2e-2 absolute and 1e-2 rms (measured 1.27e-2 max, 6.7e-3 rms on logits of magnitude <= 1.0).  A CPU emulation of
+      the rounding sites attributes 6.8e-3 of that 7.1e-3 rms to the bf16 rounding of the WEIGHTS alone (a coherent
+      perturbation of every token, which attention and LayerNorm do not average out; operand rounding of the activations
+      contributes 6e-5): it is the price of bf16 weights at this depth, not a kernel error — fp32 is 1e-6 on the same case.
     * Hungarian assignment: BIT-EXACT against the CPU oracle matcher (scipy restatement) run on the very
       outputs the product produced, every layer; and equal to the golden assignment whenever the outputs
       are close enough not to flip a near-tie (always in fp32).
@@ -559,24 +561,24 @@ def check_head_case(name, dtype, sinks=False):
     from types import SimpleNamespace
     from tests.helpers import unpack_indices
     fp32 = dtype == torch.float32
-    tol = 1e-3 if fp32 else (1.5e-2 if name.startswith('tiny') else 1e-2)
+    tol = 1e-3 if fp32 else 1e-2
+    deep = name.startswith('cfg2_b1') and not fp32      # the one relaxed case (docstring)
+    ltol = 2e-2 if deep else tol
     res = {}
     z, meta, args, out, ld, tot, model, crit = run_head_case(name, dtype, sinks)
     tag = f'head/{name}/{"fp32" if fp32 else "bf16"}' + ('/sinks' if sinks else '')
     if sinks:  # every bucket saw all of its parameters complete exactly once
         res[tag + '/buckets_incomplete'] = (float(sum(b['pending'] != 0 for b in model._test_reducer.buckets)), 0.0)
-    # logits are unbounded (largest reference logit 1.25 - 3.7 in these cases): the bar scales with it once it exceeds 1, i.e. it is
-    # relative to the output's own scale; box coordinates live in [0,1] and are compared absolutely
-    lscale = max(1.0, float(np.abs(z['pred_logits']).max()))
-    res[tag + '/pred_logits'] = (float((out['pred_logits'].cpu() - torch.from_numpy(z['pred_logits'])).abs().max()), tol * lscale)
+    dl = out['pred_logits'].cpu() - torch.from_numpy(z['pred_logits'])
+    res[tag + '/pred_logits_abs'] = (float(dl.abs().max()), ltol)
+    if deep:
+        res[tag + '/pred_logits_rms'] = (float(dl.pow(2).mean().sqrt()), 1e-2)
     res[tag + '/pred_boxes_abs'] = (float((out['pred_boxes'].cpu() - torch.from_numpy(z['pred_boxes'])).abs().max()), tol)
     if 'aux_logits' in z.files:
         al = torch.stack([a['pred_logits'] for a in out['aux_outputs']]).cpu()
         ab = torch.stack([a['pred_boxes'] for a in out['aux_outputs']]).cpu()
-        atol = tol if fp32 else 1.5e-2
-        res[tag + '/aux_logits'] = (float((al - torch.from_numpy(z['aux_logits'])).abs().max()),
-                                    atol * max(1.0, float(np.abs(z['aux_logits']).max())))
-        res[tag + '/aux_boxes_abs'] = (float((ab - torch.from_numpy(z['aux_boxes'])).abs().max()), atol)
+        res[tag + '/aux_logits_abs'] = (float((al - torch.from_numpy(z['aux_logits'])).abs().max()), ltol)
+        res[tag + '/aux_boxes_abs'] = (float((ab - torch.from_numpy(z['aux_boxes'])).abs().max()), tol)
     # --- matcher + criterion against the oracle ON THE SAME OUTPUTS (bit-exact assignment)
     tg = syn.synth_targets(meta['B'], meta['T'], seed=1)
     cpu_out = {'pred_logits': out['pred_logits'].detach().cpu(), 'pred_boxes': out['pred_boxes'].detach().cpu()}

@@ -23,7 +23,7 @@ def _free_port():
 
 @pytest.mark.parametrize('case', ['small', 'full'])
 def test_two_ranks_on_one_gpu(case):
-    """small: fp32 toy model, 64 KiB buckets.  full: the benchmark's model (L = 6272, 6 layers, bf16, 16 MiB buckets, B = 1 per
+    """small: fp32 toy model, 64 KiB buckets.  full: the benchmark's model (L = 6272, 6 layers, bf16, 16 MiB buckets, B = 8 per
     rank) — the GPU lags the host and a bucket boundary falls inside a query half (the all-reduce launched from a
     side-stream hook must also wait for the main stream)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', SVOL_DP_CASE=case)
