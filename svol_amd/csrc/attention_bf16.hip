@@ -43,6 +43,7 @@ struct Args {
     const int* tile_flags;        // [B][ceil(Lk/KT)] key-tile classes of the masked fast kernels (attn_tile_flags_bf16)
     int head_xcd, nxt;            // != 0: 1-D grid of B*H*nxt workgroups with the heads dealt to the 8 XCDs (block_coords)
     int tail_last;                // != 0 (with head_xcd): every head's LAST x tile is dispatched after all the others
+    int* redo;                    // [grid] written by attn_fwd_bf16_fast (1 = a row sum overflowed), read by the safe kernel behind it
 };
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
@@ -67,6 +68,25 @@ __device__ __forceinline__ void store_lds(char* img, const Stage& s, int tid) {
         *reinterpret_cast<uint4*>(img + img_off(row, ch)) = s.v[i];
     }
 }
+
+// LDS-DMA staging (global_load_lds_dwordx4: no VGPR round trip, no ds_write): one 1-KiB piece = 16 rows x 64 B of a
+// [128][32] bf16 tile straight into the XOR-swizzled image.  The LDS side of the instruction is linear (wave base + lane * 16),
+// so the swizzle sits on the per-lane SOURCE address: lane i lands in (row 16*piece + i/4, slot i%4), which must hold chunk
+// slot ^ ((row >> 2) & 3) = (i & 3) ^ ((i >> 4) & 3) of that row (img_off).  Rows must exist (callers: full tiles only).
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* gbl_vptr;
+__device__ __forceinline__ void dma_piece(char* img, const bf16_t* g, int64_t ld, int row0, int piece, int lane) {
+    const int row = 16 * piece + (lane >> 2);
+    const int ch = (lane & 3) ^ ((lane >> 4) & 3);
+    const bf16_t* src = g + (int64_t)(row0 + row) * ld + ch * 8;
+    __builtin_amdgcn_global_load_lds((gbl_vptr)src, (lds_vptr)(img + piece * 1024), 16, 0, 0);
+}
+// a whole 128-row tile by the four waves of a workgroup (two pieces each); `wave` must be wave-uniform (readfirstlane)
+__device__ __forceinline__ void dma_tile(char* img, const bf16_t* g, int64_t ld, int row0, int wave, int lane) {
+    dma_piece(img, g, ld, row0, 2 * wave, lane);
+    dma_piece(img, g, ld, row0, 2 * wave + 1, lane);
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ void load_lane_block(uint4 (&out)[2], const bf16_t* g, int64_t ld, int row, bool valid, int dh,
                                                 int h) {
@@ -808,6 +828,8 @@ __device__ __forceinline__ void attn_fwd_pre_body(const Args p) {
 // VGPRs (2 waves per SIMD) instead of this body's 163 (3 waves), 4 % slower.
 __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_pre(Args p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * IMG];
+    // behind attn_fwd_bf16_fast: only the workgroups whose rows overflowed there run (normally none)
+    if (p.redo && !p.redo[blockIdx.x]) return;
     char* sK = smem;
     char* sV = smem + 2 * IMG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -906,6 +928,96 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_pre(Args p) {
     if (qvalid && h == 0) p.lse2[((int64_t)b * p.H + hh) * p.Lq + qrow] = m + __builtin_amdgcn_logf(lt);
 }
 __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_pre_masked(Args p) { attn_fwd_pre_body<true>(p); }
+
+// The fast forward (round 2).  In-kernel ablations of attn_fwd_bf16_pre at the benchmark shape (tools/micro/attn_lab.hip,
+// profiles/round2_attention_lab.md) showed a kernel bound by instruction ISSUE, every class of instruction costing its own
+// time (v_exp ~6, any other VALU ~3, an MFMA ~17, a global load ~75 cycles of SIMD time): the per-tile running maximum (33
+// v_max3 + the exchange + a 20-cycle hazard fence per 128-key tile) and the register staging (4 ds_write_b128 + 16 VGPRs)
+// are pure overhead.  Here the softmax reference is anchored ONCE, at the row maximum of key tile 0, and every tile is
+// exponentiated against it: P = 2^(s - m0) is exact in floating point whatever m0 is (bf16 P keeps its relative precision
+// at any magnitude, l and O accumulate in fp32), as long as nothing overflows — a later score more than ~2^100 above the
+// anchor.  That cannot be ruled out, so it is DETECTED: an inf / NaN row sum flags the workgroup in `redo`, and
+// attn_fwd_bf16_pre, launched right behind this kernel, recomputes exactly the flagged workgroups with per-tile maxima
+// (it exits at once everywhere else).  K / V tiles are staged by LDS-DMA.  0.507 -> 0.447 ms at B 8, H 8, L 6272.
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_fast(Args p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * IMG];
+    char* sK = smem;
+    char* sV = smem + 2 * IMG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int xt, hh, b;
+    block_coords(p, xt, hh, b);
+    const int qrow = xt * 128 + wave * 32 + r;
+    const bool qvalid = qrow < p.Lq;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
+    uint4 qb[2];
+    load_lane_block(qb, Q, p.ldq, qrow, qvalid, p.dh, h);
+    const int nt = p.Lk / KT;     // launcher guarantees Lk % KT == 0 and dh == 32
+    dma_tile(sK, K, p.ldk, 0, wave, lane);
+    dma_tile(sV, V, p.ldv, 0, wave, lane);
+    dma_wait_all();
+    __syncthreads();
+    float m;                      // the anchor: this query's largest score in key tile 0 (log2 domain)
+    {
+        float mm = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            uint4 ka[2];
+            read_rows(ka, sK, sub * 32 + r, h);
+            const f32x16 S = mma_first(ka, qb);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mm = fmaxf(mm, S[i]);
+        }
+        const HalfPair sw = swap_halves(__builtin_bit_cast(unsigned, mm));
+        m = fmaxf(__builtin_bit_cast(float, sw.lo), __builtin_bit_cast(float, sw.hi));
+    }
+    const f32x16 Cm = splat16(-m);
+    f32x16 O = zero16();
+    float l = 0.f;
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {         // the other buffer was last read in tile t-1, behind that tile's barrier
+            dma_tile(sK + (cur ^ 1) * IMG, K, p.ldk, (t + 1) * KT, wave, lane);
+            dma_tile(sV + (cur ^ 1) * IMG, V, p.ldv, (t + 1) * KT, wave, lane);
+        }
+        const char* kimg = sK + cur * IMG;
+        const char* vimg = sV + cur * IMG;
+        f32x16 S[4];
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            uint4 ka[2];
+            read_rows(ka, kimg, sub * 32 + r, h);
+            S[sub] = mma_first_c(ka, qb, Cm);  // = score - anchor
+        }
+        float ls[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                S[sub][i] = __builtin_amdgcn_exp2f(S[sub][i]);
+                ls[sub] += S[sub][i];
+            }
+        l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            uint4 va[2];
+            read_tr(va, vimg, sub, lane);
+            mma_second(O, va, S[sub]);
+        }
+        dma_wait_all();           // this wave's pieces of tile t+1 have landed; the barrier publishes everyone's
+        __syncthreads();
+    }
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const int bad = __syncthreads_or(qvalid && !(lt < 1.0e30f));   // inf / NaN: some score left the anchor's range
+    if (tid == 0) p.redo[blockIdx.x] = bad ? 1 : 0;
+    if (bad) return;              // attn_fwd_bf16_pre (next launch on the stream) recomputes this workgroup
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    bf16_t* Oo = reinterpret_cast<bf16_t*>(p.out_o) + (int64_t)b * p.Lq * p.ldo + hh * p.dh;
+    store_acc(O, Oo, p.ldo, qrow, qvalid, p.dh, h, inv);
+    if (qvalid && h == 0) p.lse2[((int64_t)b * p.H + hh) * p.Lq + qrow] = m + __builtin_amdgcn_logf(lt);
+}
 
 // Two 32-query blocks per wave (256 queries per workgroup): every K / V fragment read from LDS feeds two MFMAs, and
 // a wave always has a second, independent MFMA -> exp -> MFMA chain to issue from while the first one waits.
@@ -1163,7 +1275,12 @@ static int plan_ksplit(int B, int H, int Lq, int Lk, int dh, int64_t ws_floats, 
 int64_t svol_attn_ws_floats_bf16(int B, int H, int Lq, int Lk, int dh) {
     int tps;
     const int ks = plan_ksplit(B, H, Lq, Lk, dh, INT64_MAX, &tps);
-    if (ks < 2) return (int64_t)B * ((Lk + KT - 1) / KT);  // key-tile classes of the masked fast kernels (one int each)
+    if (ks < 2) {
+        // key-tile classes of the masked fast kernels (one int per (batch, key tile)), or the redo flags of the unmasked fast
+        // forward (one int per workgroup: (batch, head, 128-query tile)) — whichever is larger
+        const int64_t cls = (int64_t)B * ((Lk + KT - 1) / KT), redo = (int64_t)B * H * ((Lq + 127) / 128);
+        return cls > redo ? cls : redo;
+    }
     return (int64_t)ks * B * Lq * H * dh + (int64_t)ks * B * H * Lq * 2 + (int64_t)B * Lq * H * dh;
 }
 // masked / ragged launches take the fast kernels when the key-split would not have been chosen anyway (enough query tiles to
@@ -1205,8 +1322,15 @@ int svol_attn_fwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
         p.tile_flags = reinterpret_cast<const int*>(ws);
         hipLaunchKernelGGL(attn_tile_flags_bf16, dim3((unsigned)ntk, (unsigned)B), dim3(64), 0, s, kbias, Lk, ntk, reinterpret_cast<int*>(ws));
         hipLaunchKernelGGL(attn_fwd_bf16_pre_masked, grid, dim3(256), 0, s, p);
-    } else if (pre) hipLaunchKernelGGL(attn_fwd_bf16_pre, grid, dim3(256), 0, s, p);
-    else if (masked) hipLaunchKernelGGL(attn_fwd_bf16<true>, grid, dim3(256), 0, s, p);
+    } else if (pre) {
+        static const bool no_fast = getenv("SVOL_ATTN_NO_FAST_FWD") != nullptr;
+        const int64_t nwg = (int64_t)grid.x * grid.y * grid.z;
+        if (!no_fast && p.head_xcd && dh == 32 && ws && ws_bytes >= nwg * 4) {
+            p.redo = reinterpret_cast<int*>(ws);
+            hipLaunchKernelGGL(attn_fwd_bf16_fast, grid, dim3(256), 0, s, p);
+        }
+        hipLaunchKernelGGL(attn_fwd_bf16_pre, grid, dim3(256), 0, s, p);  // all workgroups, or (p.redo) only the flagged ones
+    } else if (masked) hipLaunchKernelGGL(attn_fwd_bf16<true>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(attn_fwd_bf16<false>, grid, dim3(256), 0, s, p);
     if (p.ksplit > 1) {
         const int64_t total = (int64_t)B * Lq * H;

@@ -240,10 +240,10 @@ def posenc_sine(mask_f32: torch.Tensor, D: int, dtype: torch.dtype) -> torch.Ten
 
 
 def _attn_ws(q, B, H, Lq, Lk, dh, masked):
-    """scratch of the attention launches: partial results of the key-split (few queries, many keys) or the key-tile classes of
-    the masked fast kernels; None when the library needs none."""
+    """scratch of the attention launches: partial results of the key-split (few queries, many keys), the key-tile classes of
+    the masked fast kernels, or the per-workgroup redo flags of the fast unmasked forward; None when the library needs none."""
     n = _lib.lib().svol_attn_ws_bytes(B, H, Lq, Lk, dh) if q.dtype == torch.bfloat16 else 0
-    if n <= 0 or (not masked and n == B * ((Lk + 127) // 128) * 4):
+    if n <= 0:
         return None
     return torch.empty((n // 4,), dtype=torch.float32, device=q.device)
 

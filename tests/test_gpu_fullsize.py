@@ -219,3 +219,47 @@ def test_attention_values_at_the_benchmark_launch_shape(B, H, L):
             assert e <= 1.2e-2, (b, h, e)
     assert errs['o'] <= 1.2e-2 and errs['lse2'] <= 3e-3, errs
     assert errs['dq'] <= 2.4e-2 and errs['dk'] <= 2.4e-2 and errs['dv'] <= 2.4e-2, errs
+
+
+def test_fast_forward_flags_overflow_and_the_safe_kernel_repairs_it():
+    """The unmasked forward anchors the softmax reference once, at key tile 0, and exponentiates every later tile against it
+    (csrc/attention_bf16.hip: attn_fwd_bf16_fast).  A later score far above the anchor overflows 2^(s - m0): the workgroup
+    must flag itself and the safe kernel behind it (per-tile maxima) must recompute it.  Forced here (guide rule 26: a rare
+    data-dependent branch needs an input that takes it): one key in the SECOND tile scores 2^500 above everything in the
+    first for 5 queries of one head.  Checked against fp64 on the whole tensor, and the flags are read back."""
+    import math
+    from svol_amd import _lib
+    B, H, L, dh = 1, 8, 384, 32
+    d = H * dh
+    pm = 1.4426950408889634 / math.sqrt(dh)
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn((B * L, d), generator=g)
+    k = torch.randn((B * L, d), generator=g)
+    v = torch.randn((B * L, d), generator=g)
+    hot_q, hot_k, hd = [3, 40, 129, 200, 383], 300, 5          # queries (tiles 0..2), key in tile 2, head 5
+    q[hot_q, hd * dh:(hd + 1) * dh] = 16.0                     # (pre-scale applies below: 16 * 0.255 = 4.08 per dim)
+    k[hot_k, hd * dh:(hd + 1) * dh] = 4.0                      # score = 32 * 4.08 * 4 = 522 in the log2 domain
+    qkv = torch.cat([(q.double() * pm).float(), k, v], 1).to(torch.bfloat16)
+    dev = qkv.cuda()
+    o = torch.empty((B * L, d), dtype=torch.bfloat16, device='cuda')
+    lse2 = torch.empty((B, H, L), dtype=torch.float32, device='cuda')
+    n = _lib.lib().svol_attn_ws_bytes(B, H, L, L, dh)
+    assert n >= B * H * 3 * 4
+    ws = torch.full((n // 4,), -1, dtype=torch.int32, device='cuda')
+    rc = _lib.lib().svol_attn_fwd(dev[:, :d].data_ptr(), 3 * d, dev[:, d:2 * d].data_ptr(), 3 * d, dev[:, 2 * d:].data_ptr(), 3 * d,
+                                  o.data_ptr(), d, lse2.data_ptr(), None, B, H, L, L, dh, 1.0 / math.sqrt(dh), pm, ws.data_ptr(), n, 1,
+                                  torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    flags = ws[:B * H * 3].cpu().tolist()
+    assert sorted(set(flags)) == [0, 1], flags                # some workgroups flagged, most not
+    assert sum(flags) == 3, flags                             # exactly head 5's three query tiles (every tile holds a hot query)
+    dummy = torch.zeros((B * L, d), dtype=torch.bfloat16)
+    o_r, lse_r, _, _, _ = _attn_heads_fp64(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], dummy, B, H, L, L, dh, pm)
+    assert bool(torch.isfinite(o).all()) and bool(torch.isfinite(lse2).all())
+    e_o = float((o.double().cpu() - o_r).abs().max() / o_r.abs().max())
+    e_l = float((lse2.double().cpu() - lse_r).abs().max() / lse_r.abs().max())
+    assert e_o <= 1.2e-2 and e_l <= 1e-5, (e_o, e_l)
+    # the hot queries attend to the hot key only
+    for qi in hot_q:
+        assert float((o[qi, hd * dh:(hd + 1) * dh].float().cpu() - qkv[hot_k, 2 * d + hd * dh:2 * d + (hd + 1) * dh].float()).abs().max()) < 1e-2
