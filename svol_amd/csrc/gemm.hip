@@ -411,6 +411,128 @@ __global__ void act_bwd_kernel(const T* dy, const T* aux, T* dpre, int act, int6
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Skinny-M fp32 NT GEMM (the object-query stream of the bf16 model runs in exact fp32: M = B * num_queries = 800 rows).
+// The generic 64x64 kernel gives such launches 52 workgroups that each walk the K loop alone behind a barrier pair per
+// 32-deep step (30 us for 800 x 256 x 256).  Same idea as gemm_nt_bf16_skinny (gemm_bf16.hip): one workgroup owns a
+// 32 x 32 output tile, its four waves split K between them and stream their K/4 slices of A and W straight from global
+// memory (L2-resident at these sizes) into v_mfma_f32_32x32x2_f32 operands — 16 bytes per lane and row, no LDS staging,
+// the next 32-deep batch in flight under the current one — and the four partial tiles meet in LDS for the epilogue.
+// The contraction index is permuted (lane half h of chunk c, element e <-> k = 8c + 4h + e) identically for both operands.
+struct SkArgs {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* colscale; float* pre; const float* res; const float* aux; float* colsum;
+    int64_t lda, ldb, ldc, ldp, ldr, ldaux;
+    int M, N, K, act, epi;
+};
+constexpr int SKF_T = 32, SKF_LD = SKF_T + 4;
+
+__global__ __launch_bounds__(256) void gemm_nt_f32_skinny(SkArgs p) {
+    __shared__ __attribute__((aligned(16))) float red[4][SKF_T][SKF_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int bm = blockIdx.y * SKF_T, bn = blockIdx.x * SKF_T;
+    const int kslice = p.K >> 2;
+    const int nb = kslice >> 5;  // batches of 32
+    const bool va = bm + r < p.M, vb = bn + r < p.N;
+    const float* pa = p.A + (int64_t)(bm + r) * p.lda + wave * kslice + h * 4;
+    const float* pb = p.B + (int64_t)(bn + r) * p.ldb + wave * kslice + h * 4;
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 a[4], b[4], na[4], nb_[4];
+    auto load = [&](f32x4 (&xa)[4], f32x4 (&xb)[4], int bt) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            xa[c] = va ? *reinterpret_cast<const f32x4*>(pa + bt * 32 + c * 8) : z4;
+            xb[c] = vb ? *reinterpret_cast<const f32x4*>(pb + bt * 32 + c * 8) : z4;
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    load(a, b, 0);
+    for (int bt = 0; bt < nb; ++bt) {
+        if (bt + 1 < nb) load(na, nb_, bt + 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][e], b[c][e], acc, 0, 0, 0);
+        if (bt + 1 < nb) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { a[c] = na[c]; b[c] = nb_[c]; }
+        }
+    }
+    // D[m][n]: register 4g+e of lane (n = r, h) is row m = 8g + 4h + e
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave][8 * g + 4 * h + e][r] = acc[4 * g + e];
+    __syncthreads();
+    const int row = tid >> 3, c0 = (tid & 7) * 4;
+    const int m = bm + row, n0 = bn + c0;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][row][c0]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(&red[w][row][c0]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += u[e];
+    }
+    const bool mv = m < p.M;  // N % 32 == 0 (launcher): every column of the tile exists
+    if (p.epi == 0) {
+        if (mv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (p.bias) v[e] += p.bias[n0 + e];
+                if (p.colscale) v[e] *= p.colscale[n0 + e];
+            }
+            if (p.pre) *reinterpret_cast<f32x4*>(p.pre + (int64_t)m * p.ldp + n0) = v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (p.act == SVOL_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                else if (p.act == SVOL_ACT_GELU) v[e] = gelu_f(v[e]);
+                else if (p.act == SVOL_ACT_SIGMOID) v[e] = 1.f / (1.f + __expf(-v[e]));
+            }
+            if (p.res) {
+                const f32x4 rr = *reinterpret_cast<const f32x4*>(p.res + (int64_t)m * p.ldr + n0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += rr[e];
+            }
+            if (p.act == SVOL_ACT_RELU_RES) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+        }
+    } else {  // epi 1: v = acc * act'(aux), column sums of v (fused MLP backward step)
+        if (mv) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(p.aux + (int64_t)m * p.ldaux + n0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= p.act == SVOL_ACT_RELU ? (x[e] > 0.f ? 1.f : 0.f) : dgelu_f(x[e]);
+        } else {
+            v = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (p.colsum) {
+            __syncthreads();  // everyone has read the partial tiles
+            *reinterpret_cast<f32x4*>(&red[0][row][c0]) = v;
+            __syncthreads();
+            if (tid < SKF_T) {
+                float sacc = 0.f;
+#pragma unroll 8
+                for (int i = 0; i < SKF_T; ++i) sacc += red[0][i][tid];
+                atomicAdd(p.colsum + bn + tid, sacc);
+            }
+        }
+    }
+    if (mv) *reinterpret_cast<f32x4*>(p.C + (int64_t)m * p.ldc + n0) = v;
+}
+
+// the shapes the skinny fp32 kernel takes: few rows, K a multiple of 128 (four waves x 32-deep batches), N a multiple of 32,
+// 16-byte aligned rows everywhere
+inline bool skinny_f32_ok(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, const void* A, const void* B,
+                          const void* C) {
+    static const bool off = getenv("SVOL_GEMM_NO_F32_SKINNY") != nullptr;
+    return !off && M <= 2048 && K % 128 == 0 && N % 32 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && aligned16(A) &&
+           aligned16(B) && aligned16(C) && (M + 31) / 32 <= 65535;
+}
+
 inline int grid_1d(int64_t n, int block) {
     int64_t g = (n + block - 1) / block;
     return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
@@ -460,6 +582,14 @@ int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, co
                                               0, nullptr, 0, colscale, M, N, K, s);
         if (rc != SVOL_E_UNSUPPORTED) return rc;
     }
+    if (dtype == SVOL_F32 && !A2 && skinny_f32_ok(M, N, K, lda, ldb, ldc, A, B, C) && (!residual || (ldr % 4 == 0 && aligned16(residual))) &&
+        (!pre_act_out || (ldp % 4 == 0 && aligned16(pre_act_out)))) {
+        SkArgs q{(const float*)A, (const float*)B, (float*)C, bias, colscale, (float*)pre_act_out, (const float*)residual, nullptr,
+                 nullptr, lda, ldb, ldc, ldp, ldr, 0, (int)M, (int)N, (int)K, act, 0};
+        hipLaunchKernelGGL(gemm_nt_f32_skinny, dim3((unsigned)(N / 32), (unsigned)((M + 31) / 32)), dim3(256), 0, s, q);
+        SVOL_CHECK_LAUNCH();
+        return SVOL_OK;
+    }
     // 64x64 tiles when the 128x128 tiling would leave most of the 256 CUs idle (the fp32 heads: M = 4800, N = 256 -> 76 workgroups)
     const bool small = (int64_t)grid.x * grid.y < 256 && (M + 63) / 64 <= 65535;
     const dim3 g64((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
@@ -485,6 +615,13 @@ int svol_gemm_nt_dact(const void* A, int64_t lda, const void* B, int64_t ldb, vo
         const int rc = svol_gemm_nt_bf16_fast(A, lda, B, ldb, C, ldc, nullptr, act, nullptr, 0, nullptr, 0, 0, aux, ldaux, colsum, 1,
                                               nullptr, M, N, K, s);
         if (rc != SVOL_E_UNSUPPORTED) return rc;
+    }
+    if (dtype == SVOL_F32 && skinny_f32_ok(M, N, K, lda, ldb, ldc, A, B, C) && ldaux % 4 == 0 && aligned16(aux)) {
+        SkArgs q{(const float*)A, (const float*)B, (float*)C, nullptr, nullptr, nullptr, nullptr, (const float*)aux, colsum,
+                 lda, ldb, ldc, 0, 0, ldaux, (int)M, (int)N, (int)K, act, 1};
+        hipLaunchKernelGGL(gemm_nt_f32_skinny, dim3((unsigned)(N / 32), (unsigned)((M + 31) / 32)), dim3(256), 0, s, q);
+        SVOL_CHECK_LAUNCH();
+        return SVOL_OK;
     }
     // generic composition (f32 / odd shapes): GEMM, then dpre = dh * act'(aux) in place, then column sums
     if (ldc != N || ldaux != N) return SVOL_E_UNSUPPORTED;
@@ -526,13 +663,16 @@ int svol_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* 
     int64_t want = (target_wgs + tiles - 1) / tiles;
     int64_t chunk = (Mc + want - 1) / want;
     chunk = ((chunk + ct - 1) / ct) * ct;
-    if (chunk < 4 * ct) chunk = 4 * ct;
+    // (fp32 with few rows — the query stream's weight gradients, Mc = 800: the 4 x CT floor would leave 28 workgroups, each
+    //  walking 128 rows of fp32 MFMAs; one CT-row slab per workgroup gives 100 and the atomic volume stays small)
+    const int64_t floor_rows = (dtype == SVOL_F32 && Mc <= 4096) ? ct : 4 * ct;
+    if (chunk < floor_rows) chunk = floor_rows;
     int64_t splits = (Mc + chunk - 1) / chunk;
     if (splits > 8 && splits % 8) {  // keep the split count a multiple of the 8 XCDs when the rows allow it
         const int64_t s8 = (splits + 7) / 8 * 8;
         int64_t c8 = (Mc + s8 - 1) / s8;
         c8 = ((c8 + ct - 1) / ct) * ct;
-        if (c8 >= 4 * ct && (Mc + c8 - 1) / c8 == s8) { chunk = c8; splits = s8; }
+        if (c8 >= floor_rows && (Mc + c8 - 1) / c8 == s8) { chunk = c8; splits = s8; }
     }
     const int64_t ktiles = (K + 127) / 128;
     if (splits * tiles > (1ll << 30)) return SVOL_E_UNSUPPORTED;

@@ -47,11 +47,12 @@ def _act(x, act):
 def check_gemm_nt():
     res = {}
     shapes = [(300, 200, 96), (128, 128, 64), (50, 2, 32), (1, 256, 512), (257, 130, 8), (640, 2048, 256),
-              (4200, 256, 512), (4100, 256, 2048), (5000, 256, 256), (4500, 512, 256)]  # tall M: N=256 deep-K and K=256 weight-stationary paths
+              (4200, 256, 512), (4100, 256, 2048), (5000, 256, 256), (4500, 512, 256),  # tall M: N=256 deep-K and K=256 weight-stationary paths
+              (800, 256, 256), (800, 256, 2048), (790, 512, 256), (100, 32, 128), (33, 2048, 256)]  # few rows: the skinny kernels (bf16 and fp32: the query stream)
     for dt in DTYPES:
         for (M, N, K) in shapes:
             for act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_GELU, ops.ACT_SIGMOID):
-                if act != ops.ACT_NONE and (M, N, K) != (300, 200, 96):
+                if act != ops.ACT_NONE and (M, N, K) not in ((300, 200, 96), (790, 512, 256)):
                     continue
                 A = _rnd((M, K), dt, 1)
                 Bm = _rnd((N, K), dt, 2, 1.0 / math.sqrt(K))
@@ -115,7 +116,7 @@ def check_gemm_nt():
 def check_gemm_dgelu():
     res = {}
     for dt in DTYPES:
-        for (M, N, K) in [(300, 256, 64), (1000, 2048, 256), (130, 64, 128), (77, 96, 32), (801, 192, 256)]:
+        for (M, N, K) in [(300, 256, 64), (1000, 2048, 256), (130, 64, 128), (77, 96, 32), (801, 192, 256), (800, 2048, 256), (800, 256, 2048)]:
             A, W = _rnd((M, K), dt, 50), _rnd((N, K), dt, 51, 1.0 / math.sqrt(K))
             pre = _rnd((M, N), dt, 52)
             out, cs = ops.gemm_nt_dgelu(A.to(DEV), W.to(DEV), pre.to(DEV))
