@@ -145,6 +145,39 @@ def gemm_tn(A, B, out=None, colsum=None):
     return out
 
 
+# ---- weight gradients off the critical path --------------------------------------------------------------------------------
+# dW = dY^T X is needed by nobody until the optimizer step (or the bucket's all-reduce), while the dX chain behind it IS the
+# critical path of backward.  When the gradient lands in a reducer-owned bucket (a "sink": persistent memory, no autograd
+# consumer), the TN GEMM is issued on a dedicated stream that waits for the producing stream's work so far and is joined by
+# BucketedGradAllReduce (before a bucket's all-reduce and in finish()).  The split-M TN kernels are HBM / atomic bound, the
+# attention-backward kernels they now run beside are instruction-issue bound: the two overlap almost for free.
+WGRAD_ASYNC = os.environ.get('SVOL_NO_WGRAD_STREAM') is None
+_WGRAD = {}
+
+
+def wgrad_streams(dev):
+    """streams weight-gradient GEMMs have been issued on for `dev` (svol_amd.parallel joins them)."""
+    s = _WGRAD.get(torch.device(dev) if not isinstance(dev, torch.device) else dev)
+    return [s] if s is not None else []
+
+
+def gemm_tn_sink(A, B, out, colsum=None):
+    """gemm_tn into a persistent gradient bucket view, off the critical path (see above).  `out` / `colsum` must be sink
+    views: nothing on the current stream may read them before BucketedGradAllReduce.finish()."""
+    if not WGRAD_ASYNC or torch.cuda.is_current_stream_capturing():
+        return gemm_tn(A, B, out=out, colsum=colsum)
+    dev = A.device
+    ws = _WGRAD.get(dev)
+    if ws is None:
+        ws = _WGRAD[dev] = torch.cuda.Stream(device=dev)
+    ws.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(ws):
+        gemm_tn(A, B, out=out, colsum=colsum)
+    A.record_stream(ws)
+    B.record_stream(ws)
+    return out
+
+
 def gemm_nt_dact(A, B, aux, act, want_colsum=True, colsum_out=None):
     """(A @ B^T) * act'(aux), and its column sums (fp32, accumulated into colsum_out when given) — fused MLP
     backward step.  act = ACT_GELU (aux = saved pre-activation) or ACT_RELU (aux = saved post-activation)."""
@@ -540,7 +573,7 @@ class LinearFn(torch.autograd.Function):
         K_ = x2.shape[1]
         sW, sb = ctx.sinks
         if sW is not None and (sb is not None or not ctx.has_b):
-            gemm_tn(d, x2, out=sW.view, colsum=sb.view if sb else None)
+            gemm_tn_sink(d, x2, out=sW.view, colsum=sb.view if sb else None)
             dW = db = None
         else:
             buf = torch.zeros((Np * K_ + Np,), dtype=torch.float32, device=d.device)
@@ -637,10 +670,11 @@ class MLPLNFn(torch.autograd.Function):
         else:
             wbuf = torch.zeros((2 * D * F_,), dtype=torch.float32, device=ds.device)  # one memset for dW1 | dW2
             dW1, dW2 = wbuf[:D * F_].view(F_, D), wbuf[D * F_:].view(D, F_)
-        gemm_tn(ds, hid, out=dW2)
+        tn = gemm_tn_sink if (sW1 is not None and sW2 is not None) else (lambda A_, B_, out: gemm_tn(A_, B_, out=out))
+        tn(ds, hid, out=dW2)
         # (ds W2) * act'(aux) and its column sums, one kernel
         dpre, db1 = gemm_nt_dact(ds, ctx.W2T, aux, ctx.act, colsum_out=vw(sb1))
-        gemm_tn(dpre, x2, out=dW1)
+        tn(dpre, x2, out=dW1)
         dx = gemm_nt(dpre, ctx.W1T)
         if (sW1 is None) != (sW2 is None):  # only one of the two has a sink: add the other by hand
             for s_, g_ in ((sW1, dW1), (sW2, dW2)):
@@ -755,7 +789,8 @@ class AttnLNFn(torch.autograd.Function):
             dW_in, db_in = gbuf[:3 * d * d].view(3 * d, d), gbuf[3 * d * d:3 * d * d + 3 * d]
             dWo = gbuf[3 * d * d + 3 * d:].view(d, d)
         mixed = ctx.mixed
-        gemm_tn(g, cast(o, dt) if mixed else o, out=dWo)
+        tn = gemm_tn_sink if sk is not None else (lambda A_, B_, out, colsum=None: gemm_tn(A_, B_, out=out, colsum=colsum))
+        tn(g, cast(o, dt) if mixed else o, out=dWo)
         do = gemm_nt(g, WoT)
         if mixed:
             do = cast(do, o.dtype)
@@ -764,8 +799,8 @@ class AttnLNFn(torch.autograd.Function):
             dqkv = torch.empty((B * Lq, 3 * d), dtype=dt, device=g.device)
             dq, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
             attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias, ctx.premul)
-            gemm_tn(dqkv[:, :2 * d], a_qp, out=dW_in[:2 * d], colsum=db_in[:2 * d])
-            gemm_tn(dv, a_q, out=dW_in[2 * d:], colsum=db_in[2 * d:])
+            tn(dqkv[:, :2 * d], a_qp, out=dW_in[:2 * d], colsum=db_in[:2 * d])
+            tn(dv, a_q, out=dW_in[2 * d:], colsum=db_in[2 * d:])
             dxq_pos = gemm_nt(dqkv[:, :2 * d], WcT[:, :2 * d])  # d(x + pos) = [dq dk] W_qk
             dxq = gemm_nt(dv, WcT[:, 2 * d:])                    # d(x) through V
             if sk is not None:
@@ -778,9 +813,9 @@ class AttnLNFn(torch.autograd.Function):
         attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias, ctx.premul)
         if mixed:
             dq = cast(dq, dt)
-        gemm_tn(dq, a_qp, out=dW_in[:d], colsum=db_in[:d])
-        gemm_tn(dk, a_kp, out=dW_in[d:2 * d], colsum=db_in[d:2 * d])
-        gemm_tn(dv, a_v, out=dW_in[2 * d:], colsum=db_in[2 * d:])
+        tn(dq, a_qp, out=dW_in[:d], colsum=db_in[:d])
+        tn(dk, a_kp, out=dW_in[d:2 * d], colsum=db_in[d:2 * d])
+        tn(dv, a_v, out=dW_in[2 * d:], colsum=db_in[2 * d:])
         dxq_pos = gemm_nt(dq, ctx.Wq32T if mixed else WcT[:, :d])
         dxk_pos = gemm_nt(dk, WcT[:, d:2 * d])
         dxv = gemm_nt(dv, WcT[:, 2 * d:])

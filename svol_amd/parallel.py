@@ -117,8 +117,10 @@ class BucketedGradAllReduce:
         """every stream a gradient of a bucket can have been written on: the caller's compute stream (video half,
         heads, input projections), the model's side stream (query half: gradient-sink kernels and AccumulateGrad nodes
         created under ``torch.cuda.stream(side)``), and the stream of the node whose hook is running."""
+        from . import ops
         from .modeling import cross_modal_transformer as cmt
-        ss = [self.main_stream, torch.cuda.current_stream(self.device)] + list(cmt.side_streams(self.device))
+        ss = ([self.main_stream, torch.cuda.current_stream(self.device)] + list(cmt.side_streams(self.device)) +
+              list(ops.wgrad_streams(self.device)))   # weight-gradient GEMMs run on a stream of their own (ops.gemm_tn_sink)
         out = []
         for s in ss:
             if s is not None and all(s != t for t in out):
@@ -162,8 +164,9 @@ class BucketedGradAllReduce:
         if self.on_gpu:
             # kernels that accumulate straight into the buckets (gradient sinks) may have run on the model's side
             # stream (query-stream / video-stream overlap): join it before anyone reads the buckets
+            from . import ops
             from .modeling import cross_modal_transformer as cmt
-            for s in cmt.side_streams(self.device):
+            for s in list(cmt.side_streams(self.device)) + list(ops.wgrad_streams(self.device)):
                 torch.cuda.current_stream().wait_stream(s)
         for b in self.buckets:
             if b['pending'] != 0 and self.world > 1:
