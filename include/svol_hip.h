@@ -148,7 +148,8 @@ int64_t svol_attn_ws_bytes(int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t
 int svol_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                   int64_t ldo, float* lse2, const float* kbias, int64_t B, int64_t H, int64_t Lq, int64_t Lk,
                   int64_t dh, float scale, float q_premul, void* ws, int64_t ws_bytes, int dtype, void* stream);
-/* delta[B,H,Lq] = rowsum(dO * O) ; then dq / dk / dv (same layouts as q/k/v). */
+/* delta: fp32 scratch of 3*B*H*Lq elements (rowsum(dO * O), then the row constants of the second pass re-encoded for its
+ * LDS-DMA loads); then dq / dk / dv (same layouts as q/k/v). */
 int svol_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
                   int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta, const float* kbias,
                   void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int64_t B, int64_t H,

@@ -44,6 +44,7 @@ struct Args {
     int head_xcd, nxt;            // != 0: 1-D grid of B*H*nxt workgroups with the heads dealt to the 8 XCDs (block_coords)
     int tail_last;                // != 0 (with head_xcd): every head's LAST x tile is dispatched after all the others
     int* redo;                    // [grid] written by attn_fwd_bf16_fast (1 = a row sum overflowed), read by the safe kernel behind it
+    unsigned *nl2, *nd2;          // [B,H,Lq] -lse2 / -delta as (hi, lo) bf16 pairs: written by the fast dQ kernel, DMA'd by the dK/dV kernel
 };
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
@@ -1067,7 +1068,13 @@ __device__ __forceinline__ void attn_bwd_dq_pre_body(const Args& p) {
             const HalfPair sw = swap_halves(__builtin_bit_cast(unsigned, dl));
             dl = __builtin_bit_cast(float, sw.lo) + __builtin_bit_cast(float, sw.hi);
         }
-        if (qvalid[u] && h == 0) p.delta[sidx] = dl;
+        if (qvalid[u] && h == 0) {
+            p.delta[sidx] = dl;
+            if (p.nl2) {  // the dK/dV pass adds the row constants through the matrix pipe as (hi, lo) bf16 pairs: split them once, here
+                p.nl2[sidx] = split_bf16x2(-p.lse2[sidx]);
+                p.nd2[sidx] = split_bf16x2(-dl);
+            }
+        }
         Cd[u] = splat16(qvalid[u] ? -dl : 0.f);                  // dP - delta
         dQ[u] = zero16();
     }
@@ -1137,14 +1144,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_pre_masked(Args p) { 
 // loop's LDS traffic, and LDS was the busiest unit (rocprofv3 PMC: ~70 % of its bandwidth).  They ride the matrix
 // pipe instead: one more 16-deep MFMA per product contracts [hi, lo, 0...] (per query, one dword from LDS)
 // with [1, 1, 0...] (constant), i.e. adds -lse / -delta to every score of that query in fp32.
-template <bool MASKED>
+// DMA (unmasked, Lq % 128 == 0, pre-split statistics from the dQ kernel): Q / dO tiles and the two statistics vectors go
+// HBM -> LDS by LDS-DMA (no VGPR round trip, no ds_write, no split arithmetic here): 0.785 -> 0.740 ms at the benchmark shape.
+template <bool MASKED, bool DMA = false>
 __device__ __forceinline__ void attn_bwd_dkdv_pre_body(const Args& p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * IMG + 4 * KT * 4];
     char* sQ = smem;
     char* sdO = smem + 2 * IMG;
     unsigned* sL = reinterpret_cast<unsigned*>(smem + 4 * IMG);  // [2][KT] -lse2 as (hi, lo) bf16
     unsigned* sD = sL + 2 * KT;                                  // [2][KT] -delta as (hi, lo) bf16
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = DMA ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     int xt, hh, b;
     block_coords(p, xt, hh, b);
@@ -1184,19 +1193,41 @@ __device__ __forceinline__ void attn_bwd_dkdv_pre_body(const Args& p) {
     const unsigned kb_pair = kbl == -INFINITY ? 0x0000FF80u : split_bf16x2(kbl);  // (-inf, 0): x - hi would be NaN
     const uint4 ones_s = (MASKED && h == 0) ? make_uint4(0x3F803F80u, kb_pair, 0u, 0u) : ones;
     const unsigned q_one = MASKED ? 0x3F803F80u : 0u;
-    load_regs(sq, Q, p.ldq, 0, p.Lq, p.dh, tid);
-    load_regs(sdo, dO, p.lddo, 0, p.Lq, p.dh, tid);
-    load_stats(0);
-    store_lds(sQ, sq, tid);
-    store_lds(sdO, sdo, tid);
-    store_stats(0);
+    const unsigned* nl_h = DMA ? p.nl2 + ((int64_t)b * p.H + hh) * p.Lq : nullptr;
+    const unsigned* nd_h = DMA ? p.nd2 + ((int64_t)b * p.H + hh) * p.Lq : nullptr;
+    auto dma_stats = [&](int buf, int row0) {   // wave 0: -lse pairs, wave 1: -delta pairs; 32 lanes x 16 bytes = 128 queries
+        if (wave < 2 && lane < 32) {
+            const unsigned* src = (wave == 0 ? nl_h : nd_h) + row0 + lane * 4;
+            unsigned* dst = (wave == 0 ? sL : sD) + buf * KT;
+            __builtin_amdgcn_global_load_lds((gbl_vptr)src, (lds_vptr)dst, 16, 0, 0);
+        }
+    };
+    if (DMA) {
+        dma_tile(sQ, Q, p.ldq, 0, wave, lane);
+        dma_tile(sdO, dO, p.lddo, 0, wave, lane);
+        dma_stats(0, 0);
+        dma_wait_all();
+    } else {
+        load_regs(sq, Q, p.ldq, 0, p.Lq, p.dh, tid);
+        load_regs(sdo, dO, p.lddo, 0, p.Lq, p.dh, tid);
+        load_stats(0);
+        store_lds(sQ, sq, tid);
+        store_lds(sdO, sdo, tid);
+        store_stats(0);
+    }
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt) {
-            load_regs(sq, Q, p.ldq, (t + 1) * KT, p.Lq, p.dh, tid);
-            load_regs(sdo, dO, p.lddo, (t + 1) * KT, p.Lq, p.dh, tid);
-            load_stats((t + 1) * KT);
+            if (DMA) {
+                dma_tile(sQ + (cur ^ 1) * IMG, Q, p.ldq, (t + 1) * KT, wave, lane);
+                dma_tile(sdO + (cur ^ 1) * IMG, dO, p.lddo, (t + 1) * KT, wave, lane);
+                dma_stats(cur ^ 1, (t + 1) * KT);
+            } else {
+                load_regs(sq, Q, p.ldq, (t + 1) * KT, p.Lq, p.dh, tid);
+                load_regs(sdo, dO, p.lddo, (t + 1) * KT, p.Lq, p.dh, tid);
+                load_stats((t + 1) * KT);
+            }
         }
         const char* qimg = sQ + cur * IMG;
         const char* doimg = sdO + cur * IMG;
@@ -1237,11 +1268,12 @@ __device__ __forceinline__ void attn_bwd_dkdv_pre_body(const Args& p) {
             mma_second(dK, a, S);
             if (sub + 1 < 4) { S = Sn; dP = dPn; }
         }
-        if (t + 1 < nt) {
+        if (t + 1 < nt && !DMA) {
             store_lds(sQ + (cur ^ 1) * IMG, sq, tid);
             store_lds(sdO + (cur ^ 1) * IMG, sdo, tid);
             store_stats(cur ^ 1);
         }
+        if (DMA) dma_wait_all();
         __syncthreads();
     }
     bf16_t* dKo = reinterpret_cast<bf16_t*>(p.dk) + (int64_t)b * p.Lk * p.lddk + hh * p.dh;
@@ -1250,6 +1282,7 @@ __device__ __forceinline__ void attn_bwd_dkdv_pre_body(const Args& p) {
     store_acc(dV, dVo, p.lddv, krow, kvalid, p.dh, h, 1.f);
 }
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_pre(Args p) { attn_bwd_dkdv_pre_body<false>(p); }
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_pre_dma(Args p) { attn_bwd_dkdv_pre_body<false, true>(p); }
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_pre_masked(Args p) { attn_bwd_dkdv_pre_body<true>(p); }
 
 }  // namespace
@@ -1381,8 +1414,17 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
             hipLaunchKernelGGL(attn_bwd_dq_bf16_pre_masked, gq2, dim3(256), 0, s, pq);
             hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre_masked, gk2, dim3(256), 0, s, pk);
         } else {
+            // delta is a 3 x [B,H,Lq] scratch: fp32 delta | -lse2 pairs | -delta pairs (the last two for the DMA dK/dV kernel)
+            static const bool no_dma = getenv("SVOL_ATTN_NO_DKDV_DMA") != nullptr;
+            const bool dma = !no_dma && dh == 32 && Lq % KT == 0;
+            if (dma) {
+                const int64_t n = (int64_t)B * H * Lq;
+                pq.nl2 = pk.nl2 = reinterpret_cast<unsigned*>(delta + n);
+                pq.nd2 = pk.nd2 = reinterpret_cast<unsigned*>(delta + 2 * n);
+            }
             hipLaunchKernelGGL(attn_bwd_dq_bf16_pre, gq2, dim3(256), 0, s, pq);
-            hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre, gk2, dim3(256), 0, s, pk);
+            if (dma) hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre_dma, gk2, dim3(256), 0, s, pk);
+            else hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre, gk2, dim3(256), 0, s, pk);
         }
     } else if (masked) {
         hipLaunchKernelGGL(attn_bwd_dq_bf16<true>, gq, dim3(256), 0, s, p);

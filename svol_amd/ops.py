@@ -298,7 +298,7 @@ def attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias=None, premul=0.0):
 def attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias=None, premul=0.0):
     """Writes dq/dk/dv (2-D views, column slices allowed)."""
     do = do if do.stride(1) == 1 else do.contiguous()
-    delta = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
+    delta = torch.empty((3, B, H, Lq), dtype=torch.float32, device=q.device)  # delta | -lse2 pairs | -delta pairs (svol_hip.h)
     ws = _attn_ws(q, B, H, Lq, Lk, dh, kbias is not None or Lk % 128 != 0)
     tok = timer.start('attn_bwd', (B, H, Lq, Lk, dh))
     rc = _lib.lib().svol_attn_bwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o),
