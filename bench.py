@@ -223,6 +223,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
+    t_issued = time.perf_counter() - t0   # the host has ISSUED every step; the GPU is still running them
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -271,18 +272,27 @@ def main():
         which = 'attn_bwd (delta + dQ pass + dK/dV pass)' if bwd[1] >= fwd[1] else 'attn_fwd'
         flop, ms = (2.0 * attn_fwd_flop, bwd[1]) if bwd[1] >= fwd[1] else (attn_fwd_flop, fwd[1])
         ach = flop / (ms * 1e-3) / 1e12
-        # memory-side bytes per launch of the dominant kernel(s): from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
-        # this very command (profiles/round1_hbm_traffic.json; separate counter runs cannot happen inside the timed process)
+        # memory-side bytes per launch of the dominant kernel(s): from the NEWEST committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        # passes of this very command (profiles/roundN_hbm_traffic.json, which records the git head it was measured at; separate
+        # counter runs cannot happen inside the timed process)
         traffic = traffic_src = None
         if a.workload == 'cfg2' and B == 8:
             try:
-                tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'round1_hbm_traffic.json')))
-                pick = (['attn_bwd_dq_bf16_pre|', 'attn_bwd_dkdv_bf16_pre|', 'attn_delta_bf16|'] if bwd[1] >= fwd[1]
-                        else ['attn_fwd_bf16_pre|'])
+                import glob
+                import re
+                pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
+                files = sorted(glob.glob(os.path.join(pdir, 'round*_hbm_traffic.json')),
+                               key=lambda f_: int(re.search(r'round(\d+)_', os.path.basename(f_)).group(1)))
+                tj = json.load(open(files[-1]))
+                meta = tj.pop('_meta', {})
+                pick = (['attn_bwd_dq_bf16_pre|', 'attn_bwd_dkdv_bf16_pre|', 'attn_bwd_dkdv_bf16_pre_dma|', 'attn_delta_bf16|'] if bwd[1] >= fwd[1]
+                        else ['attn_fwd_bf16_pre|', 'attn_fwd_bf16_fast|'])
                 tot = sum((v['read_MB'] + v['write_MB']) * 1048576.0 for k_, v in tj.items() if any(k_.startswith(q_) for q_ in pick))
                 if tot > 0:
-                    traffic, traffic_src = tot, 'profiles/round1_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)'
-            except (OSError, ValueError, KeyError):
+                    traffic = tot
+                    traffic_src = ('profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch; measured at git %s)'
+                                   % (os.path.basename(files[-1]), meta.get('git_head', 'n/a: round-1 file')))
+            except (OSError, ValueError, KeyError, IndexError, AttributeError):
                 pass
         roof = {'bound': 'mfma', 'kernel': which, 'achieved': ach, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': ach / PEAK_BF16_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes per launch (HBM side)',
@@ -310,6 +320,8 @@ def main():
                        'global_batch': B * world, 'parallelism': f'dp{world}'},
             'n_ranks_seen': n_ranks_seen, 'dist_backend': backend if world > 1 else None,
             'final_loss': final_loss,
+            # host time to ISSUE a step (Python + launches, no sync): when it approaches ms_per_step the run is host-bound
+            'host_issue_ms_per_step': t_issued / a.steps * 1e3,
             'launch_mode': 'hipGraph replay (whole step captured)' if use_graph else 'eager',
         }
         if roof:

@@ -208,8 +208,11 @@ __global__ __launch_bounds__(256) void gate_apply_kernel(const float* __restrict
     }
 }
 
-// backward pass 1: LN1 backward, dx_part = ds1*(1+a), da[row] = sum_d ds1*x ; dgamma/dbeta atomics
-template <typename T>
+// backward pass 1: LN1 backward, dx_part = ds1*(1+a), da[row] = sum_d ds1*x ; dgamma/dbeta atomics.
+// NP = 16-byte column groups per lane (D <= 256 * NP): the row loop is latency-bound (one dependent load -> reduce -> store chain
+// per wave), so the NEXT row's four operand vectors are fetched before the current row is reduced, and the register arrays are sized
+// for the real width (the untemplated version carried four groups whatever D was: twice the registers, half the waves per SIMD).
+template <typename T, int NP>
 __global__ __launch_bounds__(256) void gate_bwd_ln_kernel(const float* __restrict__ dy32, const T* __restrict__ dy,
                                                           const T* __restrict__ dy2, const float* __restrict__ x,
                                                           const float* __restrict__ a_in,
@@ -219,34 +222,47 @@ __global__ __launch_bounds__(256) void gate_bwd_ln_kernel(const float* __restric
                                                           float* __restrict__ dbeta, int64_t M, int D, int rpw) {
     const int lane = threadIdx.x & 63;
     const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw;
-    float dg[GP][4], db[GP][4];
+    const int64_t rend = (r0 + rpw < M) ? r0 + rpw : M;
+    float dg[NP][4], db[NP][4], gm[NP][4];
 #pragma unroll
-    for (int j = 0; j < GP; ++j)
+    for (int j = 0; j < NP; ++j) {
+        const int c = (lane + 64 * j) * 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { dg[j][e] = 0.f; db[j][e] = 0.f; }
-    for (int64_t row = r0; row < r0 + rpw && row < M; ++row) {
-        const float mu = mean[row], rs = rstd[row], a = a_in[row];
-        float g[GP][4], xh[GP][4], xs[GP][4];
-        float s1 = 0.f, s2 = 0.f;
+        for (int e = 0; e < 4; ++e) { dg[j][e] = 0.f; db[j][e] = 0.f; gm[j][e] = c < D ? gamma[c + e] : 0.f; }
+    }
+    struct Row { Vec4<float> p32[NP], xv[NP]; Vec4<T> p[NP], p2[NP]; float mu, rs, a; };
+    auto fetch = [&](int64_t row, Row& r) {
 #pragma unroll
-        for (int j = 0; j < GP; ++j) {
+        for (int j = 0; j < NP; ++j) {
             const int c = (lane + 64 * j) * 4;
             if (c < D) {
-                Vec4<T> p, p2;
-                Vec4<float> p32, xv;
-                if (dy32) p32.load(dy32 + row * D + c);
-                if (dy) p.load(dy + row * D + c);
-                if (dy2) p2.load(dy2 + row * D + c);
-                xv.load(x + row * D + c);
+                if (dy32) r.p32[j].load(dy32 + row * D + c);
+                if (dy) r.p[j].load(dy + row * D + c);
+                if (dy2) r.p2[j].load(dy2 + row * D + c);
+                r.xv[j].load(x + row * D + c);
+            }
+        }
+        r.mu = mean[row]; r.rs = rstd[row]; r.a = a_in[row];
+    };
+    Row cur, nxt;
+    if (r0 < rend) fetch(r0, cur);
+    for (int64_t row = r0; row < rend; ++row) {
+        if (row + 1 < rend) fetch(row + 1, nxt);
+        const float mu = cur.mu, rs = cur.rs, a = cur.a;
+        float g[NP][4], xh[NP][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            if (c < D) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float d = (dy32 ? p32.get(e) : 0.f) + (dy ? p.get(e) : 0.f) + (dy2 ? p2.get(e) : 0.f);
-                    xs[j][e] = xv.get(e);
-                    const float hv = (xs[j][e] * (1.f + a) - mu) * rs;
+                    const float d = (dy32 ? cur.p32[j].get(e) : 0.f) + (dy ? cur.p[j].get(e) : 0.f) + (dy2 ? cur.p2[j].get(e) : 0.f);
+                    const float hv = (cur.xv[j].get(e) * (1.f + a) - mu) * rs;
                     xh[j][e] = hv;
                     dg[j][e] += d * hv;
                     db[j][e] += d;
-                    const float gg = d * gamma[c + e];
+                    const float gg = d * gm[j][e];
                     g[j][e] = gg;
                     s1 += gg;
                     s2 += gg * hv;
@@ -257,14 +273,14 @@ __global__ __launch_bounds__(256) void gate_bwd_ln_kernel(const float* __restric
         s2 = wave_sum(s2) / (float)D;
         float dacc = 0.f;
 #pragma unroll
-        for (int j = 0; j < GP; ++j) {
+        for (int j = 0; j < NP; ++j) {
             const int c = (lane + 64 * j) * 4;
             if (c < D) {
                 Vec4<float> o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float ds = rs * (g[j][e] - s1 - xh[j][e] * s2);
-                    dacc += ds * xs[j][e];
+                    dacc += ds * cur.xv[j].get(e);
                     o.set(e, ds * (1.f + a));
                 }
                 o.store(dx + row * D + c);
@@ -272,13 +288,14 @@ __global__ __launch_bounds__(256) void gate_bwd_ln_kernel(const float* __restric
         }
         dacc = wave_sum(dacc);
         if (lane == 0) da[row] = dacc;
+        cur = nxt;
     }
-    __shared__ float red[2][GP * 256];
+    __shared__ float red[2][NP * 256];
     const int wave = threadIdx.x >> 6;
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
-            for (int j = 0; j < GP; ++j) {
+            for (int j = 0; j < NP; ++j) {
                 const int c = (lane + 64 * j) * 4;
                 if (c < D) {
 #pragma unroll
@@ -326,7 +343,17 @@ __global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const float* __rest
     const int lend = min(l0 + rpw, L);
     Vec4<float> xv[NP], dv[NP], nxv[NP], ndv[NP];
     Vec4<T> pv[NP], npv[NP];
-    auto fetch = [&](int l, Vec4<float> (&xr)[NP], Vec4<T> (&pr)[NP], Vec4<float> (&dr)[NP]) {
+    // per-head constants of this batch element, and the per-row scalars (8 head scores + da): the row scalars are nine more
+    // dependent loads per row — fetched one row ahead with the vectors, or every row pays their full latency
+    float mxr[GH], isr[GH], ccr[GH], sc[GH], nsc[GH], dar = 0.f, ndar = 0.f;
+#pragma unroll
+    for (int hh = 0; hh < GH; ++hh) {
+        mxr[hh] = hh < H ? mx[b * H + hh] : 0.f;
+        isr[hh] = hh < H ? 1.f / sm[b * H + hh] : 0.f;
+        ccr[hh] = hh < H ? cc[b * H + hh] : 0.f;
+        sc[hh] = nsc[hh] = 0.f;
+    }
+    auto fetch = [&](int l, Vec4<float> (&xr)[NP], Vec4<T> (&pr)[NP], Vec4<float> (&dr)[NP], float (&sr)[GH], float& dr1) {
         const int64_t row = (int64_t)b * L + l;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
@@ -337,19 +364,22 @@ __global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const float* __rest
                 dr[j].load(dx + row * D + c);
             }
         }
+#pragma unroll
+        for (int hh = 0; hh < GH; ++hh)
+            if (hh < H) sr[hh] = scores[((int64_t)b * H + hh) * L + l];
+        dr1 = da[row];
     };
-    if (l0 < lend) fetch(l0, xv, pv, dv);
+    if (l0 < lend) fetch(l0, xv, pv, dv, sc, dar);
     for (int l = l0; l < lend; ++l) {
         const int64_t row = (int64_t)b * L + l;
-        if (l + 1 < lend) fetch(l + 1, nxv, npv, ndv);
+        if (l + 1 < lend) fetch(l + 1, nxv, npv, ndv, nsc, ndar);
         float ds[GH];
-        const float dal = da[row] / (float)H;
+        const float dal = dar / (float)H;
 #pragma unroll
         for (int hh = 0; hh < GH; ++hh) {
             if (hh < H) {
-                const int bh = b * H + hh;
-                const float pp = __expf(scores[(int64_t)bh * L + l] - mx[bh]) / sm[bh];
-                ds[hh] = pp * (dal - cc[bh]);
+                const float pp = __expf(sc[hh] - mxr[hh]) * isr[hh];
+                ds[hh] = pp * (dal - ccr[hh]);
             } else ds[hh] = 0.f;
         }
 #pragma unroll
@@ -372,6 +402,9 @@ __global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const float* __rest
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) { xv[j] = nxv[j]; pv[j] = npv[j]; dv[j] = ndv[j]; }
+#pragma unroll
+        for (int hh = 0; hh < GH; ++hh) sc[hh] = nsc[hh];
+        dar = ndar;
     }
     // du: fold the workgroup's four waves in LDS first (every wave of a batch element hits the same H*D addresses)
     __shared__ float red[GH * NP * 256];
@@ -471,8 +504,9 @@ int svol_gate_bwd(const float* dy32, const void* dy, const void* dy2, const floa
     dim3 g3((unsigned)((L + 4 * rpw3 - 1) / (4 * rpw3)), (unsigned)B);
 #define SVOL_GATE_BWD(TT)                                                                                                   \
     do {                                                                                                                    \
-        hipLaunchKernelGGL(gate_bwd_ln_kernel<TT>, dim3(g1), dim3(256), 0, s, dy32, (const TT*)dy, (const TT*)dy2, x32, a,  \
-                           gamma, mean, rstd, dx32, da, dgamma, dbeta, M, (int)D, rpw1);                                    \
+        if (np_ == 1) hipLaunchKernelGGL((gate_bwd_ln_kernel<TT, 1>), dim3(g1), dim3(256), 0, s, dy32, (const TT*)dy, (const TT*)dy2, x32, a, gamma, mean, rstd, dx32, da, dgamma, dbeta, M, (int)D, rpw1); \
+        else if (np_ == 2) hipLaunchKernelGGL((gate_bwd_ln_kernel<TT, 2>), dim3(g1), dim3(256), 0, s, dy32, (const TT*)dy, (const TT*)dy2, x32, a, gamma, mean, rstd, dx32, da, dgamma, dbeta, M, (int)D, rpw1); \
+        else hipLaunchKernelGGL((gate_bwd_ln_kernel<TT, 4>), dim3(g1), dim3(256), 0, s, dy32, (const TT*)dy, (const TT*)dy2, x32, a, gamma, mean, rstd, dx32, da, dgamma, dbeta, M, (int)D, rpw1); \
         hipLaunchKernelGGL(gate_bwd_stats_kernel, dim3((unsigned)(B * H)), dim3(256), 0, s, scores, mx, sm, da, cc, (int)L, \
                            (int)H);                                                                                         \
         if (np_ == 1) hipLaunchKernelGGL((gate_bwd_apply_kernel<TT, 1>), g3, dim3(256), 0, s, x32, (const TT*)pos, u, scores, mx, sm, da, cc, dx32, du, (int)L, (int)D, (int)H, rpw3); \

@@ -49,13 +49,19 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         # the query-stream / video-stream overlap (cross_modal_transformer.py) becomes fork / join edges in a capture,
         # which the replay executes slower than one serial chain (measured 25.5 vs 24.6 ms/step): capture it serial
+        # (SVOL_GRAPH_OVERLAP=1 keeps the side streams in the capture — to re-measure that on a new ROCm)
+        import os
+        from . import ops
         from .modeling import cross_modal_transformer as cmt
-        keep, cmt.OVERLAP_QUERY_STREAM = cmt.OVERLAP_QUERY_STREAM, False
+        overlap = os.environ.get('SVOL_GRAPH_OVERLAP') is not None
+        keep, cmt.OVERLAP_QUERY_STREAM = cmt.OVERLAP_QUERY_STREAM, cmt.OVERLAP_QUERY_STREAM and overlap
+        keep_w, ops.WGRAD_IN_CAPTURE = ops.WGRAD_IN_CAPTURE, overlap
         try:
             with torch.cuda.graph(self.graph):
                 self.static_loss, self.static_losses = self._step()
         finally:
             cmt.OVERLAP_QUERY_STREAM = keep
+            ops.WGRAD_IN_CAPTURE = keep_w
         torch.cuda.synchronize()
 
     def _step(self):

@@ -152,6 +152,7 @@ def gemm_tn(A, B, out=None, colsum=None):
 # BucketedGradAllReduce (before a bucket's all-reduce and in finish()).  The split-M TN kernels are HBM / atomic bound, the
 # attention-backward kernels they now run beside are instruction-issue bound: the two overlap almost for free.
 WGRAD_ASYNC = os.environ.get('SVOL_NO_WGRAD_STREAM') is None
+WGRAD_IN_CAPTURE = False   # (svol_amd.graph: a captured step keeps everything on one stream unless told otherwise)
 _WGRAD = {}
 
 
@@ -164,7 +165,7 @@ def wgrad_streams(dev):
 def gemm_tn_sink(A, B, out, colsum=None):
     """gemm_tn into a persistent gradient bucket view, off the critical path (see above).  `out` / `colsum` must be sink
     views: nothing on the current stream may read them before BucketedGradAllReduce.finish()."""
-    if not WGRAD_ASYNC or torch.cuda.is_current_stream_capturing():
+    if not WGRAD_ASYNC or (not WGRAD_IN_CAPTURE and torch.cuda.is_current_stream_capturing()):
         return gemm_tn(A, B, out=out, colsum=colsum)
     dev = A.device
     ws = _WGRAD.get(dev)
