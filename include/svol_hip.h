@@ -175,6 +175,15 @@ int svol_gate_bwd(const float* dy32, const void* dy, const void* dy2, const floa
                   const float* ws, float* ws2, float* dx32, float* du, float* dgamma, float* dbeta, int64_t B,
                   int64_t L, int64_t D, int64_t H, int dtype, void* stream);
 
+/* Gate VECTORS (the B*d-sized algebra in front of the gate): q[b,:] = W_q s_b + b_q, u[b,h,:] = d_h^-1/2 * W_k,h^T q[b,h,:],
+ * with W_in [3d,d] / b_in [3d] the packed nn.MultiheadAttention in_proj parameters (rows 0..d-1 = W_q, d..2d-1 = W_k),
+ * skch [B,d] the projected sketch token, all fp32.  Backward: du [B,H,d] -> dskch [B,d] (may be NULL), and dW_in / db_in are
+ * ACCUMULATED INTO (rows 0..2d-1 / entries 0..d-1; every element has one owner, no atomics), dq_ws: B*d fp32 scratch. */
+int svol_gate_vectors_fwd(const float* skch, const float* W_in, const float* b_in, float* q_out, float* u_out, int64_t B, int64_t D,
+                          int64_t H, void* stream);
+int svol_gate_vectors_bwd(const float* du, const float* skch, const float* W_in, const float* q, float* dq_ws, float* dskch,
+                          float* dW_in, float* db_in, int64_t B, int64_t D, int64_t H, void* stream);
+
 /* ---- set matching + criterion (matcher.py:38-159, loss.py:39-157) -------
  * A "problem" is one LSAP block the reference solves with scipy: one video for
  * HungarianMatcher (matcher.py:158), one (video, frame) for PerFrameMatcher (matcher.py:92-96),

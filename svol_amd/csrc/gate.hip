@@ -431,6 +431,117 @@ __global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Gate VECTORS: u[b,h,:] = d_h^-1/2 * W_k,h^T (W_q,h s_b + b_q,h) — the one-query attention's key projection folded into one
+// d-vector per (batch, head) (B*d-sized algebra on the packed in_proj parameters; cross_modal_transformer.py:122-123 through
+// nn.MultiheadAttention's in_proj).  One launch forward, two backward, instead of a dozen BLAS / elementwise launches.
+// forward: block = one (head, batch element), 256 threads.  Phase 1: the head's d_h rows of W_q, one wave per row (lanes split the
+// d columns, 16-byte loads, wave reduction) -> q[b, h*dh .. ]; phase 2: thread = column c, u[b,h,c] = sc * sum_e q[e] W_k[h*dh+e][c]
+// (row reads coalesced over the threads).
+__global__ __launch_bounds__(256) void gate_vec_fwd_kernel(const float* __restrict__ skch, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, float* __restrict__ q_out,
+                                                           float* __restrict__ u_out, int D, int H) {
+    __shared__ float s_q[GP * 256];
+    const int hh = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, dh = D / H;
+    float sv[GP][4];
+#pragma unroll
+    for (int j = 0; j < GP; ++j) {
+        const int c = (lane + 64 * j) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sv[j][e] = c < D ? skch[(int64_t)b * D + c + e] : 0.f;
+    }
+    for (int e = wave; e < dh; e += 4) {
+        const int row = hh * dh + e;
+        const float* w = W + (int64_t)row * D;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < GP; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            if (c < D) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c);
+                acc += wv[0] * sv[j][0] + wv[1] * sv[j][1] + wv[2] * sv[j][2] + wv[3] * sv[j][3];
+            }
+        }
+        acc = wave_sum(acc) + bias[row];
+        if (lane == 0) { s_q[e] = acc; q_out[(int64_t)b * D + row] = acc; }
+    }
+    __syncthreads();
+    const float sc = rsqrtf((float)dh);
+    const float* Wk = W + (int64_t)D * D + (int64_t)hh * dh * D;
+    for (int c = tid; c < D; c += 256) {
+        float acc = 0.f;
+        for (int e = 0; e < dh; ++e) acc += s_q[e] * Wk[(int64_t)e * D + c];
+        u_out[((int64_t)b * H + hh) * D + c] = acc * sc;
+    }
+}
+// backward A: block = one (head, batch element): dq[b, h*dh+e] = sc * du[b,h,:] . W_k[h*dh+e,:], one wave per row
+__global__ __launch_bounds__(256) void gate_vec_bwd_a_kernel(const float* __restrict__ du, const float* __restrict__ W,
+                                                             float* __restrict__ dq_out, int D, int H) {
+    const int hh = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, dh = D / H;
+    const float sc = rsqrtf((float)dh);
+    float gv[GP][4];
+#pragma unroll
+    for (int j = 0; j < GP; ++j) {
+        const int c = (lane + 64 * j) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gv[j][e] = c < D ? du[((int64_t)b * H + hh) * D + c + e] : 0.f;
+    }
+    const float* Wk = W + (int64_t)D * D;
+    for (int e = wave; e < dh; e += 4) {
+        const int row = hh * dh + e;
+        const float* w = Wk + (int64_t)row * D;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < GP; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            if (c < D) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c);
+                acc += wv[0] * gv[j][0] + wv[1] * gv[j][1] + wv[2] * gv[j][2] + wv[3] * gv[j][3];
+            }
+        }
+        acc = wave_sum(acc) * sc;
+        if (lane == 0) dq_out[(int64_t)b * D + row] = acc;
+    }
+}
+// backward B: blocks 0 .. D-1 = one row e of W_q and of W_k: dW_q[e][c] += sum_b dq[b][e] s[b][c] ; dW_k[e][c] += sc * sum_b q[b][e]
+// du[b][h(e)][c] ; db_q[e] += sum_b dq[b][e] (every output element has one owner: plain read-modify-write into the gradient, sink
+// or zeroed buffer); blocks D .. D+B-1 = one batch element: dskch[b][c] = sum_e dq[b][e] W_q[e][c] (row reads coalesced over c).
+__global__ __launch_bounds__(256) void gate_vec_bwd_b_kernel(const float* __restrict__ du, const float* __restrict__ skch,
+                                                             const float* __restrict__ q, const float* __restrict__ dq,
+                                                             const float* __restrict__ W, float* __restrict__ dW,
+                                                             float* __restrict__ db, float* __restrict__ dskch, int B, int D, int H) {
+    const int tid = threadIdx.x, dh = D / H;
+    if ((int)blockIdx.x >= D) {
+        const int b = blockIdx.x - D;
+        if (!dskch) return;
+        __shared__ float s_dq[GP * 256];
+        for (int e = tid; e < D; e += 256) s_dq[e] = dq[(int64_t)b * D + e];
+        __syncthreads();
+        for (int c = tid; c < D; c += 256) {
+            float acc = 0.f;
+            for (int e = 0; e < D; ++e) acc += s_dq[e] * W[(int64_t)e * D + c];
+            dskch[(int64_t)b * D + c] = acc;
+        }
+        return;
+    }
+    const int e = blockIdx.x, hh = e / dh;
+    const float sc = rsqrtf((float)dh);
+    for (int c = tid; c < D; c += 256) {
+        float aq = 0.f, ak = 0.f;
+        for (int b = 0; b < B; ++b) {
+            aq += dq[(int64_t)b * D + e] * skch[(int64_t)b * D + c];
+            ak += q[(int64_t)b * D + e] * du[((int64_t)b * H + hh) * D + c];
+        }
+        dW[(int64_t)e * D + c] += aq;
+        dW[(int64_t)(D + e) * D + c] += ak * sc;
+    }
+    if (tid == 0) {
+        float bsum = 0.f;
+        for (int b = 0; b < B; ++b) bsum += dq[(int64_t)b * D + e];
+        db[e] += bsum;
+    }
+}
+
 int rows_per_wave(int64_t rows, int64_t target_waves) {
     int64_t r = (rows + target_waves - 1) / target_waves;
     return (int)(r < 1 ? 1 : r);
@@ -516,6 +627,30 @@ int svol_gate_bwd(const float* dy32, const void* dy, const void* dy2, const floa
     if (dtype == SVOL_BF16) SVOL_GATE_BWD(bf16_t);
     else SVOL_GATE_BWD(float);
 #undef SVOL_GATE_BWD
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_gate_vectors_fwd(const float* skch, const float* W_in, const float* b_in, float* q_out, float* u_out, int64_t B, int64_t D,
+                          int64_t H, void* stream) {
+    if (!skch || !W_in || !b_in || !q_out || !u_out || B <= 0 || D <= 0 || H <= 0) return SVOL_E_INVALID;
+    if (D % 4 || D > GP * 256 || H > GH || D % H || B > 65535) return SVOL_E_UNSUPPORTED;
+    if (!aligned16(W_in)) return SVOL_E_INVALID;
+    hipLaunchKernelGGL(gate_vec_fwd_kernel, dim3((unsigned)H, (unsigned)B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), skch,
+                       W_in, b_in, q_out, u_out, (int)D, (int)H);
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_gate_vectors_bwd(const float* du, const float* skch, const float* W_in, const float* q, float* dq_ws, float* dskch,
+                          float* dW_in, float* db_in, int64_t B, int64_t D, int64_t H, void* stream) {
+    if (!du || !skch || !W_in || !q || !dq_ws || !dW_in || !db_in || B <= 0 || D <= 0 || H <= 0) return SVOL_E_INVALID;
+    if (D % 4 || D > GP * 256 || H > GH || D % H || B > 65535) return SVOL_E_UNSUPPORTED;
+    if (!aligned16(W_in)) return SVOL_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(gate_vec_bwd_a_kernel, dim3((unsigned)H, (unsigned)B), dim3(256), 0, s, du, W_in, dq_ws, (int)D, (int)H);
+    hipLaunchKernelGGL(gate_vec_bwd_b_kernel, dim3((unsigned)(D + B)), dim3(256), 0, s, du, skch, q, dq_ws, W_in, dW_in, db_in, dskch,
+                       (int)B, (int)D, (int)H);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }

@@ -75,47 +75,42 @@ def side_streams(dev):
 
 
 class _GateVectorsFn(torch.autograd.Function):
-    """u[b,h,:] = d_h^-1/2 * W_k,h^T (W_q,h s_b + b_q,h)  (B*d-sized algebra, torch ops on purpose).  A Function of
-    its own so that the packed in_proj parameters get ONE gradient each, written straight into the reducer's
-    bucket when there is one, instead of three slice-backward (zero-fill + copy + add) chains per layer."""
+    """u[b,h,:] = d_h^-1/2 * W_k,h^T (W_q,h s_b + b_q,h)  (B*d-sized algebra: svol_gate_vectors_fwd / _bwd, one launch forward and
+    two backward).  The packed in_proj parameters get ONE gradient each, accumulated straight into the reducer's bucket when
+    there is one."""
 
     @staticmethod
     def forward(ctx, skch, W_in, b_in, h):
-        d = skch.shape[1]
-        dh = d // h
-        q = torch.addmm(b_in[:d], skch, W_in[:d].t())                      # [B,d]
-        wk = W_in[d:2 * d].view(h, dh, d)
+        from .. import _lib
+        B, d = skch.shape
+        skch = skch.contiguous().float()
+        q = torch.empty((B, d), dtype=torch.float32, device=skch.device)
+        u = torch.empty((B, h, d), dtype=torch.float32, device=skch.device)
+        Wd, bd = W_in.detach(), b_in.detach()
+        rc = _lib.lib().svol_gate_vectors_fwd(ops._ptr(skch), ops._ptr(Wd), ops._ptr(bd), ops._ptr(q), ops._ptr(u), B, d, h, ops._stream())
+        _lib.check(rc, 'svol_gate_vectors_fwd')
         ctx.save_for_backward(skch, W_in, q)
         ctx.h = h
         ctx.sinks = (ops._claim(W_in, ctx.needs_input_grad[1]), ops._claim(b_in, ctx.needs_input_grad[2]))
-        return torch.einsum('bhe,hed->bhd', q.view(-1, h, dh), wk) * (dh ** -0.5)
+        return u
 
     @staticmethod
     def backward(ctx, du):
+        from .. import _lib
         skch, W_in, q = ctx.saved_tensors
         h = ctx.h
-        d = skch.shape[1]
-        dh = d // h
-        B = skch.shape[0]
+        B, d = skch.shape
         sW, sb = ctx.sinks
-        sc = dh ** -0.5
-        wk = W_in[d:2 * d].view(h, dh, d)
-        duh = du.transpose(0, 1)                                            # [h,B,d] (view)
-        dq = torch.bmm(duh, wk.transpose(1, 2)).transpose(0, 1).reshape(B, d).mul_(sc)  # sum_d du[b,h,d] wk[h,e,d] -> [B, h*dh]
-        qh = q.view(B, h, dh).permute(1, 2, 0)                              # [h,dh,B] (view)
-        dskch = dq @ W_in[:d] if ctx.needs_input_grad[0] else None
-        if sW is not None:  # straight into the gradient bucket: two fused multiply-accumulates, no temporaries
-            sW.view[:d].addmm_(dq.t(), skch)
-            sW.view[d:2 * d].view(h, dh, d).baddbmm_(qh, duh, alpha=sc)
-            dW = None
-        else:
-            dW = torch.cat([dq.t() @ skch, torch.bmm(qh, duh).mul_(sc).reshape(d, d), torch.zeros((d, d), dtype=du.dtype, device=du.device)])
-        if sb is not None:
-            sb.view[:d].add_(dq.sum(0))
-            db = None
-        else:
-            db = torch.cat([dq.sum(0), torch.zeros(2 * d, dtype=dq.dtype, device=dq.device)])
-        return dskch, dW, db, None
+        du = du.contiguous().float()
+        dev = du.device
+        dW = sW.view if sW is not None else torch.zeros((3 * d, d), dtype=torch.float32, device=dev)
+        db = sb.view if sb is not None else torch.zeros((3 * d,), dtype=torch.float32, device=dev)
+        dskch = torch.empty((B, d), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        ws = torch.empty((B, d), dtype=torch.float32, device=dev)
+        rc = _lib.lib().svol_gate_vectors_bwd(ops._ptr(du), ops._ptr(skch), ops._ptr(W_in.detach()), ops._ptr(q), ops._ptr(ws),
+                                              ops._ptr(dskch), ops._ptr(dW), ops._ptr(db), B, d, h, ops._stream())
+        _lib.check(rc, 'svol_gate_vectors_bwd')
+        return dskch, (None if sW is not None else dW), (None if sb is not None else db), None
 
 
 class CrossModalTransformerLayer(nn.Module):
