@@ -263,3 +263,73 @@ def test_fast_forward_flags_overflow_and_the_safe_kernel_repairs_it():
     # the hot queries attend to the hot key only
     for qi in hot_q:
         assert float((o[qi, hd * dh:(hd + 1) * dh].float().cpu() - qkv[hot_k, 2 * d + hd * dh:2 * d + (hd + 1) * dh].float()).abs().max()) < 1e-2
+
+
+def test_cfg5_attention_values_on_slices():
+    """BASELINE configs[4] shape (T = 128 x P = 256: L = 32768 tokens, H = 8, d_h = 32, bf16): VALUES of the streaming attention,
+    not only finiteness.  A full fp64 reference is 8.6 GB per head, so slices are checked against fp64
+    computed from the inputs the kernel saw: o / lse2 / dq for 256 queries spread over the sequence (all heads, every key), and
+    dk / dv for 256 keys of one head (every query of that head; its lse and delta in fp64, chunked)."""
+    import math
+    from svol_amd import ops
+    B, H, L, dh = 1, 8, 32768, 32
+    d = H * dh
+    pm = 1.4426950408889634 / math.sqrt(dh)
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn((L, d), generator=g) * 1.5
+    k = torch.randn((L, d), generator=g) * 1.5
+    v = torch.randn((L, d), generator=g)
+    do = torch.randn((L, d), generator=g)
+    qkv = torch.cat([(q.double() * pm).float(), k, v], 1).to(torch.bfloat16)
+    dob = do.to(torch.bfloat16)
+    dev, do_d = qkv.cuda(), dob.cuda()
+    o, lse2 = ops.attn_fwd(dev[:, :d], dev[:, d:2 * d], dev[:, 2 * d:], B, H, L, L, dh, None, pm)
+    dqkv = torch.empty_like(dev)
+    ops.attn_bwd(dev[:, :d], dev[:, d:2 * d], dev[:, 2 * d:], o, do_d, lse2, B, H, L, L, dh, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
+                 None, pm)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(o).all()) and bool(torch.isfinite(dqkv).all())
+    sc = 1.0 / math.sqrt(dh)
+    qs = torch.cat([torch.arange(0, 64), torch.arange(9000, 9064), torch.arange(20001, 20065), torch.arange(L - 64, L)])  # 256 queries
+    worst = {}
+    upd = lambda key, e: worst.__setitem__(key, max(worst.get(key, 0.0), e))   # noqa: E731
+    for h in range(H):
+        cs = slice(h * dh, (h + 1) * dh)
+        qh, kh, vh = qkv[qs, cs].double(), qkv[:, d + h * dh:d + (h + 1) * dh].double(), qkv[:, 2 * d + h * dh:2 * d + (h + 1) * dh].double()
+        s2 = qh @ kh.t()
+        m = s2.max(-1, keepdim=True).values
+        p = torch.exp2(s2 - m)
+        l_ = p.sum(-1, keepdim=True)
+        p /= l_
+        oh = p @ vh
+        lse_r = (m + torch.log2(l_)).squeeze(-1)
+        doh = dob[qs, cs].double()
+        dp = doh @ vh.t()
+        delta = (doh * oh).sum(-1, keepdim=True)
+        dq_r = ((p * (dp - delta)) @ kh) * sc
+        upd('o', float((o[qs, cs].double().cpu() - oh).abs().max() / oh.abs().max()))
+        upd('lse2', float((lse2[0, h, qs].double().cpu() - lse_r).abs().max() / lse_r.abs().max()))
+        upd('dq', float((dqkv[qs, cs].double().cpu() - dq_r).abs().max() / dq_r.abs().max()))
+    # dk / dv for 256 keys of head 3: needs lse and delta of EVERY query of that head (fp64, 1024-query chunks)
+    h = 3
+    cs = slice(h * dh, (h + 1) * dh)
+    ks = torch.cat([torch.arange(100, 228), torch.arange(L - 128, L)])
+    kh_all, vh_all = qkv[:, d + h * dh:d + (h + 1) * dh].double(), qkv[:, 2 * d + h * dh:2 * d + (h + 1) * dh].double()
+    dk_r, dv_r = torch.zeros((len(ks), dh), dtype=torch.float64), torch.zeros((len(ks), dh), dtype=torch.float64)
+    for c0 in range(0, L, 2048):
+        qc, doc = qkv[c0:c0 + 2048, cs].double(), dob[c0:c0 + 2048, cs].double()
+        s2 = qc @ kh_all.t()
+        lse_c = torch.logsumexp(s2 * math.log(2.0), -1, keepdim=True) / math.log(2.0)
+        p_all = torch.exp2(s2 - lse_c)
+        oc = p_all @ vh_all
+        delta = (doc * oc).sum(-1, keepdim=True)
+        p = p_all[:, ks]
+        dv_r += p.t() @ doc
+        dp = doc @ vh_all[ks].t()
+        dk_r += (p * (dp - delta)).t() @ (qc / pm) * sc
+        del s2, p_all
+    upd('dk', float((dqkv[ks, d + h * dh:d + (h + 1) * dh].double().cpu() - dk_r).abs().max() / dk_r.abs().max()))
+    upd('dv', float((dqkv[ks, 2 * d + h * dh:2 * d + (h + 1) * dh].double().cpu() - dv_r).abs().max() / dv_r.abs().max()))
+    print('cfg5 attention (L = 32768) slices vs fp64:', {k_: '%.2e' % e for k_, e in worst.items()})
+    assert worst['o'] <= 1.2e-2 and worst['lse2'] <= 1e-5, worst
+    assert worst['dq'] <= 2.4e-2 and worst['dk'] <= 2.4e-2 and worst['dv'] <= 2.4e-2, worst
