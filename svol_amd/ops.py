@@ -27,8 +27,31 @@ def _dt(t: torch.Tensor) -> int:
         raise _lib.SvolHipError(f'unsupported dtype {t.dtype}')
 
 
+# the raw handle of torch's CURRENT stream.  torch.cuda.current_stream() costs 5-8 us of Python per call (device-index
+# resolution through is_available / os.getenv) and every C-ABI call needs it: ~3 ms of host time per training step; the two
+# private C entry points below are what it wraps (0.3 us).
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_CUR_DEVICE = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def _stream() -> int:
+    if _RAW_STREAM is not None and _CUR_DEVICE is not None:
+        return _RAW_STREAM(_CUR_DEVICE())
     return torch.cuda.current_stream().cuda_stream
+
+
+_STREAM_OBJS = {}
+
+
+def _current_stream_obj():
+    """torch.cuda.current_stream() through a cache keyed by the raw handle (same reason as _stream)."""
+    if _RAW_STREAM is None or _CUR_DEVICE is None:
+        return torch.cuda.current_stream()
+    key = (_CUR_DEVICE(), _RAW_STREAM(_CUR_DEVICE()))
+    obj = _STREAM_OBJS.get(key)
+    if obj is None:
+        obj = _STREAM_OBJS[key] = torch.cuda.current_stream()
+    return obj
 
 
 def _ptr(t: Optional[torch.Tensor]) -> int:
@@ -130,9 +153,9 @@ def gemm_nt(A, B, bias=None, act=ACT_NONE, residual=None, want_pre=False, out=No
     return (out, pre) if want_pre else out
 
 
-def gemm_tn(A, B, out=None, colsum=None):
+def gemm_tn(A, B, out=None, colsum=None, stream=None):
     """out[N,K] (fp32) += A[Mc,N]^T @ B[Mc,K]; a fresh zeroed `out` is allocated when not given.
-    colsum (fp32 [N], zeroed by the caller) += column sums of A (bias gradient, fused)."""
+    colsum (fp32 [N], zeroed by the caller) += column sums of A (bias gradient, fused).  stream: raw handle (default: current)."""
     assert A.dim() == 2 and B.dim() == 2 and A.shape[0] == B.shape[0]
     assert A.stride(1) == 1 and B.stride(1) == 1
     Mc, N = A.shape
@@ -140,7 +163,7 @@ def gemm_tn(A, B, out=None, colsum=None):
     if out is None:
         out = torch.zeros((N, K), dtype=torch.float32, device=A.device)
     rc = _lib.lib().svol_gemm_tn(_ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), out.stride(0), _ptr(colsum),
-                                 Mc, N, K, _dt(A), _stream())
+                                 Mc, N, K, _dt(A), _stream() if stream is None else stream)
     _lib.check(rc, 'svol_gemm_tn')
     return out
 
@@ -171,9 +194,8 @@ def gemm_tn_sink(A, B, out, colsum=None):
     ws = _WGRAD.get(dev)
     if ws is None:
         ws = _WGRAD[dev] = torch.cuda.Stream(device=dev)
-    ws.wait_stream(torch.cuda.current_stream(dev))
-    with torch.cuda.stream(ws):
-        gemm_tn(A, B, out=out, colsum=colsum)
+    ws.wait_stream(_current_stream_obj())
+    gemm_tn(A, B, out=out, colsum=colsum, stream=ws.cuda_stream)   # (explicit handle: no current-stream switch on the host)
     A.record_stream(ws)
     B.record_stream(ws)
     return out
