@@ -36,6 +36,8 @@ constexpr int WS_K = 256;
 constexpr int TR = 16;                 // rows per slab
 constexpr int A_PLANE = TR * WS_K * 2;  // 8 KiB
 
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
 template <int N> __device__ __forceinline__ void ws_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void ws_wait_vm_dyn(int n) {
     switch (n) {
@@ -320,6 +322,269 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_bf16_m0(WsArgs p) { gemm_ws_bo
 __global__ __launch_bounds__(256, 2) void gemm_ws_bf16_m1(WsArgs p) { gemm_ws_body<1>(p); }
 __global__ __launch_bounds__(256, 2) void gemm_ws_bf16_m2(WsArgs p) { gemm_ws_body<2>(p); }
 
+// ---- software-pipelined body (bf16 outputs: MODE 0 and MODE 2) ---------------------------------------------------
+// The plain loop above runs a slab's stages back to back in every wave — wait, barrier, ds_read (full LDS latency exposed),
+// 32 MFMAs, the epilogue's VALU, the stores — and with W holding 128 VGPRs only two waves share a SIMD, so the stage
+// times ADD (stage ablation on MI355X, fc1 shape: 79 us = 29 skeleton + 8 ds_read + ~20 MFMA + ~25 epilogue/stores).
+// Here slab j+1's fragment reads are issued as soon as slab j's MFMAs are, and slab j's epilogue is ordinary VALU code
+// in the same basic block as slab j+1's MFMAs (the activation, the epilogue flags are template parameters: no branches),
+// so it fills the LDS latency and the matrix pipe's shadow.  Everything slab j's epilogue needs from LDS (MODE 2: the
+// saved pre-activation) is read with the fragments, because sync(j) hands slab j's slot back to the DMA ring.
+template <int MODE, int ACT, bool PRE, bool SCALE, int VPM>
+__device__ __forceinline__ void gemm_wsp_body(const WsArgs& p) {
+    static_assert(MODE == 0 || MODE == 2, "bf16 outputs only");
+    constexpr int SLOT = WsCfg<MODE>::SLOT, STG = 4, ND = WsCfg<MODE>::ND;
+    constexpr int NS = MODE == 0 ? (PRE ? 4 : 2) : 2;
+    __shared__ __attribute__((aligned(1024))) char smem[STG * SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int chunk_id = blockIdx.x % p.nchunk, cg = blockIdx.x / p.nchunk;
+    const int cg0 = cg * 256;
+    const int c0 = cg0 + wave * 64;
+    const bool active = c0 < p.N;
+    const int tile0 = chunk_id * p.tiles_per_wg;
+    const int row_base = tile0 * TR;
+    const int rows_here = min(p.tiles_per_wg * TR, p.M - row_base);
+    const int ntile = (rows_here + TR - 1) / TR;
+
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.A + (int64_t)row_base * p.lda), 0, (int)((((int64_t)rows_here - 1) * p.lda + WS_K) * 2), 0x00020000);
+    int voffA[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 2 + (lane >> 5), s = lane & 31;
+        voffA[j] = (int)(((int64_t)row * p.lda + ((s ^ row) & 31) * 8) * 2);
+    }
+    __amdgpu_buffer_rsrc_t rX = rA;
+    int voffX[2] = {0, 0};
+    if constexpr (MODE == 2) {
+        const bf16_t* X = p.aux + (int64_t)row_base * p.ldaux + cg0;
+        const int cols = min(256, p.N - cg0);
+        rX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)((((int64_t)rows_here - 1) * p.ldaux + cols) * 2), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (wave * 2 + j) * 2 + (lane >> 5), s = lane & 31;
+            voffX[j] = (int)(((int64_t)row * p.ldaux + ((s ^ row) & 31) * 8) * 2);
+        }
+    }
+    auto issue = [&](int slot, int tile) {
+        char* sl = smem + slot * SLOT;
+        const int soA = (int)((int64_t)tile * TR * p.lda * 2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(sl + (wave * 2 + j) * 1024), 16, voffA[j], soA, 0, 0);
+        if constexpr (MODE == 2) {
+            const int so = (int)((int64_t)tile * TR * p.ldaux * 2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_void_ptr)(sl + A_PLANE + (wave * 2 + j) * 1024), 16, voffX[j], so, 0, 0);
+        }
+    };
+
+    uint4 wf[4][8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const bf16_t* wrow = p.W + (int64_t)(c0 + ws_col(t, fr)) * p.ldw + fq * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) wf[t][ks] = active ? *reinterpret_cast<const uint4*>(wrow + ks * 32) : make_uint4(0, 0, 0, 0);
+    }
+    float bias8[2][8], scale8[2][8];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = c0 + hf * 32 + fq * 8 + e;
+            bias8[hf][e] = (MODE == 0 && active && p.bias) ? p.bias[n] : 0.f;
+            scale8[hf][e] = (MODE == 0 && SCALE && active && p.colscale) ? p.colscale[n] : 1.f;
+        }
+    float csum[2][8];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[hf][e] = 0.f;
+
+    const unsigned lds0 = (unsigned)(size_t)(lds_void_ptr)smem;
+    const unsigned aoff = (unsigned)(fr * 512 + ((fq ^ fr) & 3) * 16);
+    const unsigned ax_x = (unsigned)((fr & 12) * 16);
+    const unsigned xq0 = (unsigned)(A_PLANE + fr * 512 + (((wave * 8 + fq) ^ fr) & 31) * 16);
+    const unsigned xq1 = (unsigned)(A_PLANE + fr * 512 + (((wave * 8 + 4 + fq) ^ fr) & 31) * 16);
+    // outputs go through buffer stores: the range check drops rows past M (and everything of an idle wave: 0 records), so
+    // the epilogue has no branch — one basic block with the MFMAs — and every wave issues the same number of stores;
+    // per-lane offset constant, the slab advances the scalar offset (no address arithmetic in the loop)
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<bf16_t*>(p.C) + (int64_t)row_base * p.ldc), 0,
+        active ? (int)((((int64_t)rows_here - 1) * p.ldc + p.N) * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(PRE ? p.pre + (int64_t)row_base * p.ldp : nullptr), 0,
+        (PRE && active) ? (int)((((int64_t)rows_here - 1) * p.ldp + p.N) * 2) : 0, 0x00020000);
+    const int voffC = (int)(((int64_t)fr * p.ldc + c0 + fq * 8) * 2), voffP = (int)(((int64_t)fr * p.ldp + c0 + fq * 8) * 2);
+    const int cstep = (int)(TR * p.ldc * 2), pstep = (int)(TR * p.ldp * 2);
+
+    u32x4_t af[8], ax[2] = {u32x4_t{0, 0, 0, 0}, u32x4_t{0, 0, 0, 0}};
+    // fragment (and MODE 2: aux) reads of the slab in `slot`, NOT waited for
+    auto read_frags = [&](int slot) {
+        const unsigned sl = lds0 + (unsigned)(slot * SLOT);
+        const unsigned b = sl + aoff;
+        asm volatile(
+            "ds_read_b128 %0, %8\n\t"
+            "ds_read_b128 %1, %9\n\t"
+            "ds_read_b128 %2, %10\n\t"
+            "ds_read_b128 %3, %11\n\t"
+            "ds_read_b128 %4, %8 offset:256\n\t"
+            "ds_read_b128 %5, %9 offset:256\n\t"
+            "ds_read_b128 %6, %10 offset:256\n\t"
+            "ds_read_b128 %7, %11 offset:256"
+            : "=&v"(af[0]), "=&v"(af[1]), "=&v"(af[2]), "=&v"(af[3]), "=&v"(af[4]), "=&v"(af[5]), "=&v"(af[6]), "=&v"(af[7])
+            : "v"(b + ((0u * 64) ^ ax_x)), "v"(b + ((1u * 64) ^ ax_x)), "v"(b + ((2u * 64) ^ ax_x)), "v"(b + ((3u * 64) ^ ax_x))
+            : "memory");
+        if constexpr (MODE == 2) {
+            asm volatile(
+                "ds_read_b128 %0, %2\n\t"
+                "ds_read_b128 %1, %3"
+                : "=&v"(ax[0]), "=&v"(ax[1])
+                : "v"(sl + xq0), "v"(sl + xq1)
+                : "memory");
+        }
+    };
+    auto wait_frags = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]),
+                       "+v"(ax[0]), "+v"(ax[1]));
+    };
+    auto mfma_slab = [&](f32x4 (&acc)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t][ks]),
+                                                                 __builtin_bit_cast(bf16x8, af[ks]), acc[t], 0, 0, 0);
+    };
+    // epilogue of slab j from its accumulators (and, MODE 2, its aux fragment)
+    auto epilogue = [&](int j, const f32x4 (&acc)[4], const u32x4_t (&axj)[2]) {
+        float v[2][8];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[hf][e] = acc[2 * hf + (e >> 2)][e & 3];
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[hf][e] += bias8[hf][e];
+                    if constexpr (SCALE) v[hf][e] *= scale8[hf][e];
+                }
+            if constexpr (PRE) {
+                bf16x8 o[2];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[hf][e] = (bf16_t)v[hf][e];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[0]), rP, voffP, j * pstep, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[1]), rP, voffP + 64, j * pstep, 0);
+            }
+            bf16x8 o[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float y = v[hf][e];
+                    if constexpr (ACT == SVOL_ACT_GELU) y = gelu_fast(y);
+                    if constexpr (ACT == SVOL_ACT_RELU) y = fmaxf(y, 0.f);
+                    o[hf][e] = (bf16_t)y;
+                }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[0]), rC, voffC, j * cstep, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[1]), rC, voffC + 64, j * cstep, 0);
+        } else {
+            bf16x8 o[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const bf16x8 a8 = __builtin_bit_cast(bf16x8, axj[hf]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    // rows past M and idle waves: acc = 0 (zero-filled slabs, zero W) and a finite derivative: d = 0
+                    const float d = v[hf][e] * dact_fast((float)a8[e], ACT);
+                    csum[hf][e] += d;
+                    o[hf][e] = (bf16_t)d;
+                }
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[0]), rC, voffC, j * cstep, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[1]), rC, voffC + 64, j * cstep, 0);
+        }
+    };
+
+#pragma unroll
+    for (int s = 0; s < STG; ++s)
+        if (s < ntile) issue(s, s);
+    ws_wait_vm_dyn(ND * min(STG - 1, ntile - 1));
+    __builtin_amdgcn_s_barrier();
+    read_frags(0);
+    wait_frags();
+    f32x4 acc[4];
+    mfma_slab(acc);
+    for (int j = 0; j + 1 < ntile; ++j) {
+        // ---- sync(j): slab j+1 has landed everywhere, slab j's slot is free --------------------------------------
+        // operations of this wave younger than slab j+1's DMA: the DMAs of slabs j+2 .. j+STG-1 and the stores of the
+        // epilogues j+1-STG .. j-1
+        const int nd = min(STG - 2, ntile - 2 - j), nst = min(j, STG - 1);
+        if (nd == STG - 2 && nst == STG - 1) ws_wait_vm<ND * (STG - 2) + NS * (STG - 1)>();
+        else ws_wait_vm_dyn(ND * nd + NS * nst);
+        __builtin_amdgcn_s_barrier();
+        if (j + STG < ntile) issue(j % STG, j + STG);
+        f32x4 accp[4];
+        u32x4_t axp[2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accp[t] = acc[t];
+        axp[0] = ax[0];
+        axp[1] = ax[1];
+        read_frags((j + 1) % STG);
+        wait_frags();
+        mfma_slab(acc);
+        epilogue(j, accp, axp);
+        // hipcc would issue the 32 MFMAs back to back and the epilogue after them; spread the epilogue's VALU work over
+        // the matrix pipe's shadow instead (a 16x16x32 MFMA occupies the pipe for 16 cycles, its issue takes 4)
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+        }
+    }
+    {
+        u32x4_t axp[2] = {ax[0], ax[1]};
+        epilogue(ntile - 1, acc, axp);
+    }
+    if constexpr (MODE == 2) {
+        if (p.colsum) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float s = csum[hf][e];
+                    s += __shfl_xor(s, 1, 64);
+                    s += __shfl_xor(s, 2, 64);
+                    s += __shfl_xor(s, 4, 64);
+                    s += __shfl_xor(s, 8, 64);
+                    if (fr == 0 && active) atomicAdd(p.colsum + c0 + hf * 32 + fq * 8 + e, s);
+                }
+        }
+    }
+}
+
+// VPM: VALU instructions scheduled behind each MFMA (about the epilogue's VALU count / 32)
+#define WSP_KERNEL(name, MODE, ACT, PRE, SCALE, VPM) \
+    __global__ __launch_bounds__(256, 2) void name(WsArgs p) { gemm_wsp_body<MODE, ACT, PRE, SCALE, VPM>(p); }
+WSP_KERNEL(gemm_wsp_bf16_none, 0, SVOL_ACT_NONE, false, false, 2)
+WSP_KERNEL(gemm_wsp_bf16_none_scale, 0, SVOL_ACT_NONE, false, true, 2)
+WSP_KERNEL(gemm_wsp_bf16_gelu, 0, SVOL_ACT_GELU, false, false, 7)
+WSP_KERNEL(gemm_wsp_bf16_gelu_pre, 0, SVOL_ACT_GELU, true, false, 8)
+WSP_KERNEL(gemm_wsp_bf16_relu, 0, SVOL_ACT_RELU, false, false, 2)
+WSP_KERNEL(gemm_wsp_bf16_dgelu, 2, SVOL_ACT_GELU, false, false, 9)
+WSP_KERNEL(gemm_wsp_bf16_drelu, 2, SVOL_ACT_RELU, false, false, 3)
+#undef WSP_KERNEL
+
 }  // namespace
 
 // launcher used by gemm_bf16.hip's fast-path dispatcher.  Returns SVOL_E_UNSUPPORTED when the call does not fit.
@@ -355,7 +620,10 @@ int svol_gemm_ws_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, vo
         if (tpw > 64) tpw = 64;
     }
     const int64_t ldmax = lda > ldr * 2 ? lda : ldr * 2;
-    if (tpw * TR * (ldmax > ldaux ? ldmax : ldaux) * 2 >= (1ll << 31)) return SVOL_E_UNSUPPORTED;
+    int64_t ldbig = ldmax > ldaux ? ldmax : ldaux;  // 32-bit buffer offsets inside one workgroup's rows (loads and stores)
+    if (ldc > ldbig) ldbig = ldc;
+    if (pre && ldp > ldbig) ldbig = ldp;
+    if (tpw * TR * ldbig * 2 >= (1ll << 31)) return SVOL_E_UNSUPPORTED;
     int64_t nchunk = (ntile + tpw - 1) / tpw;
     if (ncg > 1 && nchunk > 8 && nchunk % 8) {  // a multiple of the 8 XCDs when column groups share rows
         const int64_t n8 = (nchunk + 7) / 8 * 8;
@@ -366,7 +634,17 @@ int svol_gemm_ws_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, vo
     WsArgs p{(const bf16_t*)A, (const bf16_t*)W, C, bias, colscale, (bf16_t*)pre, res, (const bf16_t*)aux, colsum,
              lda, ldw, ldc, ldp, ldr, ldaux, (int)M, (int)N, act, (int)tpw, (int)nchunk};
     dim3 grid((unsigned)(ncg * nchunk));
-    if (mode == 0) hipLaunchKernelGGL(gemm_ws_bf16_m0, grid, dim3(256), 0, s, p);
+    static const bool no_pipe = getenv("SVOL_WS_NO_PIPE") != nullptr;
+    void (*kp)(WsArgs) = nullptr;
+    if (!no_pipe && mode == 0) {
+        if (act == SVOL_ACT_NONE && !pre) kp = colscale ? gemm_wsp_bf16_none_scale : gemm_wsp_bf16_none;
+        else if (act == SVOL_ACT_GELU && !colscale) kp = pre ? gemm_wsp_bf16_gelu_pre : gemm_wsp_bf16_gelu;
+        else if (act == SVOL_ACT_RELU && !pre && !colscale) kp = gemm_wsp_bf16_relu;
+    } else if (!no_pipe && mode == 2) {
+        kp = act == SVOL_ACT_RELU ? gemm_wsp_bf16_drelu : gemm_wsp_bf16_dgelu;
+    }
+    if (kp) hipLaunchKernelGGL(kp, grid, dim3(256), 0, s, p);
+    else if (mode == 0) hipLaunchKernelGGL(gemm_ws_bf16_m0, grid, dim3(256), 0, s, p);
     else if (mode == 1) hipLaunchKernelGGL(gemm_ws_bf16_m1, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(gemm_ws_bf16_m2, grid, dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;

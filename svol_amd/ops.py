@@ -132,7 +132,7 @@ def cast_transpose(w: torch.Tensor, dtype: torch.dtype, want: bool = True, want_
     return d, dT
 
 
-def gemm_nt(A, B, bias=None, act=ACT_NONE, residual=None, want_pre=False, out=None, out_f32=False, colscale=None):
+def gemm_nt(A, B, bias=None, act=ACT_NONE, residual=None, want_pre=False, out=None, out_f32=False, colscale=None, pre_out=None):
     """out[M,N] = act(A[M,K] @ B[N,K]^T + bias) + residual.  A/B/out/residual may be column slices
     of wider row-major buffers (stride(0) is the leading dimension).  out_f32: `out` and `residual`
     are fp32 (the fp32 residual stream) whatever the operand dtype."""
@@ -143,7 +143,7 @@ def gemm_nt(A, B, bias=None, act=ACT_NONE, residual=None, want_pre=False, out=No
     if out is None:
         out = torch.empty((M, N), dtype=cdt, device=A.device)
     assert out.dtype == cdt and (residual is None or residual.dtype == cdt)
-    pre = torch.empty((M, N), dtype=A.dtype, device=A.device) if want_pre else None
+    pre = (pre_out if pre_out is not None else torch.empty((M, N), dtype=A.dtype, device=A.device)) if want_pre else None
     rc = _lib.lib().svol_gemm_nt(_ptr(A), A.stride(0), 0, 0, _ptr(B), B.stride(0), _ptr(out), out.stride(0),
                                  _ptr(bias), _ptr(colscale), act, _ptr(pre), pre.stride(0) if pre is not None else 0,
                                  _ptr(residual),

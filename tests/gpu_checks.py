@@ -92,6 +92,25 @@ def check_gemm_nt():
         A, Bm, bias = _rnd((4300, 768), dt, 21), _rnd((1024, 768), dt, 22, 1.0 / math.sqrt(768)), _rnd((1024,), torch.float32, 23)
         out = ops.gemm_nt(A.to(DEV), Bm.to(DEV), bias.to(DEV), ops.ACT_GELU)
         res[f'gemm_nt/{dt}/wide_gelu'] = (rel_err(out, _act(A.double() @ Bm.double().t() + bias.double(), ops.ACT_GELU)), TOL[dt])
+        # tall M at K = 256 without a residual: the weight-stationary kernel's bf16 epilogues (ragged M: the last slab is
+        # partly past the end; N not a multiple of 256: idle waves; output into a column slice of a wider buffer; colscale)
+        for (M, N) in [(4133, 512), (4500, 2048), (4099, 64), (5001, 320)]:
+            A, Bm, bias = _rnd((M, 256), dt, 31), _rnd((N, 256), dt, 32, 1.0 / 16), _rnd((N,), torch.float32, 33)
+            cs = (torch.arange(N) % 3 + 1).float() * 0.5
+            pre_ref = A.double() @ Bm.double().t() + bias.double()
+            for act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_GELU):
+                out = ops.gemm_nt(A.to(DEV), Bm.to(DEV), bias.to(DEV), act, want_pre=(act == ops.ACT_GELU))
+                if act == ops.ACT_GELU:
+                    out, pre = out
+                    res[f'gemm_nt/{dt}/tall{M}x{N}/pre'] = (rel_err(pre, pre_ref), TOL[dt])
+                res[f'gemm_nt/{dt}/tall{M}x{N}/act{act}'] = (rel_err(out, _act(pre_ref, act)), TOL[dt])
+            wide = torch.full((M + 3, N + 64), 7.0, dtype=dt, device=DEV)
+            ops.gemm_nt(A.to(DEV), Bm.to(DEV), bias.to(DEV), out=wide[:M, 32:32 + N] if dt == torch.float32 else wide[:M, 64:], colscale=cs.to(DEV))
+            got = wide[:M, 32:32 + N] if dt == torch.float32 else wide[:M, 64:]
+            res[f'gemm_nt/{dt}/tall{M}x{N}/slice_colscale'] = (rel_err(got, pre_ref * cs.double()), TOL[dt])
+            rest = wide.clone()
+            (rest[:M, 32:32 + N] if dt == torch.float32 else rest[:M, 64:]).fill_(7.0)
+            res[f'gemm_nt/{dt}/tall{M}x{N}/slice_untouched'] = (float((rest - 7.0).abs().max()), 0.0)
         # skinny-M path (bf16: intra-workgroup split-K kernel): every epilogue, ragged M, deep K, fp32 stream, colscale
         for (M, N, K) in [(333, 128, 256), (800, 256, 2048), (31, 64, 512)]:
             A = _rnd((M, K), dt, 11)
@@ -116,7 +135,8 @@ def check_gemm_nt():
 def check_gemm_dgelu():
     res = {}
     for dt in DTYPES:
-        for (M, N, K) in [(300, 256, 64), (1000, 2048, 256), (130, 64, 128), (77, 96, 32), (801, 192, 256), (800, 2048, 256), (800, 256, 2048)]:
+        for (M, N, K) in [(300, 256, 64), (1000, 2048, 256), (130, 64, 128), (77, 96, 32), (801, 192, 256), (800, 2048, 256), (800, 256, 2048),
+                          (4133, 512, 256), (5001, 320, 256)]:  # the last two: weight-stationary kernel, ragged M, idle waves
             A, W = _rnd((M, K), dt, 50), _rnd((N, K), dt, 51, 1.0 / math.sqrt(K))
             pre = _rnd((M, N), dt, 52)
             out, cs = ops.gemm_nt_dgelu(A.to(DEV), W.to(DEV), pre.to(DEV))

@@ -105,6 +105,22 @@ if 'gemm2' in which:  # the step's GEMM variants with their real epilogues; GB/s
         t = timeit(fn)
         print(f'{name:34s}: {t * 1e3:7.1f} us  {2.0 * M * n * kk / t / 1e9:6.1f} TFLOP/s  {byts / t / 1e6:6.0f} GB/s')
 
+if 'gemm3' in which:  # fc1 epilogue ablation: what bounds the weight-stationary kernel at N = F
+    M = B * L
+    x = rnd(M, D)
+    W_fd = rnd(F, D, scale=0.05)
+    b_f = torch.zeros(F, device=DEV)
+    for name, fn, byts in [
+        ('fc1 none', lambda: ops.gemm_nt(x, W_fd, b_f), M * D * 2 + M * F * 2),
+        ('fc1 relu', lambda: ops.gemm_nt(x, W_fd, b_f, ops.ACT_RELU), M * D * 2 + M * F * 2),
+        ('fc1 gelu', lambda: ops.gemm_nt(x, W_fd, b_f, ops.ACT_GELU), M * D * 2 + M * F * 2),
+        ('fc1 relu+pre', lambda: ops.gemm_nt(x, W_fd, b_f, ops.ACT_RELU, want_pre=True), M * D * 2 + M * F * 4),
+        ('fc1 gelu+pre', lambda: ops.gemm_nt(x, W_fd, b_f, ops.ACT_GELU, want_pre=True), M * D * 2 + M * F * 4),
+        ('fill [M,F] bf16', (lambda o=torch.empty((M, F), dtype=torch.bfloat16, device=DEV): o.fill_(1.0)), M * F * 2),
+    ]:
+        t = timeit(fn)
+        print(f'{name:34s}: {t * 1e3:7.1f} us  {byts / t / 1e6:6.0f} GB/s')
+
 if 'ln' in which:
     M = B * L
     x = torch.randn(M, D, device=DEV)
