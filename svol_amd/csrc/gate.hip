@@ -514,13 +514,28 @@ __global__ __launch_bounds__(256) void gate_vec_bwd_b_kernel(const float* __rest
     if ((int)blockIdx.x >= D) {
         const int b = blockIdx.x - D;
         if (!dskch) return;
+        // 4 waves x 64 lanes: a lane owns 4 consecutive columns (one 16-byte load per row of W), a wave every 4th row; the
+        // four partial sums meet in LDS (256 dependent row reads per thread in the one-column-per-thread form: 40 us)
         __shared__ float s_dq[GP * 256];
+        __shared__ float4 s_red[4][GP * 64];
         for (int e = tid; e < D; e += 256) s_dq[e] = dq[(int64_t)b * D + e];
         __syncthreads();
+        const int w = tid >> 6, l = tid & 63;
+        for (int c = 4 * l, k = l; c < D; c += 256, k += 64) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+            for (int e = w; e < D; e += 4) {
+                const float4 wv = *reinterpret_cast<const float4*>(W + (int64_t)e * D + c);
+                const float g = s_dq[e];
+                acc.x += g * wv.x; acc.y += g * wv.y; acc.z += g * wv.z; acc.w += g * wv.w;
+            }
+            s_red[w][k] = acc;
+        }
+        __syncthreads();
         for (int c = tid; c < D; c += 256) {
-            float acc = 0.f;
-            for (int e = 0; e < D; ++e) acc += s_dq[e] * W[(int64_t)e * D + c];
-            dskch[(int64_t)b * D + c] = acc;
+            const float* r = reinterpret_cast<const float*>(&s_red[0][0]);
+            const int stride = GP * 64 * 4;
+            dskch[(int64_t)b * D + c] = (r[c] + r[stride + c]) + (r[2 * stride + c] + r[3 * stride + c]);
         }
         return;
     }
