@@ -142,7 +142,10 @@ int svol_posenc_sine(const float* mask, void* pos, int64_t B, int64_t L, int64_t
  * merged by a small second kernel.  Launches with a key bias or a key count that is not a multiple of 128 and MANY queries
  * use the scratch for one int per (batch, 128-key tile) — the tile's class: no bias / mixed / fully masked (skipped) — so
  * that the fast kernels can serve them; without scratch such launches run on the general (slower) kernels.
- * Nothing is allocated inside the library.
+ * Unmasked bf16 launches with dh == 32 and pre-multiplied q use it for one int per workgroup (batch, head, 128-query tile): the
+ * fast forward anchors the softmax once per query and FLAGS a workgroup whose row sums overflowed; the per-tile-maximum kernel
+ * launched right behind it recomputes exactly the flagged ones.  Without scratch only the per-tile-maximum kernel runs.
+ * svol_attn_ws_bytes() returns the largest of these needs for the shape.  Nothing is allocated inside the library.
  * Replaces the core of nn.MultiheadAttention (cross_modal_transformer.py:139,147,154). */
 int64_t svol_attn_ws_bytes(int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t dh);
 int svol_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
