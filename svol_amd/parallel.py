@@ -55,7 +55,8 @@ class BucketedGradAllReduce:
     re-ordered by ``reversed`` as a fallback guess when ``ordered=False``)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 16 << 20,
-                 skip: Optional[Iterable[torch.nn.Parameter]] = None, process_group=None, ordered: bool = False):
+                 skip: Optional[Iterable[torch.nn.Parameter]] = None, process_group=None, ordered: bool = False,
+                 tail_bytes: int = 2 << 20):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         skip_ids = {id(p) for p in (skip or [])}
@@ -66,16 +67,28 @@ class BucketedGradAllReduce:
         self.on_gpu = self.device.type == 'cuda'
         order = plist if ordered else list(reversed(plist))
         self.buckets: List[dict] = []
-        cur, cur_bytes = [], 0
+        groups, cur, cur_bytes = [], [], 0
         for p in order:
             nbytes = p.numel() * 4
             if cur and cur_bytes + nbytes > bucket_bytes:
-                self._make_bucket(cur)
+                groups.append(cur)
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nbytes
         if cur:
-            self._make_bucket(cur)
+            groups.append(cur)
+        # The LAST bucket's all-reduce cannot overlap with anything: its last gradient is the last thing backward produces.
+        # Keep that exposed exchange small: the final `tail_bytes` of the arrival order (the input projections, the query
+        # embedding, the end of layer 0) get a bucket of their own, the rest of the old last bucket reduces under layer 0's backward.
+        if tail_bytes and groups:
+            last, tail, tb = groups[-1], [], 0
+            while len(last) > 1 and tb + last[-1].numel() * 4 <= tail_bytes:
+                tb += last[-1].numel() * 4
+                tail.insert(0, last.pop())
+            if tail:
+                groups.append(tail)
+        for g in groups:
+            self._make_bucket(g)
         self._handles = []
         self._hooks = []
         self.fire_order: List[int] = []   # diagnostics: bucket index of every hook of the current step, in firing order
