@@ -9,7 +9,7 @@ constexpr int LN_MAX_PASSES = 4;  // D <= 4 * 64 * 4 = 1024
 
 // T  = element type of the compute-dtype outputs / gradients, TX = element type of the LN input
 // (float when the input is the fp32 residual stream).
-template <typename T, typename TX>
+template <typename T, typename TX, int NP>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ y32,
                                                      T* __restrict__ y, T* __restrict__ ypos, const T* __restrict__ pos,
@@ -21,24 +21,37 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const TX* xr = x + row * D;
-    float v[LN_MAX_PASSES][4];
+    float v[NP][4];
     float s = 0.f;
+    // every global load of the wave's one row goes out before the first reduction: one memory latency per wave, not two
+    // (x, then pos / gamma / beta behind the statistics: 39 us per [50176, 256] launch; NP = passes of 256 columns)
+    const T* pr = pos ? pos + (row % pos_rows) * D : nullptr;
+    Vec4<TX> t[NP];
+    Vec4<T> pv[NP];
+    Vec4<float> gv[NP], bv[NP];
 #pragma unroll
-    for (int j = 0; j < LN_MAX_PASSES; ++j) {
+    for (int j = 0; j < NP; ++j) {
         const int c = (lane + 64 * j) * 4;
         if (c < D) {
-            Vec4<TX> t; t.load(xr + c);
+            t[j].load(xr + c);
+            if (pr) pv[j].load(pr + c);
+            gv[j].load(gamma + c);
+            bv[j].load(beta + c);
+        }
+    }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[j][e] = t.get(e); s += v[j][e]; }
-        } else {
+    for (int j = 0; j < NP; ++j) {
+        const int c = (lane + 64 * j) * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[j][e] = 0.f;
+        for (int e = 0; e < 4; ++e) {
+            v[j][e] = c < D ? t[j].get(e) : 0.f;
+            s += v[j][e];
         }
     }
     const float mu = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAX_PASSES; ++j) {
+    for (int j = 0; j < NP; ++j) {
         const int c = (lane + 64 * j) * 4;
         if (c < D) {
 #pragma unroll
@@ -47,21 +60,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
     }
     const float rs = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-    const T* pr = pos ? pos + (row % pos_rows) * D : nullptr;
 #pragma unroll
-    for (int j = 0; j < LN_MAX_PASSES; ++j) {
+    for (int j = 0; j < NP; ++j) {
         const int c = (lane + 64 * j) * 4;
         if (c < D) {
-            Vec4<T> o, op, pv;
+            Vec4<T> o, op;
             Vec4<float> o32;
-            if (pr) pv.load(pr + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float r = (v[j][e] - mu) * rs * gamma[c + e] + beta[c + e];
+                float r = (v[j][e] - mu) * rs * gv[j].get(e) + bv[j].get(e);
                 if (p > 0.f) r *= dropout_scale(seed, (uint64_t)(row * D + c + e), p, inv_keep);
                 o.set(e, r);
                 o32.set(e, r);
-                if (pr) op.set(e, r + pv.get(e));
+                if (pr) op.set(e, r + pv[j].get(e));
             }
             if (y32) o32.store(y32 + row * D + c);
             if (y) o.store(y + row * D + c);
@@ -241,15 +252,20 @@ int svol_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float
     const float inv_keep = 1.f / (1.f - dropout_p);
     const unsigned grid = (unsigned)((M + 3) / 4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == SVOL_BF16 && x_f32)
-        hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, (const float*)x, gamma, beta, y32,
-                           (bf16_t*)y, (bf16_t*)ypos, (const bf16_t*)pos, pos_rows, mean, rstd, M, (int)D, dropout_p, inv_keep, seed, seed_offset_dev);
-    else if (dtype == SVOL_BF16)
-        hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, y32,
-                           (bf16_t*)y, (bf16_t*)ypos, (const bf16_t*)pos, pos_rows, mean, rstd, M, (int)D, dropout_p, inv_keep, seed, seed_offset_dev);
-    else
-        hipLaunchKernelGGL((ln_fwd_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)x, gamma, beta, y32,
-                           (float*)y, (float*)ypos, (const float*)pos, pos_rows, mean, rstd, M, (int)D, dropout_p, inv_keep, seed, seed_offset_dev);
+#define SVOL_LNF(TT, TXX, NPP)                                                                                              \
+    hipLaunchKernelGGL((ln_fwd_kernel<TT, TXX, NPP>), dim3(grid), dim3(256), 0, s, (const TXX*)x, gamma, beta, y32, (TT*)y,      \
+                       (TT*)ypos, (const TT*)pos, pos_rows, mean, rstd, M, (int)D, dropout_p, inv_keep, seed, seed_offset_dev)
+#define SVOL_LNF_NP(TT, TXX)                     \
+    do {                                         \
+        if (D <= 256) SVOL_LNF(TT, TXX, 1);      \
+        else if (D <= 512) SVOL_LNF(TT, TXX, 2); \
+        else SVOL_LNF(TT, TXX, 4);               \
+    } while (0)
+    if (dtype == SVOL_BF16 && x_f32) SVOL_LNF_NP(bf16_t, float);
+    else if (dtype == SVOL_BF16) SVOL_LNF_NP(bf16_t, bf16_t);
+    else SVOL_LNF_NP(float, float);
+#undef SVOL_LNF_NP
+#undef SVOL_LNF
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }
