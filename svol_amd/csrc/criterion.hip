@@ -145,12 +145,50 @@ __device__ __forceinline__ double readlane_f64(double x, int l) {
     const unsigned lo = __builtin_amdgcn_readlane((unsigned)b, l), hi = __builtin_amdgcn_readlane((unsigned)(b >> 32), l);
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
+// wave-wide min / max of a 32-bit key, result uniform (SGPR): DPP quad / row permutations, then row_bcast15 / row_bcast31
+// gather the four 16-lane rows into lane 63.  With the folded DPP operand each stage is one v_min_u32 / v_max_u32.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u32(unsigned x) {
+    if constexpr (ROW_MASK == 0xf) return (unsigned)__builtin_amdgcn_mov_dpp((int)x, CTRL, 0xf, 0xf, true);  // folds into the consumer
+    else return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, ROW_MASK, 0xf, false);         // masked rows keep x
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned x) {
+    x = min(x, dpp_u32<0xB1, 0xf>(x));
+    x = min(x, dpp_u32<0x4E, 0xf>(x));
+    x = min(x, dpp_u32<0x141, 0xf>(x));
+    x = min(x, dpp_u32<0x140, 0xf>(x));
+    x = min(x, dpp_u32<0x142, 0xa>(x));   // row_bcast15 into rows 1 and 3
+    x = min(x, dpp_u32<0x143, 0xc>(x));   // row_bcast31 into rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
+    x = max(x, dpp_u32<0xB1, 0xf>(x));
+    x = max(x, dpp_u32<0x4E, 0xf>(x));
+    x = max(x, dpp_u32<0x141, 0xf>(x));
+    x = max(x, dpp_u32<0x140, 0xf>(x));
+    x = max(x, dpp_u32<0x142, 0xa>(x));
+    x = max(x, dpp_u32<0x143, 0xc>(x));
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+// order-preserving map double -> uint64 (x < y  <=>  mono(x) < mono(y); -0.0 is folded onto +0.0 first so that equal doubles
+// map to equal keys): the arg-min below compares integers, 32 bits at a time
+__device__ __forceinline__ unsigned long long mono_f64(double x) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x + 0.0);
+    const unsigned long long m = (unsigned long long)((long long)b >> 63);
+    return b ^ (m | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double unmono_f64(unsigned long long k) {
+    const unsigned long long m = (k >> 63) ? 0x8000000000000000ull : ~0ull;
+    return __builtin_bit_cast(double, k ^ m);
+}
 __device__ __forceinline__ bool lsap_reg(const float* __restrict__ Cs, int nr, int nc, int lane, int (&col4row_out)) {
     const int j0 = lane, j1 = lane + 64;
     const bool ok0 = j0 < nc, ok1 = j1 < nc;
+    const int j0c = ok0 ? j0 : 0, j1c = ok1 ? j1 : 0;  // clamped cost-row offsets (the value is discarded for a missing column)
     double v0 = 0.0, v1 = 0.0, spc0 = INFINITY, spc1 = INFINITY, u = 0.0;
     int path0 = -1, path1 = -1, r4c0 = -1, r4c1 = -1, pos0 = -1, pos1 = -1, c4r = -1;
     bool sc0 = false, sc1 = false, sr = false;
+    const unsigned long long K_INF = 0xFFF0000000000000ull;  // mono_f64(+inf)
     for (int cur = 0; cur < nr; ++cur) {
         pos0 = ok0 ? nc - 1 - j0 : -1;  // remaining[it] = nc - it - 1
         pos1 = ok1 ? nc - 1 - j1 : -1;
@@ -159,41 +197,55 @@ __device__ __forceinline__ bool lsap_reg(const float* __restrict__ Cs, int nr, i
         int num_remaining = nc, i = cur, sink = -1;
         double min_val = 0.0;
         while (sink == -1) {
-            if (lane == i) sr = true;
+            sr = sr || lane == i;
             const double ui = readlane_f64(u, i);
-            MinKey mk;
-            mk.s = INFINITY;
-            mk.key = (int)0x80000000;
-            if (pos0 >= 0) {
-                const double r = min_val + (double)Cs[i * nc + j0] - ui - v0;
-                if (r < spc0) { path0 = i; spc0 = r; }
-                mk.s = spc0;
-                mk.key = r4c0 == -1 ? 0x40000000 + pos0 : 0x3fffffff - pos0;
+            const float* crow = Cs + i * nc;
+            const double r0 = min_val + (double)crow[j0c] - ui - v0;
+            const double r1 = min_val + (double)crow[j1c] - ui - v1;
+            const bool a0 = pos0 >= 0, a1 = pos1 >= 0;
+            const bool up0 = a0 && r0 < spc0, up1 = a1 && r1 < spc1;
+            spc0 = up0 ? r0 : spc0;
+            path0 = up0 ? i : path0;
+            spc1 = up1 ? r1 : spc1;
+            path1 = up1 ? i : path1;
+            // (cost, preference) of the lane's two columns.  scipy's rule over the remaining columns: lowest cost; among equal costs the
+            // LAST unassigned column visited, else the FIRST column visited -> preference = [unassigned][pos | 127 - pos], larger wins;
+            // slot and lane ride in the low bits (positions are unique, they never decide)
+            const unsigned long long k0 = a0 ? mono_f64(spc0) : ~0ull, k1 = a1 ? mono_f64(spc1) : ~0ull;
+            const unsigned t0 = a0 ? (0x100000u | ((r4c0 == -1 ? 0x80u | (unsigned)pos0 : 127u - (unsigned)pos0) << 8) | (unsigned)lane) : 0u;
+            const unsigned t1 = a1 ? (0x100000u | ((r4c1 == -1 ? 0x80u | (unsigned)pos1 : 127u - (unsigned)pos1) << 8) | 0x40u | (unsigned)lane) : 0u;
+            const bool second = k1 < k0 || (k1 == k0 && t1 > t0);
+            const unsigned long long k = second ? k1 : k0;
+            const unsigned t = second ? t1 : t0;
+            const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+            const unsigned mh = wave_min_u32(hi);
+            // usually ONE lane holds the smallest upper word (sign, exponent, 20 mantissa bits): it is the arg-min, whatever the rest says
+            const unsigned long long cand = __ballot(hi == mh);
+            unsigned ml, mt;
+            if ((cand & (cand - 1)) == 0) {
+                const int w = __builtin_ctzll(cand);
+                ml = (unsigned)__builtin_amdgcn_readlane((int)lo, w);
+                mt = (unsigned)__builtin_amdgcn_readlane((int)t, w);
+            } else {
+                ml = wave_min_u32(hi == mh ? lo : 0xffffffffu);
+                mt = wave_max_u32((hi == mh && lo == ml) ? t : 0u);
             }
-            if (pos1 >= 0) {
-                const double r = min_val + (double)Cs[i * nc + j1] - ui - v1;
-                if (r < spc1) { path1 = i; spc1 = r; }
-                MinKey m1;
-                m1.s = spc1;
-                m1.key = r4c1 == -1 ? 0x40000000 + pos1 : 0x3fffffff - pos1;
-                mk = better(mk, m1);
-            }
-            mk = wave_argmin(mk);
-            if (mk.s == INFINITY) return false;  // infeasible
-            min_val = mk.s;
-            const int index = mk.key >= 0x40000000 ? mk.key - 0x40000000 : 0x3fffffff - mk.key;
-            const unsigned long long m0 = __ballot(pos0 == index), m1b = __ballot(pos1 == index);
-            const int slot = m0 ? 0 : 1;
-            const int lj = __builtin_amdgcn_readfirstlane(m0 ? __builtin_ctzll(m0) : __builtin_ctzll(m1b));
+            const unsigned long long kmin = ((unsigned long long)mh << 32) | ml;
+            if (kmin >= K_INF) return false;  // infeasible: the cheapest remaining column costs +inf
+            min_val = unmono_f64(kmin);
+            const unsigned pf = (mt >> 8) & 0xffu;
+            const int index = (pf & 0x80u) ? (int)(pf & 0x7fu) : 127 - (int)pf;
+            const int lj = (int)(mt & 0x3fu), slot = (int)((mt >> 6) & 1u);
             const int j = lj + 64 * slot;
-            const int r4 = slot ? __builtin_amdgcn_readlane(r4c1, lj) : __builtin_amdgcn_readlane(r4c0, lj);
+            const int r4 = __builtin_amdgcn_readlane(slot ? r4c1 : r4c0, lj);
             if (r4 == -1) sink = j; else i = r4;
             const int last = num_remaining - 1;
             // SC[j] = true; remaining[index] = remaining[last]; --num_remaining
-            if (lane == lj) { if (slot) sc1 = true; else sc0 = true; }
-            const bool rm0 = lane == lj && slot == 0, rm1 = lane == lj && slot == 1;
-            if (rm0) pos0 = -1; else if (pos0 == last) pos0 = index;
-            if (rm1) pos1 = -1; else if (pos1 == last) pos1 = index;
+            const bool me0 = lane == lj && slot == 0, me1 = lane == lj && slot == 1;
+            sc0 = sc0 || me0;
+            sc1 = sc1 || me1;
+            pos0 = me0 ? -1 : (pos0 == last ? index : pos0);
+            pos1 = me1 ? -1 : (pos1 == last ? index : pos1);
             num_remaining = last;
         }
         // dual update
