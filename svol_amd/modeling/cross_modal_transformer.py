@@ -158,13 +158,22 @@ class CrossModalTransformerLayer(nn.Module):
 
     def query_half(self, out, m, mpos, qpos, kbias):
         """the "decoder-like" half, :145-158: object queries attend to themselves, then to the video tokens."""
-        h = self.nhead
+        return self.query_cross(self.query_self(out, qpos), m, mpos, qpos, kbias)
+
+    def query_self(self, out, qpos):
+        """:145-147: query self-attention + norm4 — needs only the previous layer's queries, not this layer's video tokens."""
+        n = lambda m_: (m_.weight, m_.bias)
+        mha = lambda m_: (m_.in_proj_weight, m_.in_proj_bias, m_.out_proj.weight, m_.out_proj.bias)
+        o32, o, opos = out
+        return ops.self_attn_ln(o32, o, opos, *mha(self.token_self_attn), *n(self.norm4), qpos, self.nhead)
+
+    def query_cross(self, out, m, mpos, qpos, kbias):
+        """:149-158: query -> video cross-attention + norm5, MLP2 + norm6."""
         n = lambda m_: (m_.weight, m_.bias)
         mha = lambda m_: (m_.in_proj_weight, m_.in_proj_bias, m_.out_proj.weight, m_.out_proj.bias)
         mlp = lambda m_: (m_.fc1.weight, m_.fc1.bias, m_.fc2.weight, m_.fc2.bias)
         o32, o, opos = out
-        o32, o, opos = ops.self_attn_ln(o32, o, opos, *mha(self.token_self_attn), *n(self.norm4), qpos, h)
-        o32, o = ops.cross_attn_ln(o32, o, opos, mpos, m, *mha(self.content_token_cross_attn), *n(self.norm5), None, h,
+        o32, o = ops.cross_attn_ln(o32, o, opos, mpos, m, *mha(self.content_token_cross_attn), *n(self.norm5), None, self.nhead,
                                    kbias)
         return ops.mlp_ln(o32, o, *mlp(self.mlp2), *n(self.norm6), qpos)
 
@@ -187,12 +196,14 @@ class CrossModalTransformer(nn.Module):
         dt = torch.float32 if QUERY_FP32 else vid_pos.dtype   # element type of the QUERY stream's GEMM operands
         qpos = ops.cast_ag(query_embed, dt)
         N, d = qpos.shape
-        out = (torch.zeros((B, N, d), dtype=torch.float32, device=vid_pos.device),  # reference :56
-               torch.zeros((B, N, d), dtype=dt, device=vid_pos.device),
-               qpos.unsqueeze(0).expand(B, -1, -1).contiguous())
+        def initial_queries():  # reference :56: tgt = zeros; (fp32 stream, compute copy, copy + query_pos)
+            return (torch.zeros((B, N, d), dtype=torch.float32, device=vid_pos.device),
+                    torch.zeros((B, N, d), dtype=dt, device=vid_pos.device),
+                    qpos.unsqueeze(0).expand(B, -1, -1).contiguous())
         mem32 = src_vid32
         outputs = []
         if not OVERLAP_QUERY_STREAM:
+            out = initial_queries()
             for layer in self.layers:
                 mem32, out = layer(mem32, src_skch32, out, vid_pos, qpos, kbias)
                 outputs.append(out[0])
@@ -208,17 +219,25 @@ class CrossModalTransformer(nn.Module):
         qpos.record_stream(side)
         kbias.record_stream(side)
         with torch.cuda.stream(side):
-            # the query state lives on the side stream from the start: a tensor allocated on the main stream and
-            # dropped by the host while a side-stream kernel still has it queued (the fp32 zeros are only a GEMM
-            # residual, nothing keeps them alive) would be handed to the next main-stream allocation
-            out = tuple(t.clone() for t in out)
+            # The query state is ALLOCATED on the side stream.  A tensor allocated on the main stream and dropped by the host
+            # while a side-stream kernel still has it queued (the fp32 zeros are only a GEMM residual, nothing keeps them
+            # alive) goes back to the main stream's pool and is handed to the next main-stream allocation: round 1 cloned
+            # main-stream zeros here, which only moved the problem to the clone's SOURCE — dropped right after the clone was
+            # queued, overwritten by the video half before a lagging side stream had read it (a 1-in-15 garbage forward in
+            # the test suite, in streaks; never seen in the bench, where the side stream does not lag at that point)
+            out = initial_queries()
         for layer in self.layers:
+            # the query self-attention of layer i needs only layer i-1's queries: it goes out before this layer's video half is
+            # issued and runs under it; only the cross-attention waits for the video tokens (the last layer's tail is shorter
+            # by that block)
+            with torch.cuda.stream(side):
+                out_sa = layer.query_self(out, qpos)
             m32, m, mpos = layer.video_half(mem32, src_skch32, vid_pos)
             side.wait_stream(main)
             m.record_stream(side)
             mpos.record_stream(side)
             with torch.cuda.stream(side):
-                out = layer.query_half(out, m, mpos, qpos, kbias)
+                out = layer.query_cross(out_sa, m, mpos, qpos, kbias)
                 outputs.append(out[0])
             mem32 = m32
         main.wait_stream(side)

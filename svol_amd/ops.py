@@ -440,8 +440,24 @@ class _WeightCache:
             blob = b''.join(struct.pack('<QQQiiii', *rec) for rec in recs)
             st['table'] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
             st['tiles'] = t0
+            st['gen'] = st.get('gen', 0) + 1
         _lib.check(_lib.lib().svol_cast_transpose_multi(_ptr(st['table']), len(st['items']), st['tiles'], _DT[dtype],
                                                         _stream()), 'svol_cast_transpose_multi')
+        # The copies were allocated on the stream of their first use (the query half's weights: the side stream) and are
+        # rewritten HERE, on the caller's stream.  Tell the allocator, or a copy whose owner dies (a model dropped between two
+        # tests, a re-built module) goes back to its own stream's pool while this launch is still queued and the refresh lands
+        # in whoever got the block next (seen as a 1-in-15 garbage forward in the test suite, never with one long-lived model)
+        if dev.type == 'cuda':
+            cur = _current_stream_obj()
+            done = st.setdefault('recorded', set())
+            key_ = (cur.cuda_stream, st.get('gen', 0))
+            if key_ not in done:
+                done.clear()
+                done.add(key_)
+                for r, e in st['items']:
+                    if e.wc is not None and e.wc.dtype != torch.float32:
+                        e.wc.record_stream(cur)
+                    e.wt.record_stream(cur)
         for r, e in st['items']:
             e.epoch = self.epoch
             e.version = r()._version

@@ -66,3 +66,33 @@ def test_model_level_mask_expansion_matches_the_head_golden(name, dtype):
                  src_sketch_mask=inp['src_sketch_mask'].cuda(), src_video_mask=torch.ones(B, T).cuda())
     assert float((out2['pred_logits'] - out['pred_logits'])[1::2].abs().max()) > 1e-4
     assert float((out2['pred_logits'] - out['pred_logits'])[0::2].abs().max()) <= (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize('lag', ['side', 'main'])
+def test_forward_does_not_depend_on_which_stream_lags(lag):
+    """The object-query half runs on a side stream.  Stall one of the two streams in front of the forward (a spin kernel) so
+    that the other runs far ahead of it: the outputs must be bit-identical to an undisturbed forward.  (Regression: the
+    initial query state was cloned on the side stream from main-stream zeros that the host dropped right away; with the side
+    stream lagging, the video half reused and overwrote that memory before the clone had read it — garbage logits in about
+    one run of the suite in fifteen.)"""
+    from svol_amd.modeling import cross_modal_transformer as cmt
+    from svol_amd.modeling.svanet import build_svanet
+    from tests.helpers import head_case
+    z, meta, args, sd, inp, tg = head_case('cfg1_video')
+    args.compute_dtype = 'bf16'
+    dev = torch.device('cuda', 0)
+    model = build_svanet(args)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    x = [inp[k].to(dev) for k in ('src_sketch', 'src_sketch_mask', 'src_video', 'src_video_mask')]
+    with torch.no_grad():
+        ref = model(*x)
+        torch.cuda.synchronize()
+        side = cmt._side_stream(dev)
+        for _ in range(3):
+            stalled = side if lag == 'side' else torch.cuda.current_stream()
+            with torch.cuda.stream(stalled):
+                torch.cuda._sleep(200_000_000)   # ~0.1 s: the other stream gets through the whole forward meanwhile
+            out = model(*x)
+            torch.cuda.synchronize()
+            assert torch.equal(out['pred_logits'], ref['pred_logits']) and torch.equal(out['pred_boxes'], ref['pred_boxes'])
