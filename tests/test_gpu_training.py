@@ -57,3 +57,63 @@ def test_training_loop_learns_and_optimiser_variants_agree():
     # flipped Hungarian assignments (after tens of steps two runs of even the SAME variant drift apart by 10-20 %)
     for k in range(8):
         assert abs(a[k] - b[k]) <= 0.03 * abs(b[k]), (k, a[k], b[k])
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_training_step_does_not_depend_on_stream_timing(dtype):
+    """A whole step (zero_grad, forward, criterion, backward into gradient sinks, reducer.finish) uses three streams: the caller's, the
+    object-query side stream and the weight-gradient stream.  Stall each of them in turn (a spin kernel) in front of the forward and in
+    front of the backward, so that the others run far ahead of it: losses identical, every gradient equal to the undisturbed step's
+    up to the order of its fp32 atomics.  A missing cross-stream dependency or a tensor recycled under a queued kernel shows up as a
+    gross difference."""
+    from svol_amd import ops, parallel
+    from svol_amd.modeling import cross_modal_transformer as cmt
+    from svol_amd.modeling.loss import build_loss
+    from svol_amd.modeling.svanet import build_svanet
+    from tests.helpers import head_case
+    z, meta, args, sd, inp, tg = head_case('mid32_video')
+    args.compute_dtype = dtype
+    args.input_dropout = 0.0           # no dropout (every step draws a fresh mask): the comparison is between runs
+    dev = torch.device('cuda', 0)
+    model = build_svanet(args)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).train()
+    crit = build_loss(args).to(dev).train()
+    red = parallel.BucketedGradAllReduce(parallel.arrival_order(model), bucket_bytes=1 << 20, skip=parallel.unused_parameters(model),
+                                         ordered=True)
+    x = [inp[k].to(dev) for k in ('src_sketch', 'src_sketch_mask', 'src_video', 'src_video_mask')]
+
+    def stall(which):
+        if which is None:
+            return
+        streams = {'main': torch.cuda.current_stream(), 'side': cmt._side_stream(dev)}
+        ws = ops.wgrad_streams(dev)
+        if ws:
+            streams['wgrad'] = ws[0]
+        if which in streams:
+            with torch.cuda.stream(streams[which]):
+                torch.cuda._sleep(100_000_000)
+
+    def step(before_fwd=None, before_bwd=None):
+        red.zero_grad()
+        stall(before_fwd)
+        out = model(*x)
+        ld = crit(out, tg)
+        loss = crit.weighted_total()
+        stall(before_bwd)
+        loss.backward()
+        red.finish()
+        torch.cuda.synchronize()
+        return float(loss), torch.cat([b['flat'].clone() for b in red.buckets])
+
+    step()                             # first-use casts, stream creation
+    l0, g0 = step()
+    gn = float(g0.norm())
+    assert gn > 0
+    tol = 1e-5 if dtype == 'fp32' else 2e-3
+    for which in ('main', 'side', 'wgrad'):
+        for where in ('fwd', 'bwd'):
+            l1, g1 = step(before_fwd=which if where == 'fwd' else None, before_bwd=which if where == 'bwd' else None)
+            assert l1 == l0, (which, where, l0, l1)
+            err = float((g1 - g0).norm()) / gn
+            assert err <= tol, (which, where, err)
