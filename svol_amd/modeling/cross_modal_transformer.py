@@ -137,22 +137,19 @@ class CrossModalTransformerLayer(nn.Module):
         m = self.sketch_video_cross_attn
         return _GateVectorsFn.apply(skch, m.in_proj_weight, m.in_proj_bias, self.nhead)
 
-    def forward(self, mem32, skch32, out, pos, qpos, kbias):
-        """mem32: fp32 video stream [B,L,d]; out = (out32, out, out + query_pos) query stream triple."""
-        h = self.nhead
-        n = lambda m: (m.weight, m.bias)
-        mha = lambda m: (m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias)
-        mlp = lambda m: (m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
-        m32, m, mpos = self.video_half(mem32, skch32, pos)
+    def forward(self, mem32, skch32, out, pos, qpos, kbias, u=None):
+        """mem32: fp32 video stream [B,L,d]; out = (out32, out, out + query_pos) query stream triple; u: this layer's gate
+        vectors when the caller computed them ahead of the layer loop."""
+        m32, m, mpos = self.video_half(mem32, skch32, pos, u)
         return m32, self.query_half(out, m, mpos, qpos, kbias)
 
-    def video_half(self, mem32, skch32, pos):
+    def video_half(self, mem32, skch32, pos, u=None):
         """the "encoder-like" half, :122-143 -> (fp32 stream, compute-dtype copy, copy + pos)."""
         h = self.nhead
         n = lambda m: (m.weight, m.bias)
         mha = lambda m: (m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias)
         mlp = lambda m: (m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
-        m32, m, mpos = ops.gate(mem32, pos, self.gate_vectors(skch32), *n(self.norm1), h)
+        m32, m, mpos = ops.gate(mem32, pos, self.gate_vectors(skch32) if u is None else u, *n(self.norm1), h)
         m32, m = ops.self_attn_ln(m32, m, mpos, *mha(self.content_self_attn), *n(self.norm2), None, h)
         return ops.mlp_ln(m32, m, *mlp(self.mlp1), *n(self.norm3), pos)
 
@@ -202,10 +199,16 @@ class CrossModalTransformer(nn.Module):
                     qpos.unsqueeze(0).expand(B, -1, -1).contiguous())
         mem32 = src_vid32
         outputs = []
+        # The gate vectors of every layer depend only on the sketch token and the layer's weights (B*d-sized algebra): all of them
+        # are computed HERE, before the first big kernel is queued, instead of one tiny launch in front of each layer's gate where it
+        # waits for a CU beside the other streams' kernels (15 us each).  Their autograd nodes get the lowest sequence numbers of the
+        # transformer, so the engine runs their backward (two tiny launches per layer, 65 us each in the middle of the backward)
+        # after everything else: 6 x 14 us at the end.  (svol_amd.parallel.arrival_order puts these parameters last accordingly.)
+        us = [layer.gate_vectors(src_skch32) for layer in self.layers]
         if not OVERLAP_QUERY_STREAM:
             out = initial_queries()
-            for layer in self.layers:
-                mem32, out = layer(mem32, src_skch32, out, vid_pos, qpos, kbias)
+            for layer, u in zip(self.layers, us):
+                mem32, out = layer(mem32, src_skch32, out, vid_pos, qpos, kbias, u)
                 outputs.append(out[0])
             return torch.stack(outputs)
         # The query half of layer i (N = 100 object queries: skinny GEMMs, 64-512 workgroup attention launches, small
@@ -226,13 +229,13 @@ class CrossModalTransformer(nn.Module):
             # queued, overwritten by the video half before a lagging side stream had read it (a 1-in-15 garbage forward in
             # the test suite, in streaks; never seen in the bench, where the side stream does not lag at that point)
             out = initial_queries()
-        for layer in self.layers:
+        for layer, u in zip(self.layers, us):
             # the query self-attention of layer i needs only layer i-1's queries: it goes out before this layer's video half is
             # issued and runs under it; only the cross-attention waits for the video tokens (the last layer's tail is shorter
             # by that block)
             with torch.cuda.stream(side):
                 out_sa = layer.query_self(out, qpos)
-            m32, m, mpos = layer.video_half(mem32, src_skch32, vid_pos)
+            m32, m, mpos = layer.video_half(mem32, src_skch32, vid_pos, u)
             side.wait_stream(main)
             m.record_stream(side)
             mpos.record_stream(side)

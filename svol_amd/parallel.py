@@ -29,6 +29,8 @@ import torch
 import torch.distributed as dist
 
 _LATE = ('query_embed', 'input_', 'backbone', 'pos_embed', 'position_embedding')   # first used in forward = last in backward
+_GATE = ('sketch_video_cross_attn',)   # the gate-vector algebra of every layer runs ahead of the layer loop (cross_modal_transformer.py):
+                                       # its backward is the last thing the transformer does, just before the input projections'
 _EARLY = ('bbox_embed', 'class_embed')                                            # the heads: last in forward
 
 
@@ -44,6 +46,8 @@ def arrival_order(model: torch.nn.Module) -> List[torch.nn.Parameter]:
         if any(t in name for t in _EARLY):
             return 0
         if any(t in name for t in _LATE):
+            return 3
+        if any(t in name for t in _GATE):
             return 2
         return 1
     idx = sorted(range(len(named)), key=lambda i: (rank(named[i][0]), -i))

@@ -129,10 +129,17 @@ def test_arrival_order_puts_heads_first_and_input_projections_last():
     k_last_layer = max(i for i, n in enumerate(order) if 'transformer.layers.' in n)
     k_late = min(i for i, n in enumerate(order) if 'query_embed' in n or 'input_' in n)
     assert k_heads < k_first_layer and k_last_layer < k_late
-    layer_of = [int(n.split('transformer.layers.')[1].split('.')[0]) for n in order if 'transformer.layers.' in n]
+    gate = [i for i, n in enumerate(order) if 'sketch_video_cross_attn' in n]
+    body = [n for n in order if 'transformer.layers.' in n and 'sketch_video_cross_attn' not in n]
+    layer_of = [int(n.split('transformer.layers.')[1].split('.')[0]) for n in body]
     assert layer_of == sorted(layer_of, reverse=True)            # last layer first
-    l2 = [n for n in order if 'transformer.layers.2.' in n]
-    assert 'norm6' in l2[0] and 'sketch_video_cross_attn' in l2[-1]  # inside a layer: last sub-block first
+    l2 = [n for n in body if 'transformer.layers.2.' in n]
+    assert 'norm6' in l2[0] and 'norm1' in l2[-1]                # inside a layer: last sub-block first
+    # the gate-vector algebra of all layers runs ahead of the layer loop, so its gradients come after every layer's (last layer
+    # first) and before the input projections'
+    assert min(gate) > max(i for i, n in enumerate(order) if n in body) and max(gate) < k_late
+    gl = [int(order[i].split('transformer.layers.')[1].split('.')[0]) for i in gate]
+    assert gl == sorted(gl, reverse=True)
     # the reducer keeps that order when told so
     red = parallel.BucketedGradAllReduce(parallel.arrival_order(model), bucket_bytes=16 << 10,
                                          skip=parallel.unused_parameters(model), ordered=True)
