@@ -19,7 +19,7 @@ reducer = parallel.BucketedGradAllReduce(parallel.arrival_order(model), skip=par
 opt = parallel.FlatAdamW(reducer, lr=1e-4, weight_decay=1e-4, params=params)
 inp = {k: v.to(dev) for k, v in syn.synth_inputs(args, B, T, P, seed=1).items()}
 tg = syn.synth_targets(B, T, seed=1)
-names = ['zero_grad+prepack', 'forward', 'criterion+total', 'backward+finish', 'optimizer']
+names = ['zero_grad+prepack', 'forward', 'criterion+total', 'backward (main stream)', 'finish (side + wgrad tails)', 'optimizer']
 def step(ev=None):
     def mark(i):
         if ev is not None:
@@ -34,25 +34,26 @@ def step(ev=None):
     loss = crit.weighted_total()
     mark(3)
     loss.backward()
-    reducer.finish()
     mark(4)
-    opt.step()
+    reducer.finish()
     mark(5)
+    opt.step()
+    mark(6)
 for _ in range(5): step()
 torch.cuda.synchronize()
 N = 12
 for sync_each in (True, False):
-    acc = [0.0] * 5
+    acc = [0.0] * 6
     evs = []
     for _ in range(N):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
         step(ev)
         if sync_each:
             torch.cuda.synchronize()
         evs.append(ev)
     torch.cuda.synchronize()
     for ev in evs[2:]:   # the first steps of the free-running loop still start level with the GPU
-        for i in range(5):
+        for i in range(6):
             acc[i] += ev[i].elapsed_time(ev[i + 1])
     n = len(evs) - 2
     print('== host synchronised with the GPU after every step' if sync_each else '== free-running (the host runs ahead, as in bench.py)')
