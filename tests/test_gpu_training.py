@@ -117,3 +117,23 @@ def test_training_step_does_not_depend_on_stream_timing(dtype):
             assert l1 == l0, (which, where, l0, l1)
             err = float((g1 - g0).norm()) / gn
             assert err <= tol, (which, where, err)
+    # the same in the MIDDLE of the passes: a stall in front of one layer's video half (forward) and at the moment that layer's
+    # video-token gradient arrives (backward)
+    layers = model.transformer.layers
+    mid = len(layers) // 2
+    orig = type(layers[mid]).video_half
+    for which in ('main', 'side', 'wgrad'):
+        def patched(self, mem32, skch32, pos, u=None, _which=which):
+            if self is layers[mid]:
+                stall(_which)
+                if mem32.requires_grad:
+                    mem32.register_hook(lambda g, w=_which: (stall(w), g)[1])
+            return orig(self, mem32, skch32, pos, u)
+        type(layers[mid]).video_half = patched
+        try:
+            l1, g1 = step()
+        finally:
+            type(layers[mid]).video_half = orig
+        assert l1 == l0, (which, 'mid', l0, l1)
+        err = float((g1 - g0).norm()) / gn
+        assert err <= tol, (which, 'mid', err)
