@@ -185,16 +185,51 @@ def wgrad_streams(dev):
     return [s] if s is not None else []
 
 
+# Deferral: the weight-gradient GEMMs are HBM / atomic bound.  Run the moment they are issued they share the memory system with
+# the LayerNorm / gate / projection kernels of the dX chain (LayerNorm backward 46 -> 70 us, gate backward 102 -> 167 us per layer in
+# the step); run beside the video attention backward — instruction-issue bound, 1.3 ms per layer — they are nearly free.  So a
+# gradient-sink TN GEMM is only QUEUED here (with an event that says "its operands exist") and the queue is flushed onto the
+# weight-gradient stream right before the next large attention backward is launched, before a bucket's all-reduce, and in
+# BucketedGradAllReduce.finish().  The autograd engine runs every backward node of a device on one thread, so the queue needs no lock.
+WGRAD_DEFER = os.environ.get('SVOL_NO_WGRAD_DEFER') is None
+_WGRAD_PENDING = []
+_WGRAD_FLUSH_MIN_SCORES = 1 << 27   # B*H*Lq*Lk of an attention backward worth hiding weight gradients under (cfg2: 2.5e9)
+
+
+def _wgrad_stream(dev):
+    ws = _WGRAD.get(dev)
+    if ws is None:
+        ws = _WGRAD[dev] = torch.cuda.Stream(device=dev)
+    return ws
+
+
+def flush_wgrad():
+    """issue every queued weight-gradient GEMM on the weight-gradient stream (behind the event recorded when it was queued)."""
+    if not _WGRAD_PENDING:
+        return
+    items = list(_WGRAD_PENDING)
+    _WGRAD_PENDING.clear()
+    for A, B, out, colsum, ev in items:
+        ws = _wgrad_stream(A.device)
+        ws.wait_event(ev)
+        gemm_tn(A, B, out=out, colsum=colsum, stream=ws.cuda_stream)   # (explicit handle: no current-stream switch on the host)
+        A.record_stream(ws)
+        B.record_stream(ws)
+
+
 def gemm_tn_sink(A, B, out, colsum=None):
     """gemm_tn into a persistent gradient bucket view, off the critical path (see above).  `out` / `colsum` must be sink
     views: nothing on the current stream may read them before BucketedGradAllReduce.finish()."""
     if not WGRAD_ASYNC or (not WGRAD_IN_CAPTURE and torch.cuda.is_current_stream_capturing()):
         return gemm_tn(A, B, out=out, colsum=colsum)
-    dev = A.device
-    ws = _WGRAD.get(dev)
-    if ws is None:
-        ws = _WGRAD[dev] = torch.cuda.Stream(device=dev)
-    ws.wait_stream(_current_stream_obj())
+    cur = _current_stream_obj()
+    if WGRAD_DEFER and not torch.cuda.is_current_stream_capturing():
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        _WGRAD_PENDING.append((A, B, out, colsum, ev))
+        return out
+    ws = _wgrad_stream(A.device)
+    ws.wait_stream(cur)
     gemm_tn(A, B, out=out, colsum=colsum, stream=ws.cuda_stream)   # (explicit handle: no current-stream switch on the host)
     A.record_stream(ws)
     B.record_stream(ws)
@@ -321,6 +356,8 @@ def attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias=None, premul=0.0):
 def attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias=None, premul=0.0):
     """Writes dq/dk/dv (2-D views, column slices allowed)."""
     do = do if do.stride(1) == 1 else do.contiguous()
+    if _WGRAD_PENDING and B * H * Lq * Lk >= _WGRAD_FLUSH_MIN_SCORES:
+        flush_wgrad()   # the queued weight-gradient GEMMs run beside this launch (flushing behind it instead: same step time)
     delta = torch.empty((3, B, H, Lq), dtype=torch.float32, device=q.device)  # delta | -lse2 pairs | -delta pairs (svol_hip.h)
     ws = _attn_ws(q, B, H, Lq, Lk, dh, kbias is not None or Lk % 128 != 0)
     tok = timer.start('attn_bwd', (B, H, Lq, Lk, dh))

@@ -154,6 +154,8 @@ class BucketedGradAllReduce:
             # By the time the last hook of a bucket fires every producing kernel of the bucket has been ENQUEUED on
             # its stream (autograd issues nodes in order on the host), so waiting on all producer streams here is
             # sufficient.
+            from . import ops
+            ops.flush_wgrad()   # weight-gradient GEMMs still queued on the host (ops.gemm_tn_sink) may belong to this bucket
             for s in self._producer_streams():
                 self.comm_stream.wait_stream(s)
             with torch.cuda.stream(self.comm_stream):
@@ -183,6 +185,7 @@ class BucketedGradAllReduce:
             # stream (query-stream / video-stream overlap): join it before anyone reads the buckets
             from . import ops
             from .modeling import cross_modal_transformer as cmt
+            ops.flush_wgrad()
             for s in list(cmt.side_streams(self.device)) + list(ops.wgrad_streams(self.device)):
                 torch.cuda.current_stream().wait_stream(s)
         for b in self.buckets:
