@@ -194,6 +194,8 @@ def wgrad_streams(dev):
 WGRAD_DEFER = os.environ.get('SVOL_NO_WGRAD_DEFER') is None
 _WGRAD_PENDING = []
 _WGRAD_FLUSH_MIN_SCORES = 1 << 27   # B*H*Lq*Lk of an attention backward worth hiding weight gradients under (cfg2: 2.5e9)
+_BIG_ATTN = {'left': 0}             # large attention forwards of this step whose backward has not run yet: nothing is deferred once
+                                    # it reaches 0 (after the first layer's attention backward there is nothing left to hide under)
 
 
 def _wgrad_stream(dev):
@@ -223,7 +225,7 @@ def gemm_tn_sink(A, B, out, colsum=None):
     if not WGRAD_ASYNC or (not WGRAD_IN_CAPTURE and torch.cuda.is_current_stream_capturing()):
         return gemm_tn(A, B, out=out, colsum=colsum)
     cur = _current_stream_obj()
-    if WGRAD_DEFER and not torch.cuda.is_current_stream_capturing():
+    if WGRAD_DEFER and _BIG_ATTN['left'] > 0 and not torch.cuda.is_current_stream_capturing():
         ev = torch.cuda.Event()
         ev.record(cur)
         _WGRAD_PENDING.append((A, B, out, colsum, ev))
@@ -344,6 +346,8 @@ def attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias=None, premul=0.0):
     o = torch.empty((B * Lq, H * dh), dtype=q.dtype, device=q.device)
     lse2 = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
     ws = _attn_ws(q, B, H, Lq, Lk, dh, kbias is not None or Lk % 128 != 0)
+    if B * H * Lq * Lk >= _WGRAD_FLUSH_MIN_SCORES:
+        _BIG_ATTN['left'] += 1
     tok = timer.start('attn_fwd', (B, H, Lq, Lk, dh))
     rc = _lib.lib().svol_attn_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o),
                                   o.stride(0), _ptr(lse2), _ptr(kbias), B, H, Lq, Lk, dh, 1.0 / math.sqrt(dh),
@@ -356,7 +360,8 @@ def attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias=None, premul=0.0):
 def attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias=None, premul=0.0):
     """Writes dq/dk/dv (2-D views, column slices allowed)."""
     do = do if do.stride(1) == 1 else do.contiguous()
-    if _WGRAD_PENDING and B * H * Lq * Lk >= _WGRAD_FLUSH_MIN_SCORES:
+    if B * H * Lq * Lk >= _WGRAD_FLUSH_MIN_SCORES:
+        _BIG_ATTN['left'] -= 1
         flush_wgrad()   # the queued weight-gradient GEMMs run beside this launch (flushing behind it instead: same step time)
     delta = torch.empty((3, B, H, Lq), dtype=torch.float32, device=q.device)  # delta | -lse2 pairs | -delta pairs (svol_hip.h)
     ws = _attn_ws(q, B, H, Lq, Lk, dh, kbias is not None or Lk % 128 != 0)
@@ -450,6 +455,7 @@ class _WeightCache:
         __slots__ = ('wc', 'wt', 'ptr', 'epoch', 'version', 'shape')
 
     def new_epoch(self):
+        _BIG_ATTN['left'] = 0   # a new forward starts (see gemm_tn_sink)
         if self.static:
             return
         self.epoch += 1
