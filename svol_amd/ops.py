@@ -185,12 +185,11 @@ def wgrad_streams(dev):
     return [s] if s is not None else []
 
 
-# Deferral: the weight-gradient GEMMs are HBM / atomic bound.  Run the moment they are issued they share the memory system with
-# the LayerNorm / gate / projection kernels of the dX chain (LayerNorm backward 46 -> 70 us, gate backward 102 -> 167 us per layer in
-# the step); run beside the video attention backward — instruction-issue bound, 1.3 ms per layer — they are nearly free.  So a
-# gradient-sink TN GEMM is only QUEUED here (with an event that says "its operands exist") and the queue is flushed onto the
-# weight-gradient stream right before the next large attention backward is launched, before a bucket's all-reduce, and in
-# BucketedGradAllReduce.finish().  The autograd engine runs every backward node of a device on one thread, so the queue needs no lock.
+# Deferral: the weight-gradient GEMMs are HBM / atomic bound; the video attention backward — 1.3 ms per layer — is instruction-issue
+# bound and is the part of the backward they disturb least.  So a gradient-sink TN GEMM is only QUEUED here (with an event that says
+# "its operands exist") and the queue is flushed onto the weight-gradient stream right before the next large attention backward is
+# launched, before a bucket's all-reduce, and in BucketedGradAllReduce.finish() (same-box A/B: -0.2 ms per step).  The autograd engine
+# runs every backward node of a device on one thread, so the queue needs no lock.
 WGRAD_DEFER = os.environ.get('SVOL_NO_WGRAD_DEFER') is None
 _WGRAD_PENDING = []
 _WGRAD_FLUSH_MIN_SCORES = 1 << 27   # B*H*Lq*Lk of an attention backward worth hiding weight gradients under (cfg2: 2.5e9)
