@@ -124,22 +124,6 @@ __global__ __launch_bounds__(256) void gate_stats_kernel(const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void gate_bwd_stats_kernel(const float* __restrict__ scores,
-                                                             const float* __restrict__ mx, const float* __restrict__ sm,
-                                                             const float* __restrict__ da, float* __restrict__ c_out,
-                                                             int L, int H) {
-    __shared__ float red[4];
-    const int bh = blockIdx.x, b = bh / H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* s = scores + (int64_t)bh * L;
-    const float m = mx[bh], inv = 1.f / sm[bh];
-    float acc = 0.f;
-    for (int l = tid; l < L; l += 256) acc += __expf(s[l] - m) * inv * da[(int64_t)b * L + l];
-    acc = wave_sum(acc);
-    if (lane == 0) red[wave] = acc;
-    __syncthreads();
-    if (tid == 0) c_out[bh] = (red[0] + red[1] + red[2] + red[3]) / (float)H;
-}
-
 // a[b,l] = mean_h softmax ; s1 = x*(1+a) ; y = LN(s1) ; ypos = y + pos        one wave per row
 template <typename T, int NP>
 __global__ __launch_bounds__(256) void gate_apply_kernel(const float* __restrict__ x, const T* __restrict__ pos,
@@ -235,19 +219,27 @@ __global__ __launch_bounds__(256) void gate_bwd_ln_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, float* __restrict__ dx,
                                                           float* __restrict__ da, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta, int64_t M, int D, int rpw) {
+                                                          float* __restrict__ dbeta, const float* __restrict__ scores,
+                                                          const float* __restrict__ mx, const float* __restrict__ sm,
+                                                          float* __restrict__ cc, int L, int H, int64_t M, int D, int rpw) {
     const int lane = threadIdx.x & 63;
     const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw;
     const int64_t rend = (r0 + rpw < M) ? r0 + rpw : M;
     float dg[NP][4], db[NP][4], gm[NP][4];
+    // c[b,h] = sum_l p[b,h,l] * da[b,l] / H (what the softmax backward of the next pass needs) is folded in here: lane h < H keeps
+    // head h's partial sum over this wave's rows and adds it to cc[b,h] (zeroed by the launcher) when the batch element changes and at
+    // the end — the separate B*H-block statistics kernel between the two row passes cost 24 us per layer inside the step
+    int bcur = r0 < rend ? (int)(r0 / L) : 0, lcur = r0 < rend ? (int)(r0 % L) : 0;
+    float cacc = 0.f, mxl = 0.f, isl = 0.f;
+    if (lane < H && r0 < rend) { mxl = mx[bcur * H + lane]; isl = 1.f / sm[bcur * H + lane]; }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         const int c = (lane + 64 * j) * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { dg[j][e] = 0.f; db[j][e] = 0.f; gm[j][e] = c < D ? gamma[c + e] : 0.f; }
     }
-    struct Row { Vec4<float> p32[NP], xv[NP]; Vec4<T> p[NP], p2[NP]; float mu, rs, a; };
-    auto fetch = [&](int64_t row, Row& r) {
+    struct Row { Vec4<float> p32[NP], xv[NP]; Vec4<T> p[NP], p2[NP]; float mu, rs, a, sc; };
+    auto fetch = [&](int64_t row, int b, int l, Row& r) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const int c = (lane + 64 * j) * 4;
@@ -259,11 +251,14 @@ __global__ __launch_bounds__(256) void gate_bwd_ln_kernel(const float* __restric
             }
         }
         r.mu = mean[row]; r.rs = rstd[row]; r.a = a_in[row];
+        r.sc = lane < H ? scores[((int64_t)b * H + lane) * L + l] : 0.f;
     };
     Row cur, nxt;
-    if (r0 < rend) fetch(r0, cur);
+    if (r0 < rend) fetch(r0, bcur, lcur, cur);
     for (int64_t row = r0; row < rend; ++row) {
-        if (row + 1 < rend) fetch(row + 1, nxt);
+        int bn = bcur, ln = lcur + 1;
+        if (ln == L) { ln = 0; ++bn; }
+        if (row + 1 < rend) fetch(row + 1, bn, ln, nxt);
         const float mu = cur.mu, rs = cur.rs, a = cur.a;
         float g[NP][4], xh[NP][4];
         float s1 = 0.f, s2 = 0.f;
@@ -304,6 +299,16 @@ __global__ __launch_bounds__(256) void gate_bwd_ln_kernel(const float* __restric
         }
         dacc = wave_sum(dacc);
         if (lane == 0) da[row] = dacc;
+        cacc += __expf(cur.sc - mxl) * isl * dacc;
+        if (bn != bcur || row + 1 == rend) {   // wave-uniform: leaving this batch element (or done)
+            if (lane < H) {
+                atomicAdd(cc + bcur * H + lane, cacc / (float)H);
+                cacc = 0.f;
+                if (row + 1 < rend) { mxl = mx[bn * H + lane]; isl = 1.f / sm[bn * H + lane]; }
+            }
+        }
+        bcur = bn;
+        lcur = ln;
         cur = nxt;
     }
     __shared__ float red[2][NP * 256];
@@ -645,13 +650,12 @@ int svol_gate_bwd(const float* dy32, const void* dy, const void* dy2, const floa
     const unsigned g1 = (unsigned)(((M + rpw1 - 1) / rpw1 + 3) / 4);
     const int rpw3 = rows_per_wave(L, gate_waves(2) / B + 1);
     dim3 g3((unsigned)((L + 4 * rpw3 - 1) / (4 * rpw3)), (unsigned)B);
+    if (hipMemsetAsync(cc, 0, sizeof(float) * (size_t)(B * H), s) != hipSuccess) return SVOL_E_LAUNCH;
 #define SVOL_GATE_BWD(TT)                                                                                                   \
     do {                                                                                                                    \
-        if (np_ == 1) hipLaunchKernelGGL((gate_bwd_ln_kernel<TT, 1>), dim3(g1), dim3(256), 0, s, dy32, (const TT*)dy, (const TT*)dy2, x32, a, gamma, mean, rstd, dx32, da, dgamma, dbeta, M, (int)D, rpw1); \
-        else if (np_ == 2) hipLaunchKernelGGL((gate_bwd_ln_kernel<TT, 2>), dim3(g1), dim3(256), 0, s, dy32, (const TT*)dy, (const TT*)dy2, x32, a, gamma, mean, rstd, dx32, da, dgamma, dbeta, M, (int)D, rpw1); \
-        else hipLaunchKernelGGL((gate_bwd_ln_kernel<TT, 4>), dim3(g1), dim3(256), 0, s, dy32, (const TT*)dy, (const TT*)dy2, x32, a, gamma, mean, rstd, dx32, da, dgamma, dbeta, M, (int)D, rpw1); \
-        hipLaunchKernelGGL(gate_bwd_stats_kernel, dim3((unsigned)(B * H)), dim3(256), 0, s, scores, mx, sm, da, cc, (int)L, \
-                           (int)H);                                                                                         \
+        if (np_ == 1) hipLaunchKernelGGL((gate_bwd_ln_kernel<TT, 1>), dim3(g1), dim3(256), 0, s, dy32, (const TT*)dy, (const TT*)dy2, x32, a, gamma, mean, rstd, dx32, da, dgamma, dbeta, scores, mx, sm, cc, (int)L, (int)H, M, (int)D, rpw1); \
+        else if (np_ == 2) hipLaunchKernelGGL((gate_bwd_ln_kernel<TT, 2>), dim3(g1), dim3(256), 0, s, dy32, (const TT*)dy, (const TT*)dy2, x32, a, gamma, mean, rstd, dx32, da, dgamma, dbeta, scores, mx, sm, cc, (int)L, (int)H, M, (int)D, rpw1); \
+        else hipLaunchKernelGGL((gate_bwd_ln_kernel<TT, 4>), dim3(g1), dim3(256), 0, s, dy32, (const TT*)dy, (const TT*)dy2, x32, a, gamma, mean, rstd, dx32, da, dgamma, dbeta, scores, mx, sm, cc, (int)L, (int)H, M, (int)D, rpw1); \
         if (np_ == 1) hipLaunchKernelGGL((gate_bwd_apply_kernel<TT, 1>), g3, dim3(256), 0, s, x32, (const TT*)pos, u, scores, mx, sm, da, cc, dx32, du, (int)L, (int)D, (int)H, rpw3); \
         else if (np_ == 2) hipLaunchKernelGGL((gate_bwd_apply_kernel<TT, 2>), g3, dim3(256), 0, s, x32, (const TT*)pos, u, scores, mx, sm, da, cc, dx32, du, (int)L, (int)D, (int)H, rpw3); \
         else hipLaunchKernelGGL((gate_bwd_apply_kernel<TT, 4>), g3, dim3(256), 0, s, x32, (const TT*)pos, u, scores, mx, sm, da, cc, dx32, du, (int)L, (int)D, (int)H, rpw3); \
