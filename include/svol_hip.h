@@ -54,10 +54,16 @@ int svol_cast(const void* src, int dtype_src, void* dst, int dtype_dst, int64_t 
 int svol_cast_transpose(const float* src, void* dst, void* dstT, int dtype, int64_t R, int64_t C, void* stream);
 /* The same for MANY weights in one launch (one per training step instead of one per weight).  `descs` is a DEVICE
  * array of n_desc records, sorted by tile_begin:
- *   struct { const float* src; void* dst; void* dstT; int32 R, C, tiles_c, tile_begin; }   (40 bytes)
+ *   struct { const float* src; void* dst; void* dstT; void* dstS; int32 R, C, tiles_c, tile_begin; }   (48 bytes)
  * tiles_c = ceil(C/32); a weight owns ceil(R/32)*tiles_c consecutive 32x32 tiles starting at tile_begin;
- * total_tiles = their sum.  dst or dstT may be NULL per record. */
+ * total_tiles = their sum.  dst, dstT, dstS may each be NULL per record; dstS (bf16 only) receives the SPLIT copy
+ * [R, 2C] = [hi | lo] of svol_cast_split. */
 int svol_cast_transpose_multi(const void* descs, int32_t n_desc, int64_t total_tiles, int dtype, void* stream);
+/* Split bf16 copy of an fp32 weight: dst_hilo [R, 2C] bf16 = [hi | lo], hi = bf16(w), lo = bf16(w - hi) (src rows ld_src
+ * floats apart).  hi + lo carries 16 mantissa bits of w: rounding the value-projection WEIGHTS to bf16 was 95 % of the
+ * bf16 logit error at the benchmark depth (it shifts every token's value the same way; attention over 6272 keys and
+ * LayerNorm do not average it out, profiles/round2_bf16_output_error.md), so those products use both halves. */
+int svol_cast_split(const float* src, int64_t ld_src, void* dst_hilo, int64_t R, int64_t C, void* stream);
 
 /* One AdamW step (torch.optim.AdamW semantics: decoupled weight decay, amsgrad / maximize off — the reference's optimizer,
  * train.py:98-99) over a FLAT fp32 range of parameters p with gradients g and moment buffers m, v, all 16-byte aligned:
@@ -81,6 +87,12 @@ int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, co
                  void* C, int64_t ldc, const float* bias, const float* colscale, int act, void* pre_act_out,
                  int64_t ldp, const void* residual, int64_t ldr, int out_f32, int64_t M, int64_t N, int64_t K,
                  int dtype, void* stream);
+/* C[M,N] (bf16) = A[M,K] * (W_hi + W_lo)[N,K]^T + bias[N] with W_hilo [N, 2K] from svol_cast_split (ld = ldw): ONE
+ * K-concatenated product [A | A] * [W_hi | W_lo]^T — the kernels wrap A's contraction index, [A | A] is never materialised;
+ * fp32 accumulation over both halves, one rounding of the result.  The V projections of nn.MultiheadAttention in bf16 mode
+ * (cross_modal_transformer.py:137-139,151-154; transformer.py:183-186,237-246). */
+int svol_gemm_nt_split(const void* A, int64_t lda, const void* W_hilo, int64_t ldw, void* C, int64_t ldc, const float* bias,
+                       int64_t M, int64_t N, int64_t K, void* stream);
 /* Fused MLP backward step: C[M,N] = (A[M,K] * B[N,K]^T) .* gelu'(pre[M,N]);  colsum[N] (fp32, may be NULL,
  * caller zeroes) += column sums of C (= the fc1 bias gradient).  Replaces dh = ds W2, dpre = dh *
  * gelu'(pre), db1 = sum(dpre) of the MLP backward (cross_modal_transformer.py:163-179). */

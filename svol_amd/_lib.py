@@ -23,6 +23,8 @@ _u64 = ctypes.c_uint64
 SIGNATURES = {
     'svol_cast': [_p, _int, _p, _int, _i64, _p],
     'svol_cast_transpose': [_p, _p, _p, _int, _i64, _i64, _p],
+    'svol_cast_split': [_p, _i64, _p, _i64, _i64, _p],
+    'svol_gemm_nt_split': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p],
     'svol_gemm_nt': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _int, _p, _i64, _p, _i64, _int, _i64, _i64, _i64,
                      _int, _p],
     'svol_gemm_nt_dgelu': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p],

@@ -37,6 +37,7 @@ struct NtArgs {
     const float* bias; const float* colscale; void* pre; const void* res;
     int64_t lda, ldb, ldc, ldr, ldp, n_split;
     int M, N, K, act;
+    int kwrap;  // A's contraction index is k % kwrap (kwrap == K: plain; svol_gemm_nt_split: K = 2 * kwrap)
 };
 
 // TC = element type of C and of the residual (T, or float for the fp32 residual stream)
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs p) {
             const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
             const int kk = k0 + ch * EPC;
             const int gm = bm + row, gn = bn + row;
-            ra[i] = (gm < p.M && kk < p.K) ? *reinterpret_cast<const uint4*>(A + (int64_t)gm * p.lda + kk)
+            ra[i] = (gm < p.M && kk < p.K) ? *reinterpret_cast<const uint4*>(A + (int64_t)gm * p.lda + (kk >= p.kwrap ? kk - p.kwrap : kk))
                                            : make_uint4(0, 0, 0, 0);
             rb[i] = (gn < p.N && kk < p.K) ? *reinterpret_cast<const uint4*>(B + (int64_t)gn * p.ldb + kk)
                                            : make_uint4(0, 0, 0, 0);
@@ -357,9 +358,23 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* src, T
 
 // all of a model's weights in ONE launch: block -> (descriptor, 32x32 tile) through a prefix table
 struct CastDesc {
-    const float* src; void* dst; void* dstT;
+    const float* src; void* dst; void* dstT; void* dstS;
     int R, C, tiles_c, tile_begin;
 };
+// split copy [R, 2C] = [hi | lo]: hi = bf16(w), lo = bf16(w - hi) — 16 mantissa bits of the fp32 master weight in two bf16 operands
+__device__ __forceinline__ void store_split(void* dstS, int r, int c, int C, float v) {
+    bf16_t* d = reinterpret_cast<bf16_t*>(dstS) + (int64_t)r * 2 * C + c;
+    const bf16_t hi = (bf16_t)v;
+    d[0] = hi;
+    d[C] = (bf16_t)(v - (float)hi);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void cast_split_kernel(const float* src, int64_t lds, void* dstS, int R, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)R * C) return;
+    const int r = (int)(i / C), c = (int)(i % C);
+    store_split(dstS, r, c, C, src[(int64_t)r * lds + c]);
+}
 template <typename T>
 __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const CastDesc* __restrict__ descs, int n_desc) {
     __shared__ float tile[32][33];
@@ -385,6 +400,7 @@ __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const CastDes
         float v = (r < d.R && c < d.C) ? d.src[(int64_t)r * d.C + c] : 0.f;
         tile[ty + 8 * j][tx] = v;
         if (dst && r < d.R && c < d.C) dst[(int64_t)r * d.C + c] = from_f32<T>(v);
+        if (d.dstS && r < d.R && c < d.C) store_split(d.dstS, r, c, d.C, v);
     }
     __syncthreads();
     if (dstT) {
@@ -546,11 +562,11 @@ int svol_gemm_tn_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ld
 int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
                            int act, void* pre, int64_t ldp, const void* res, int64_t ldr, int out_f32, const void* aux,
                            int64_t ldaux, float* colsum, int epi, const float* colscale, int64_t M, int64_t N, int64_t K,
-                           hipStream_t s);
+                           int64_t kwrap, hipStream_t s);
 
 extern "C" {
 
-int svol_abi_version(void) { return 2; }
+int svol_abi_version(void) { return 3; }
 
 const char* svol_strerror(int code) {
     switch (code) {
@@ -562,9 +578,10 @@ const char* svol_strerror(int code) {
     }
 }
 
-int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, const void* B, int64_t ldb, void* C,
-                 int64_t ldc, const float* bias, const float* colscale, int act, void* pre_act_out, int64_t ldp,
-                 const void* residual, int64_t ldr, int out_f32, int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
+static int gemm_nt_impl(const void* A, int64_t lda, const void* A2, int64_t n_split, const void* B, int64_t ldb, void* C,
+                        int64_t ldc, const float* bias, const float* colscale, int act, void* pre_act_out, int64_t ldp,
+                        const void* residual, int64_t ldr, int out_f32, int64_t M, int64_t N, int64_t K, int64_t kwrap, int dtype,
+                        void* stream) {
     if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return SVOL_E_INVALID;
     if (M == 0 || N == 0) return SVOL_OK;
     const int epc = dtype == SVOL_BF16 ? 8 : 4;
@@ -573,16 +590,16 @@ int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, co
     if (!aligned16(A) || !aligned16(B) || (A2 && !aligned16(A2))) return SVOL_E_INVALID;
     if (A2 && (n_split % 128)) return SVOL_E_UNSUPPORTED;
     if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return SVOL_E_UNSUPPORTED;
-    NtArgs p{A, A2, B, C, bias, colscale, pre_act_out, residual, lda, ldb, ldc, ldr, ldp, n_split, (int)M, (int)N, (int)K, act};
+    NtArgs p{A, A2, B, C, bias, colscale, pre_act_out, residual, lda, ldb, ldc, ldr, ldp, n_split, (int)M, (int)N, (int)K, act, (int)kwrap};
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
     if (grid.y > 65535u) return SVOL_E_UNSUPPORTED;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SVOL_BF16 && !A2) {
         const int rc = svol_gemm_nt_bf16_fast(A, lda, B, ldb, C, ldc, bias, act, pre_act_out, ldp, residual, ldr, out_f32, nullptr,
-                                              0, nullptr, 0, colscale, M, N, K, s);
+                                              0, nullptr, 0, colscale, M, N, K, kwrap, s);
         if (rc != SVOL_E_UNSUPPORTED) return rc;
     }
-    if (dtype == SVOL_F32 && !A2 && skinny_f32_ok(M, N, K, lda, ldb, ldc, A, B, C) && (!residual || (ldr % 4 == 0 && aligned16(residual))) &&
+    if (dtype == SVOL_F32 && !A2 && kwrap == K && skinny_f32_ok(M, N, K, lda, ldb, ldc, A, B, C) && (!residual || (ldr % 4 == 0 && aligned16(residual))) &&
         (!pre_act_out || (ldp % 4 == 0 && aligned16(pre_act_out)))) {
         SkArgs q{(const float*)A, (const float*)B, (float*)C, bias, colscale, (float*)pre_act_out, (const float*)residual, nullptr,
                  nullptr, lda, ldb, ldc, ldp, ldr, 0, (int)M, (int)N, (int)K, act, 0};
@@ -605,6 +622,21 @@ int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, co
     return SVOL_OK;
 }
 
+int svol_gemm_nt(const void* A, int64_t lda, const void* A2, int64_t n_split, const void* B, int64_t ldb, void* C,
+                 int64_t ldc, const float* bias, const float* colscale, int act, void* pre_act_out, int64_t ldp,
+                 const void* residual, int64_t ldr, int out_f32, int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
+    return gemm_nt_impl(A, lda, A2, n_split, B, ldb, C, ldc, bias, colscale, act, pre_act_out, ldp, residual, ldr, out_f32, M, N, K, K,
+                        dtype, stream);
+}
+
+// C = A (W_hi + W_lo)^T + bias as ONE K-concatenated product [A | A] [W_hi | W_lo]^T: the kernels wrap A's contraction index
+int svol_gemm_nt_split(const void* A, int64_t lda, const void* W_hilo, int64_t ldw, void* C, int64_t ldc, const float* bias,
+                       int64_t M, int64_t N, int64_t K, void* stream) {
+    if (K <= 0 || K % 8) return SVOL_E_UNSUPPORTED;
+    return gemm_nt_impl(A, lda, nullptr, 0, W_hilo, ldw, C, ldc, bias, nullptr, SVOL_ACT_NONE, nullptr, 0, nullptr, 0, 0, M, N, 2 * K, K,
+                        SVOL_BF16, stream);
+}
+
 int svol_gemm_nt_dact(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* aux,
                       int64_t ldaux, int act, float* colsum, int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
     if (!A || !B || !C || !aux || M < 0 || N < 0 || K <= 0) return SVOL_E_INVALID;
@@ -613,7 +645,7 @@ int svol_gemm_nt_dact(const void* A, int64_t lda, const void* B, int64_t ldb, vo
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SVOL_BF16) {
         const int rc = svol_gemm_nt_bf16_fast(A, lda, B, ldb, C, ldc, nullptr, act, nullptr, 0, nullptr, 0, 0, aux, ldaux, colsum, 1,
-                                              nullptr, M, N, K, s);
+                                              nullptr, M, N, K, K, s);
         if (rc != SVOL_E_UNSUPPORTED) return rc;
     }
     if (dtype == SVOL_F32 && skinny_f32_ok(M, N, K, lda, ldb, ldc, A, B, C) && ldaux % 4 == 0 && aligned16(aux)) {
@@ -742,8 +774,17 @@ int svol_cast_transpose(const float* src, void* dst, void* dstT, int dtype, int6
     return SVOL_OK;
 }
 
+int svol_cast_split(const float* src, int64_t ld_src, void* dst_hilo, int64_t R, int64_t C, void* stream) {
+    if (!src || !dst_hilo || R <= 0 || C <= 0 || ld_src < C) return SVOL_E_INVALID;
+    if (R * C > (1ll << 38)) return SVOL_E_UNSUPPORTED;
+    hipLaunchKernelGGL(cast_split_kernel<bf16_t>, dim3((unsigned)((R * C + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       src, ld_src, dst_hilo, (int)R, (int)C);
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
 int svol_cast_transpose_multi(const void* descs, int32_t n_desc, int64_t total_tiles, int dtype, void* stream) {
-    static_assert(sizeof(CastDesc) == 40, "descriptor layout is part of the ABI (include/svol_hip.h)");
+    static_assert(sizeof(CastDesc) == 48, "descriptor layout is part of the ABI (include/svol_hip.h)");
     if (!descs || n_desc <= 0 || total_tiles <= 0) return SVOL_E_INVALID;
     if (total_tiles > (1ll << 30)) return SVOL_E_UNSUPPORTED;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -31,6 +31,7 @@ struct FastArgs {
     // (n, ho, wo) and column k = (ky*ckw + kx)*cC + c is gathered on the fly — the im2col matrix never exists
     int cH, cW, cC, ckw, cstride, cpad, cHo, cWo;
     int64_t a_bytes;
+    int kwrap;  // A's contraction index is k % kwrap (kwrap == K: plain).  Split weights: C = A [W_hi | W_lo]^T reads [A | A] in place
 };
 
 constexpr int EP_STRIDE = 272;       // bytes per staged accumulator row (64 floats + 16 pad)
@@ -125,7 +126,8 @@ __device__ __forceinline__ void gemm_nt_bf16_body(const FastArgs& p) {
                 const int off = ok ? ((((cvn[i] + hi) * p.cW + wi) * p.cC + c0) * 2 + voffA[i]) : 0x7ffffff0;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(sa + (wave * NI + i) * 1024), 16, off, 0, 0, 0);
             } else {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(sa + (wave * NI + i) * 1024), 16, voffA[i], k0 * 2, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(sa + (wave * NI + i) * 1024), 16, voffA[i],
+                                                         (k0 >= p.kwrap ? k0 - p.kwrap : k0) * 2, 0, 0);
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_ptr)(sb + (wave * NI + i) * 1024), 16, voffB[i], k0 * 2, 0, 0);
         }
@@ -293,7 +295,7 @@ __device__ __forceinline__ void gemm_nt_bf16_skinny_body(const FastArgs& p) {
     const bool va = bm + r < p.M, vb0 = bn + r < p.N, vb1 = bn + 32 + r < p.N;
     // the contraction index may be permuted freely as long as both operands agree: lane (r, h) takes the 32
     // consecutive elements [h*32, h*32+32) of each 64-element batch, 8 per MFMA
-    const bf16_t* pa = p.A + (int64_t)(bm + r) * p.lda + wave * kslice + h * 32;
+    const bf16_t* pa = p.A + (int64_t)(bm + r) * p.lda + (wave * kslice) % p.kwrap + h * 32;  // (kwrap % kslice == 0: launcher)
     const bf16_t* pb0 = p.B + (int64_t)(bn + r) * p.ldb + wave * kslice + h * 32;
     const bf16_t* pb1 = pb0 + (int64_t)32 * p.ldb;
     const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
@@ -415,14 +417,16 @@ int svol_gemm_ws_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, vo
 
 int svol_gemm_n256_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias, int act,
                         void* pre, const void* res, int64_t ldr, int out_f32, int epi, const float* colscale, int64_t M,
-                        int64_t N, int64_t K, hipStream_t s);
+                        int64_t N, int64_t K, int64_t kwrap, hipStream_t s);
 
 // launcher used by gemm.hip's C-ABI entry points.  Returns SVOL_E_UNSUPPORTED when the shape does not
 // qualify (the caller then uses the generic kernel).
 int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
                            int act, void* pre, int64_t ldp, const void* res, int64_t ldr, int out_f32, const void* aux,
                            int64_t ldaux, float* colsum, int epi, const float* colscale, int64_t M, int64_t N, int64_t K,
-                           hipStream_t s) {
+                           int64_t kwrap, hipStream_t s) {
+    // kwrap != K: the split-weight product C = A [W_hi | W_lo]^T, K = 2 * kwrap, A has kwrap columns (svol_gemm_nt_split)
+    if (kwrap != K && (2 * kwrap != K || kwrap % 32)) return SVOL_E_UNSUPPORTED;
     if (K % 32 || lda % 8 || ldb % 8 || !aligned16(A) || !aligned16(B)) return SVOL_E_UNSUPPORTED;
     // vector epilogue needs 8-byte (bf16) / 16-byte (f32) aligned rows; otherwise the scalar tail path is used per lane
     if ((int64_t)128 * lda * 2 >= (1ll << 31) || (int64_t)128 * ldb * 2 >= (1ll << 31)) return SVOL_E_UNSUPPORTED;
@@ -433,17 +437,18 @@ int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ld
     if (aux && (ldaux % 4 || (reinterpret_cast<uintptr_t>(aux) % 8))) return SVOL_E_UNSUPPORTED;
     FastArgs p{(const bf16_t*)A, (const bf16_t*)B, C, bias, colscale, (bf16_t*)pre, res, (const bf16_t*)aux, colsum,
                lda, ldb, ldc, ldp, ldr, ldaux, (int)M, (int)N, (int)K, act, epi};
-    {   // K = 256, tall M: weight-stationary kernel (gemm_ws_bf16.hip)
+    p.kwrap = (int)kwrap;
+    if (kwrap == K) {   // K = 256, tall M: weight-stationary kernel (gemm_ws_bf16.hip)
         const int rc = svol_gemm_ws_bf16(A, lda, B, ldb, C, ldc, bias, act, pre, ldp, res, ldr, out_f32, aux, ldaux, colsum, epi,
                                          colscale, M, N, K, s);
         if (rc != SVOL_E_UNSUPPORTED) return rc;
     }
     {   // N = 256, deep K, tall M: full-width tiles (gemm_n256_bf16.hip)
-        const int rc = svol_gemm_n256_bf16(A, lda, B, ldb, C, ldc, bias, act, pre, res, ldr, out_f32, epi, colscale, M, N, K, s);
+        const int rc = svol_gemm_n256_bf16(A, lda, B, ldb, C, ldc, bias, act, pre, res, ldr, out_f32, epi, colscale, M, N, K, kwrap, s);
         if (rc != SVOL_E_UNSUPPORTED) return rc;
     }
     static const int skinny_max = getenv("SVOL_GEMM_SKINNY_M") ? atoi(getenv("SVOL_GEMM_SKINNY_M")) : 2048;
-    if (M <= skinny_max && K % 256 == 0 && N % SK_BN == 0) {
+    if (M <= skinny_max && K % 256 == 0 && N % SK_BN == 0 && kwrap % (K / 4) == 0) {
         dim3 g((unsigned)(N / SK_BN), (unsigned)((M + SK_BM - 1) / SK_BM));
         if (out_f32) hipLaunchKernelGGL(gemm_nt_bf16_skinny_f32, g, dim3(256), 0, s, p);
         else hipLaunchKernelGGL(gemm_nt_bf16_skinny_b16, g, dim3(256), 0, s, p);
@@ -455,7 +460,7 @@ int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ld
     // short K = 256 loops); deep-K launches use 64-deep steps (half the barriers)
     static const int force_bk = getenv("SVOL_GEMM_BK") ? atoi(getenv("SVOL_GEMM_BK")) : 0;
     const bool bk64 = force_bk ? (force_bk == 64) : (K % 64 == 0 && K >= 1024);
-    if (bk64 && K % 64 == 0) {
+    if (bk64 && K % 64 == 0 && kwrap % 64 == 0) {
         if (out_f32) hipLaunchKernelGGL(gemm_nt_bf16_f32_k64, grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL(gemm_nt_bf16_b16_k64, grid, dim3(256), 0, s, p);
     } else {
@@ -485,7 +490,7 @@ extern "C" int svol_conv_nhwc(const void* x, const void* w, int64_t ldw, void* y
     if (act != SVOL_ACT_NONE && act != SVOL_ACT_RELU && act != SVOL_ACT_RELU_RES) return SVOL_E_UNSUPPORTED;
     FastArgs p{(const bf16_t*)x, (const bf16_t*)w, y, bias, nullptr, nullptr, residual, nullptr, nullptr,
                0, ldw, Cout, 0, Cout, 0, (int)M, (int)Cout, (int)K, act, 0,
-               (int)H, (int)W, (int)C, (int)kw, (int)stride, (int)pad, (int)Ho, (int)Wo, a_bytes};
+               (int)H, (int)W, (int)C, (int)kw, (int)stride, (int)pad, (int)Ho, (int)Wo, a_bytes, (int)K};
     dim3 grid((unsigned)((Cout + 127) / 128), (unsigned)((M + 127) / 128));
     if (grid.y > 65535u) return SVOL_E_UNSUPPORTED;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -23,6 +23,8 @@ struct N256Args {
     const float* bias; const float* res;
     int64_t lda, ldw, ldc, ldr;
     int M, K, act, nrt;  // nrt: row tiles per column group (padded to a multiple of 8 when there are several groups)
+    int kwt;             // A's contraction index wraps every kwt slabs (kwt = K / BK: no wrap).  Split weights: C = A [W_hi | W_lo]^T
+                         // reads the K-concatenated [A | A] without materialising it
 };
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -77,7 +79,7 @@ __device__ __forceinline__ void gemm_n256_body(const N256Args& p) {
     const int bn = cg * BN;
 
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.A + (int64_t)bm * p.lda), 0, (int)((((int64_t)rows - 1) * p.lda + p.K) * 2), 0x00020000);
+        (void*)(p.A + (int64_t)bm * p.lda), 0, (int)((((int64_t)rows - 1) * p.lda + p.kwt * BK) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rW =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)bn * p.ldw), 0, (int)((((int64_t)BN - 1) * p.ldw + p.K) * 2), 0x00020000);
     // DMA: one instruction = 16 image rows x 4 chunks.  A: instructions 2w, 2w+1; W: 4w .. 4w+3.
@@ -97,9 +99,10 @@ __device__ __forceinline__ void gemm_n256_body(const N256Args& p) {
     auto issue = [&](int slot, int kt) {
         char* sl = smem + slot * SLOT;
         const int so = kt * BK * 2;
+        const int soA = (kt >= p.kwt ? kt - p.kwt : kt) * BK * 2;   // (at most one wrap: K <= 2 * kwt * BK)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(sl + (wave * 2 + j) * 1024), 16, voffA[j], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(sl + (wave * 2 + j) * 1024), 16, voffA[j], soA, 0, 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_void_ptr)(sl + A_ST + (wave * 4 + j) * 1024), 16, voffW[j], so, 0, 0);
@@ -202,10 +205,11 @@ __global__ __launch_bounds__(256, 2) void gemm_n256_bf16_b16(N256Args p) { gemm_
 // launcher used by gemm_bf16.hip's fast-path dispatcher.  Returns SVOL_E_UNSUPPORTED when the call does not fit.
 int svol_gemm_n256_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const float* bias, int act,
                         void* pre, const void* res, int64_t ldr, int out_f32, int epi, const float* colscale, int64_t M,
-                        int64_t N, int64_t K, hipStream_t s) {
+                        int64_t N, int64_t K, int64_t kwrap, hipStream_t s) {
     static const bool off = getenv("SVOL_GEMM_NO_N256") != nullptr;
     if (off || N % BN || K % BK || K < 512 || M < 4096) return SVOL_E_UNSUPPORTED;
     if (epi != 0 || pre || colscale) return SVOL_E_UNSUPPORTED;
+    if (kwrap != K && (kwrap % BK || 2 * kwrap != K)) return SVOL_E_UNSUPPORTED;
     if (act != SVOL_ACT_NONE && ((act != SVOL_ACT_GELU && act != SVOL_ACT_RELU) || out_f32)) return SVOL_E_UNSUPPORTED;
     if (res && !out_f32) return SVOL_E_UNSUPPORTED;
     auto al16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
@@ -216,7 +220,8 @@ int svol_gemm_n256_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, 
     int64_t nrt = (M + BM - 1) / BM;
     if (ncg > 1) nrt = (nrt + 7) / 8 * 8;
     if (nrt * ncg > (1ll << 30)) return SVOL_E_UNSUPPORTED;
-    N256Args p{(const bf16_t*)A, (const bf16_t*)W, C, bias, (const float*)res, lda, ldw, ldc, ldr, (int)M, (int)K, act, (int)nrt};
+    N256Args p{(const bf16_t*)A, (const bf16_t*)W, C, bias, (const float*)res, lda, ldw, ldc, ldr, (int)M, (int)K, act, (int)nrt,
+               (int)(kwrap / BK)};
     dim3 grid((unsigned)(nrt * ncg));
     if (out_f32) hipLaunchKernelGGL(gemm_n256_bf16_f32, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(gemm_n256_bf16_b16, grid, dim3(256), 0, s, p);

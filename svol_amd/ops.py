@@ -153,6 +153,21 @@ def gemm_nt(A, B, bias=None, act=ACT_NONE, residual=None, want_pre=False, out=No
     return (out, pre) if want_pre else out
 
 
+def gemm_nt_split(A, W_hilo, bias=None, out=None):
+    """out[M,N] (bf16) = A[M,K] @ (W_hi + W_lo)[N,K]^T + bias with W_hilo [N, 2K] = [hi | lo] (weights.get_split): one
+    K-concatenated product, [A | A] is never materialised."""
+    assert A.dim() == 2 and W_hilo.dim() == 2 and A.stride(1) == 1 and W_hilo.stride(1) == 1 and A.dtype == torch.bfloat16
+    M, K = A.shape
+    N = W_hilo.shape[0]
+    assert W_hilo.shape[1] == 2 * K
+    if out is None:
+        out = torch.empty((M, N), dtype=A.dtype, device=A.device)
+    rc = _lib.lib().svol_gemm_nt_split(_ptr(A), A.stride(0), _ptr(W_hilo), W_hilo.stride(0), _ptr(out), out.stride(0), _ptr(bias),
+                                       M, N, K, _stream())
+    _lib.check(rc, 'svol_gemm_nt_split')
+    return out
+
+
 def gemm_tn(A, B, out=None, colsum=None, stream=None):
     """out[N,K] (fp32) += A[Mc,N]^T @ B[Mc,K]; a fresh zeroed `out` is allocated when not given.
     colsum (fp32 [N], zeroed by the caller) += column sums of A (bias gradient, fused).  stream: raw handle (default: current)."""
@@ -451,7 +466,7 @@ class _WeightCache:
         self._sets = {}  # (device, dtype) -> {'items': [(weakref(param), entry)], 'table': tensor|None, 'tiles': int}
 
     class _Entry:
-        __slots__ = ('wc', 'wt', 'ptr', 'epoch', 'version', 'shape')
+        __slots__ = ('wc', 'wt', 'ws', 'ptr', 'epoch', 'version', 'shape')
 
     def new_epoch(self):
         _BIG_ATTN['left'] = 0   # a new forward starts (see gemm_tn_sink)
@@ -463,8 +478,14 @@ class _WeightCache:
 
     def _refresh(self, key, st):
         dev, dtype = key
-        live = [(r, e) for (r, e) in st['items'] if r() is not None and getattr(r(), '_svol_cache', {}).get(dtype) is e
-                and r().data_ptr() == e.ptr]
+        def alive(r, e):
+            w = r()
+            if w is None:
+                return False
+            if e.ws is not None:   # split entry: keyed by (row0, rows), ptr = address of the first row
+                return any(v is e for v in getattr(w, '_svol_split', {}).values())
+            return getattr(w, '_svol_cache', {}).get(dtype) is e and w.data_ptr() == e.ptr
+        live = [(r, e) for (r, e) in st['items'] if alive(r, e)]
         if len(live) != len(st['items']) or st['table'] is None:
             st['items'] = live
             st['table'] = None
@@ -475,11 +496,14 @@ class _WeightCache:
             for r, e in live:
                 R, C = e.shape
                 tc = (C + 31) // 32
-                # src, dst, dstT (8 bytes each) ; R, C, tiles_c, tile_begin (int32)
-                recs.append((e.ptr, 0 if dtype == torch.float32 else e.wc.data_ptr(), e.wt.data_ptr(), R, C, tc, t0))
+                # src, dst, dstT, dstS (8 bytes each) ; R, C, tiles_c, tile_begin (int32)
+                if e.ws is not None:   # split copy of a row range of the weight (get_split): its own record
+                    recs.append((e.ptr, 0, 0, e.ws.data_ptr(), R, C, tc, t0))
+                else:
+                    recs.append((e.ptr, 0 if dtype == torch.float32 else e.wc.data_ptr(), e.wt.data_ptr(), 0, R, C, tc, t0))
                 t0 += ((R + 31) // 32) * tc
             import struct
-            blob = b''.join(struct.pack('<QQQiiii', *rec) for rec in recs)
+            blob = b''.join(struct.pack('<QQQQiiii', *rec) for rec in recs)
             st['table'] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
             st['tiles'] = t0
             st['gen'] = st.get('gen', 0) + 1
@@ -497,6 +521,9 @@ class _WeightCache:
                 done.clear()
                 done.add(key_)
                 for r, e in st['items']:
+                    if e.ws is not None:
+                        e.ws.record_stream(cur)
+                        continue
                     if e.wc is not None and e.wc.dtype != torch.float32:
                         e.wc.record_stream(cur)
                     e.wt.record_stream(cur)
@@ -520,6 +547,7 @@ class _WeightCache:
         fresh = e is None or e.ptr != w.data_ptr() or tuple(w.shape) != e.shape
         if fresh:
             e = self._Entry()
+            e.ws = None
             e.shape, e.ptr = tuple(w.shape), w.data_ptr()
             R, C = e.shape
             e.wc = wd if dtype == torch.float32 else torch.empty((R, C), dtype=dtype, device=w.device)
@@ -538,6 +566,42 @@ class _WeightCache:
             except TypeError:  # pragma: no cover
                 pass
         return e.wc, e.wt
+
+    def get_split(self, w: torch.Tensor, row0: int, rows: int):
+        """bf16 split copy [rows, 2C] = [hi | lo] of rows [row0, row0 + rows) of the fp32 master weight `w` (svol_cast_split):
+        the operand of gemm_nt_split.  Refreshed once per epoch by the same multi-weight launch as the plain copies."""
+        cache = getattr(w, '_svol_split', None)
+        if cache is None:
+            cache = {}
+            try:
+                w._svol_split = cache
+            except Exception:  # pragma: no cover
+                pass
+        C = w.shape[1]
+        ptr = w.data_ptr() + row0 * C * 4
+        e = cache.get((row0, rows))
+        if e is not None and e.ptr == ptr and e.version == w._version and (self.static or e.epoch == self.epoch):
+            return e.ws
+        wd = w.detach()
+        assert wd.dtype == torch.float32 and wd.dim() == 2 and wd.is_contiguous()
+        fresh = e is None or e.ptr != ptr
+        if fresh:
+            e = self._Entry()
+            e.wc = e.wt = None
+            e.shape, e.ptr = (rows, C), ptr
+            e.ws = torch.empty((rows, 2 * C), dtype=torch.bfloat16, device=w.device)
+        _lib.check(_lib.lib().svol_cast_split(ptr, C, _ptr(e.ws), rows, C, _stream()), 'svol_cast_split')
+        e.epoch, e.version = self.epoch, w._version
+        if fresh:
+            cache[(row0, rows)] = e
+            st = self._sets.setdefault((w.device, torch.bfloat16), {'items': [], 'table': None, 'tiles': 0})
+            try:
+                import weakref
+                st['items'].append((weakref.ref(w), e))
+                st['table'] = None
+            except TypeError:  # pragma: no cover
+                pass
+        return e.ws
 
 
 weights = _WeightCache()
@@ -766,6 +830,15 @@ class MLPLNFn(torch.autograd.Function):
                 n_(sbt, dbt), dpos, None)
 
 
+# bf16 mode: the VALUE projections of every attention block multiply by split weights W_hi + W_lo (two bf16 operands = 16
+# mantissa bits of the fp32 master weight, one K-concatenated GEMM).  Rounding W_v to bf16 shifts every token's value the same way,
+# which attention over thousands of keys and LayerNorm do not average out: at the benchmark depth (6 layers, L = 6272) the V weights
+# of the query -> video attention (4.3e-3 rms) and of the video self-attention (2.7e-3) were 95 % of the 6.8e-3 rms logit error, the
+# q / k / MLP weights together 1.1e-3 (profiles/round3_bf16_output_error.md).  Forward only: gradients take the plain bf16 copy.
+# SVOL_NO_SPLIT_V=1 restores single-bf16 V weights (A/B; changes results).
+SPLIT_V = os.environ.get('SVOL_NO_SPLIT_V') is None
+
+
 class AttnLNFn(torch.autograd.Function):
     """LN(xq32 + out_proj(MHA(q = Wq xq_pos, k = Wk xk_pos, v = Wv xv))) with packed in_proj
     (nn.MultiheadAttention + post-norm, cross_modal_transformer.py:137-141,145-149,151-156; transformer.py:183-189,
@@ -798,10 +871,15 @@ class AttnLNFn(torch.autograd.Function):
         a_kp = a_qp if self_attn else xk_pos.reshape(B * Lk, d)
         a_v = a_q if self_attn else xv.reshape(B * Lk, d)
         Wq32T = None
+        # bf16: the V projection uses SPLIT weights (hi + lo, 16 mantissa bits; svol_gemm_nt_split) — see SPLIT_V
+        Wv_hilo = weights.get_split(W_in, 2 * d, d) if (SPLIT_V and dkv == torch.bfloat16 and d % 32 == 0) else None
         if self_attn:
             qkv = torch.empty((B * Lq, 3 * d), dtype=dt, device=xq.device)
             gemm_nt(a_qp, Wc[:2 * d], b_in[:2 * d], out=qkv[:, :2 * d], colscale=qscale)
-            gemm_nt(a_q, Wc[2 * d:], b_in[2 * d:], out=qkv[:, 2 * d:])
+            if Wv_hilo is not None:
+                gemm_nt_split(a_q, Wv_hilo, b_in[2 * d:], out=qkv[:, 2 * d:])
+            else:
+                gemm_nt(a_q, Wc[2 * d:], b_in[2 * d:], out=qkv[:, 2 * d:])
             q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         else:
             if mixed:
@@ -812,7 +890,10 @@ class AttnLNFn(torch.autograd.Function):
                 q = gemm_nt(a_qp, Wc[:d], b_in[:d], colscale=qscale[:d] if qscale is not None else None)
             kv = torch.empty((B * Lk, 2 * d), dtype=dkv, device=xq.device)
             gemm_nt(a_kp, Wc[d:2 * d], b_in[d:2 * d], out=kv[:, :d])
-            gemm_nt(a_v, Wc[2 * d:], b_in[2 * d:], out=kv[:, d:])
+            if Wv_hilo is not None:
+                gemm_nt_split(a_v, Wv_hilo, b_in[2 * d:], out=kv[:, d:])
+            else:
+                gemm_nt(a_v, Wc[2 * d:], b_in[2 * d:], out=kv[:, d:])
             k, v = kv[:, :d], kv[:, d:]
         o, lse2 = attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias, premul)
         att = attn_weights_mean(q, k, lse2, B, H, Lq, Lk, dh, kbias, premul) if need_weights else None

@@ -132,6 +132,44 @@ def check_gemm_nt():
     return res
 
 
+def check_gemm_split():
+    """svol_cast_split + svol_gemm_nt_split: y = x (W_hi + W_lo)^T + b.  (1) the split copy is exactly [bf16(w) | bf16(w - bf16(w))];
+    (2) the product equals fp64 math on the SAME split operands to fp32-accumulation accuracy (one bf16 rounding of the result);
+    (3) the COHERENT error (the part a mean over thousands of rows keeps: the weight rounding; the rounding noise of the bf16 result
+    averages out) is at most a quarter of the single-bf16-weight product's.
+    Shapes walk every kernel that takes the wrapped contraction index: deep-K N = 256 (tall M), 128x128 tiles (k32 and k64),
+    skinny split-K, generic (unaligned ld)."""
+    res = {}
+    for (M, N, K) in [(6272, 256, 256), (4100, 512, 256), (5000, 256, 512), (300, 64, 64), (130, 96, 32), (4200, 128, 1024), (800, 256, 256),
+                      (100, 128, 128), (257, 72, 40)]:
+        x = (1.0 + 0.5 * _rnd((M, K), torch.float32, 41)).to(torch.bfloat16)   # non-zero mean: the row mean keeps the weight error
+        W = _rnd((3 * N, K), torch.float32, 42, 1.0 / math.sqrt(K))
+        b = _rnd((N,), torch.float32, 43)
+        Wd = W.to(DEV)
+        Wd.requires_grad_(False)
+        hl = ops.weights.get_split(Wd, 2 * N, N)
+        wv = W[2 * N:]
+        hi = wv.to(torch.bfloat16)
+        lo = (wv - hi.float()).to(torch.bfloat16)
+        res[f'gemm_split/{M}x{N}x{K}/cast_hi'] = (float((hl[:, :K].cpu().float() - hi.float()).abs().max()), 0.0)
+        res[f'gemm_split/{M}x{N}x{K}/cast_lo'] = (float((hl[:, K:].cpu().float() - lo.float()).abs().max()), 0.0)
+        wide = torch.full((M, N + 64), 3.0, dtype=torch.bfloat16, device=DEV)
+        y = ops.gemm_nt_split(x.to(DEV), hl, b.to(DEV), out=wide[:, 64:])
+        ref_split = x.double() @ (hi.double() + lo.double()).t() + b.double()
+        res[f'gemm_split/{M}x{N}x{K}/vs_split_operands'] = (rel_err(y, ref_split), 4.5e-3)   # one bf16 rounding of the result (2^-8)
+        res[f'gemm_split/{M}x{N}x{K}/untouched'] = (float((wide[:, :64].float() - 3.0).abs().max()), 0.0)
+        # how much of the weight-rounding error is left: compare UNROUNDED-size quantities via the mean over rows (rounding noise of
+        # the bf16 result averages out over M rows, the coherent weight error does not)
+        exact = (x.double() @ wv.double().t() + b.double()).mean(0)
+        single = (x.double() @ hi.double().t() + b.double()).mean(0)
+        got = y.double().cpu().mean(0)
+        e_single = float((single - exact).abs().max())
+        e_split = float((got - exact).abs().max())
+        if M >= 4000:
+            res[f'gemm_split/{M}x{N}x{K}/coherent_error_vs_single_bf16'] = (e_split / max(e_single, 1e-30), 0.25)
+    return res
+
+
 def check_gemm_dgelu():
     res = {}
     for dt in DTYPES:
@@ -562,13 +600,10 @@ def check_head_case(name, dtype, sinks=False):
     """Whole hot path through the product modules vs the reference's golden vectors.
 
     * outputs (pred_logits / pred_boxes, final and auxiliary layers — the outputs north_star names): ABSOLUTE
-      |diff| <= 1e-3 fp32 / 1e-2 bf16, every case up to mid32 (measured bf16 worst case 6.6e-3, profiles/round2_bf16_output_error.md;
-      the object-query stream runs in fp32 in bf16 mode, which halved the round-1 errors).  ONE relaxed case, justified in
-      DESIGN.md §3: the full-depth cfg2 goldens (6 layers, L = 6272) in bf16 — boxes still 1e-2 (measured 1.1e-3), logits
-      2e-2 absolute and 1e-2 rms (measured 1.27e-2 max, 6.7e-3 rms on logits of magnitude <= 1.0).  A CPU emulation of
-      the rounding sites attributes 6.8e-3 of that 7.1e-3 rms to the bf16 rounding of the WEIGHTS alone (a coherent
-      perturbation of every token, which attention and LayerNorm do not average out; operand rounding of the activations
-      contributes 6e-5): it is the price of bf16 weights at this depth, not a kernel error — fp32 is 1e-6 on the same case.
+      |diff| <= 1e-3 fp32 / 1e-2 bf16 on EVERY case, including the two full-depth cfg2 goldens (6 layers, L = 6272) that are the
+      (config, dtype) bench.py times.  Round 2 needed 2e-2 there (measured 1.27e-2): the bf16 rounding of the value-projection
+      WEIGHTS shifted every token coherently; since round 3 those products use split hi + lo weights (ops.SPLIT_V,
+      profiles/round3_bf16_output_error.md).
     * Hungarian assignment: BIT-EXACT against the CPU oracle matcher (scipy restatement) run on the very
       outputs the product produced, every layer; and equal to the golden assignment whenever the outputs
       are close enough not to flip a near-tie (always in fp32).
@@ -583,8 +618,7 @@ def check_head_case(name, dtype, sinks=False):
     from tests.helpers import unpack_indices
     fp32 = dtype == torch.float32
     tol = 1e-3 if fp32 else 1e-2
-    deep = name.startswith('cfg2_b1') and not fp32      # the one relaxed case (docstring)
-    ltol = 2e-2 if deep else tol
+    ltol = tol
     res = {}
     z, meta, args, out, ld, tot, model, crit = run_head_case(name, dtype, sinks)
     tag = f'head/{name}/{"fp32" if fp32 else "bf16"}' + ('/sinks' if sinks else '')
@@ -592,8 +626,6 @@ def check_head_case(name, dtype, sinks=False):
         res[tag + '/buckets_incomplete'] = (float(sum(b['pending'] != 0 for b in model._test_reducer.buckets)), 0.0)
     dl = out['pred_logits'].cpu() - torch.from_numpy(z['pred_logits'])
     res[tag + '/pred_logits_abs'] = (float(dl.abs().max()), ltol)
-    if deep:
-        res[tag + '/pred_logits_rms'] = (float(dl.pow(2).mean().sqrt()), 1e-2)
     res[tag + '/pred_boxes_abs'] = (float((out['pred_boxes'].cpu() - torch.from_numpy(z['pred_boxes'])).abs().max()), tol)
     if 'aux_logits' in z.files:
         al = torch.stack([a['pred_logits'] for a in out['aux_outputs']]).cpu()
@@ -623,14 +655,17 @@ def check_head_case(name, dtype, sinks=False):
     if fp32:
         res[tag + '/assignment_vs_golden'] = (float(gm), 0.0)
     else:
+        # bf16 output noise may flip a near-tie of the assignment (both assignments then cost the same to ~1e-2): bounded — at most
+        # one video-layer in eight — and the matched loss is held to north_star's 1e-2 against the golden WHETHER OR NOT one flipped
         print(f'   note: {tag}: {gm} video-layer assignments differ from the golden (bf16 output noise flips near-ties)')
+        res[tag + '/assignment_flips_vs_golden'] = (float(gm), float(max(1, (nl * meta['B']) // 8)))
+    res[tag + '/loss_total'] = (abs(float(tot) - float(z['loss_total'])), tol * max(1.0, abs(float(z['loss_total']))))
     if gm == 0:
         names = str(z['loss_names']).split('\n')
         for k, v in zip(names, z['loss_values']):
             if 'class_error' in k:
                 continue
             res[tag + '/' + k] = (abs(float(ld[k]) - v), tol * max(1.0, abs(v)))
-        res[tag + '/loss_total'] = (abs(float(tot) - float(z['loss_total'])), tol * max(1.0, abs(float(z['loss_total']))))
         gtol = 2e-3 if fp32 else 0.25  # bf16: ReLU masks flip where |pre-activation| ~ bf16 noise (measured <= 0.16)
         gmax = 0.0
         for k in z.files:

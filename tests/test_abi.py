@@ -25,7 +25,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(L, n), f'{n} declared in include/svol_hip.h but not exported'
     assert set(_lib.SIGNATURES) | {'svol_abi_version', 'svol_strerror'} == set(names)
-    assert L.svol_abi_version() == 2
+    assert L.svol_abi_version() == 3
     assert b'invalid' in L.svol_strerror(-1)
 
 

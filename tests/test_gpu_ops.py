@@ -20,11 +20,15 @@ def G():
 
 def test_native_library_loaded():
     from svol_amd import _lib
-    assert _lib.lib().svol_abi_version() == 2
+    assert _lib.lib().svol_abi_version() == 3
 
 
 def test_gemm_nt(G):
     _assert(G.check_gemm_nt())
+
+
+def test_gemm_nt_split_weights(G):
+    _assert(G.check_gemm_split())
 
 
 def test_gemm_nt_dgelu_fused(G):
