@@ -281,7 +281,8 @@ def main():
                 import glob
                 import re
                 pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
-                files = sorted(glob.glob(os.path.join(pdir, 'round*_hbm_traffic.json')),
+                files = sorted((f_ for f_ in glob.glob(os.path.join(pdir, 'round*_hbm_traffic.json'))
+                                if re.fullmatch(r'round\d+_hbm_traffic\.json', os.path.basename(f_))),   # (not the cfg5 file)
                                key=lambda f_: int(re.search(r'round(\d+)_', os.path.basename(f_)).group(1)))
                 tj = json.load(open(files[-1]))
                 meta = tj.pop('_meta', {})

@@ -305,6 +305,117 @@ int svol_attn_weights_mean(const void* q, int64_t ldq, const void* k, int64_t ld
 int svol_attn_small_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo,
                         int64_t n_seq, int64_t H, int64_t L, int64_t dh, float scale, int dtype, void* stream);
 
+
+/* ---- composite block programs (round 3: the host off the critical path) ---------------------------------------------
+ * One C call enqueues a whole block of a CrossModalTransformerLayer (cross_modal_transformer.py:105-160) — the same kernels,
+ * in the same order, that the per-op entry points above would launch — so the Python host issues ~3 calls per layer and
+ * direction instead of ~50 (a ctypes call + a torch.empty + an autograd node per kernel was 19.6 ms of host time for a 20.8 ms
+ * step).  Nothing is allocated inside: every buffer (inputs, parameters, compute-dtype weight copies, tensors saved for
+ * backward, scratch, gradient targets) is a caller-owned DEVICE pointer in a slot table.
+ *
+ *   dims  : int64[SVOL_DIM_COUNT], see SVOL_DIM_* ;  slots : void*[SVOL_xx_COUNT], see the SVOL_xx_SLOTS lists below.
+ *   *_fwd  : forward.      *_bwd : the dX chain of backward (phase: 0 = all, 1 = the part in front of the large attention
+ *   backward, 2 = the rest — so the caller can release queued weight-gradient work right before that launch).
+ *   *_wgrad: the weight-gradient GEMMs of the block (dW += dY^T X with fp32 atomics into the gradient targets), separate so
+ *   that the caller can put them on another stream, later.  Gradient targets are ACCUMULATED INTO (caller zeroes).
+ * Layouts: activations [B*L, D] / [B*N, D] row-major; "dt" = element type SVOL_DIM_DTYPE of the video tokens, "qdt" =
+ * SVOL_DIM_QDTYPE of the object-query stream (fp32 in the bf16 model: ops.QUERY_FP32); f32 = float whatever the dtypes.
+ * Optional slots may be NULL where noted.  EV_* slots: optional hipEvent_t handles recorded around the large attention launch
+ * (bench.py's live roofline figure). */
+#define SVOL_DIM_B 0
+#define SVOL_DIM_L 1        /* video tokens per sample */
+#define SVOL_DIM_N 2        /* object queries per sample */
+#define SVOL_DIM_D 3
+#define SVOL_DIM_H 4
+#define SVOL_DIM_F 5        /* MLP hidden width */
+#define SVOL_DIM_DTYPE 6
+#define SVOL_DIM_QDTYPE 7
+#define SVOL_DIM_ATTN_WS_BYTES 8   /* size of the ATTN_WS slot */
+#define SVOL_DIM_COUNT 9
+
+#define SVOL_BLK_VIDEO_HALF 0
+#define SVOL_BLK_QUERY_SELF 1
+#define SVOL_BLK_QUERY_CROSS 2
+/* comma-separated slot names of a block, in index order (the host builds its name -> index map from this) */
+const char* svol_block_slot_names(int block);
+
+/* video half (:122-143): gate -> LN1 ; q|k, v projections, self-attention, out-proj + residual -> LN2 ; fc1+GELU, fc2 + residual
+ * -> LN3 (+pos).  M = B*L rows.
+ *  in : X32 f32 [M,D] · POS dt [M,D] · U f32 [B,H,D] (svol_gate_vectors_fwd)
+ *  par: G1,BT1,G2,BT2,G3,BT3 f32 [D] (norm weight, bias) · B_IN f32 [3D] · B_O [D] · B_FC1 [F] · B_FC2 [D] · QSCALE f32 [2D] or NULL
+ *  w  : W_IN dt [3D,D] · WV_HILO bf16 [D,2D] or NULL · W_O dt [D,D] · W_FC1 dt [F,D] · W_FC2 dt [D,F] and the transposes
+ *       W_IN_T [D,3D] · W_O_T · W_FC1_T [D,F] · W_FC2_T [F,D]
+ *  sav: Y1, Y1POS dt [M,D] · A, MEAN1, RSTD1 f32 [M] · GATE_WS f32 [B*H*(L+2)] · QKV dt [M,3D] · O dt [M,D] · LSE f32 [B,H,L] ·
+ *       S2 f32 [M,D] · Y2 dt [M,D] · MEAN2, RSTD2 · PRE, HID dt [M,F] · S3 f32 [M,D] · MEAN3, RSTD3
+ *  out: M32 f32, M dt, MPOS dt [M,D]          scr: Y1_32, Y2_32 f32 [M,D] · ATTN_WS
+ *  bwd in : DM32 f32, DM dt, DMPOS dt (each may be NULL, not all)
+ *  bwd tmp: DS32_3 f32, DS3 dt [M,D] · DPRE dt [M,F] · DY2 dt · DS32_2 f32 · G2D dt · DO dt [M,D] · DQKV dt [M,3D] ·
+ *           DELTA f32 [3,B,H,L] · DXQP, DXQ dt [M,D] · GATE_WS2 f32 [B*L + B*H]
+ *  bwd out: DX32 f32 [M,D] · DU f32 [B,H,D] (caller zeroes)
+ *  grads  : DG1,DBT1,DG2,DBT2,DG3,DBT3 · DW_IN [3D,D], DB_IN · DW_O, DB_O · DW_FC1, DB_FC1 · DW_FC2, DB_FC2 (f32, accumulated) */
+#define SVOL_VH_SLOTS(X) \
+    X(X32) X(POS) X(U) X(G1) X(BT1) X(G2) X(BT2) X(G3) X(BT3) X(B_IN) X(B_O) X(B_FC1) X(B_FC2) X(QSCALE) \
+    X(W_IN) X(WV_HILO) X(W_O) X(W_FC1) X(W_FC2) X(W_IN_T) X(W_O_T) X(W_FC1_T) X(W_FC2_T) \
+    X(Y1) X(Y1POS) X(A) X(MEAN1) X(RSTD1) X(GATE_WS) X(QKV) X(O) X(LSE) X(S2) X(Y2) X(MEAN2) X(RSTD2) X(PRE) X(HID) X(S3) \
+    X(MEAN3) X(RSTD3) X(M32) X(M) X(MPOS) X(Y1_32) X(Y2_32) X(ATTN_WS) \
+    X(DM32) X(DM) X(DMPOS) X(DS32_3) X(DS3) X(DPRE) X(DY2) X(DS32_2) X(G2D) X(DO) X(DQKV) X(DELTA) X(DXQP) X(DXQ) X(GATE_WS2) \
+    X(DX32) X(DU) \
+    X(DG1) X(DBT1) X(DG2) X(DBT2) X(DG3) X(DBT3) X(DW_IN) X(DB_IN) X(DW_O) X(DB_O) X(DW_FC1) X(DB_FC1) X(DW_FC2) X(DB_FC2) \
+    X(EV_A0) X(EV_A1)
+/* query self-attention (:145-147): packed q|k, v projections of the N queries, self-attention, out-proj + residual -> LN4 (+query_pos).
+ * R = B*N rows, everything in qdt.
+ *  in : O32 f32, O qdt, OPOS qdt [R,D] · QPOS qdt [N,D]
+ *  par: B_IN f32 [3D], B_O, G4, BT4 · QSCALE or NULL        w: W_IN qdt [3D,D], WV_HILO (bf16 queries only) or NULL, W_O, W_IN_T, W_O_T
+ *  sav: QKV qdt [R,3D] · OA qdt [R,D] · LSE f32 [B,H,N] · S4 f32 [R,D] · MEAN4, RSTD4 [R]      out: Y32 f32, Y qdt, YPOS qdt [R,D]
+ *  scr: ATTN_WS       bwd in: DY32, DY, DYPOS (each may be NULL)
+ *  bwd tmp: G qdt [R,D] · DOA qdt · DQKV qdt [R,3D] · DELTA f32 [3,B,H,N]
+ *  bwd out: DO32 f32 [R,D] (residual path) · DXQ qdt (through v) · DXQP qdt (through q, k) · DQPOS f32 [N,D] or NULL (caller zeroes)
+ *  grads  : DW_IN, DB_IN, DW_O, DB_O, DG4, DBT4 */
+#define SVOL_QS_SLOTS(X) \
+    X(O32) X(O) X(OPOS) X(QPOS) X(B_IN) X(B_O) X(G4) X(BT4) X(QSCALE) X(W_IN) X(WV_HILO) X(W_O) X(W_IN_T) X(W_O_T) \
+    X(QKV) X(OA) X(LSE) X(S4) X(MEAN4) X(RSTD4) X(Y32) X(Y) X(YPOS) X(ATTN_WS) \
+    X(DY32) X(DY) X(DYPOS) X(G) X(DOA) X(DQKV) X(DELTA) X(DO32) X(DXQ) X(DXQP) X(DQPOS) \
+    X(DW_IN) X(DB_IN) X(DW_O) X(DB_O) X(DG4) X(DBT4)
+/* query -> video cross-attention + MLP2 (:151-158): q projection of the queries (qdt), k / v projections of the L video tokens
+ * (dt; v with split weights), attention with the additive key mask, out-proj + residual -> LN5 ; fc1+GELU, fc2 + residual ->
+ * LN6 (+query_pos).  R = B*N, M = B*L.  qdt != dt ("mixed": fp32 queries over bf16 video tokens): q and the attention output
+ * cross the boundary through one cast each.
+ *  in : O32 f32, O qdt, OPOS qdt [R,D] · MV dt [M,D] (values from) · MPOS dt [M,D] (keys from) · KBIAS f32 [B,L] · QPOS qdt [N,D]
+ *  par: B_IN f32 [3D] · B_O · G5, BT5 · B_FC1 [F] · B_FC2 · G6, BT6 · QSCALE f32 [>= D] or NULL
+ *  w  : W_INQ qdt [3D,D] (rows 0..D-1 used) · W_INQ_T qdt [D,3D] · W_KV dt [3D,D] (rows D.. used) · W_KV_T dt [D,3D] · WV_HILO or NULL ·
+ *       W_O, W_O_T qdt [D,D] · W_FC1 qdt [F,D] · W_FC1_T [D,F] · W_FC2 qdt [D,F] · W_FC2_T [F,D]
+ *  sav: Q qdt [R,D] (mixed only) · QC dt [R,D] · KV dt [M,2D] · OA dt [R,D] · OAQ qdt [R,D] (mixed only) · LSE f32 [B,H,N] · S5 f32 ·
+ *       Y5_32 f32, Y5 qdt · MEAN5, RSTD5 · PRE, HID qdt [R,F] · S6 f32 · MEAN6, RSTD6        out: Y32 f32, Y qdt, YPOS qdt
+ *  scr: ATTN_WS       bwd in: DY32, DY, DYPOS
+ *  bwd tmp: DS32_6 f32, DS6 qdt [R,D] · DPRE qdt [R,F] · DY5 qdt · G5D qdt · DOAQ qdt · DOA dt · DQC dt [R,D] · DQ qdt (mixed only) ·
+ *           DKV dt [M,2D] · DELTA f32 [3,B,H,N]
+ *  bwd out: DO32 f32 [R,D] · DXQP qdt [R,D] · DMPOS dt [M,D] (through k) · DMV dt [M,D] (through v) · DQPOS f32 [N,D] or NULL
+ *  grads  : DW_IN [3D,D], DB_IN · DW_O, DB_O · DG5, DBT5 · DW_FC1, DB_FC1 · DW_FC2, DB_FC2 · DG6, DBT6 */
+#define SVOL_QC_SLOTS(X) \
+    X(O32) X(O) X(OPOS) X(MV) X(MPOS) X(KBIAS) X(QPOS) X(B_IN) X(B_O) X(G5) X(BT5) X(B_FC1) X(B_FC2) X(G6) X(BT6) X(QSCALE) \
+    X(W_INQ) X(W_INQ_T) X(W_KV) X(W_KV_T) X(WV_HILO) X(W_O) X(W_O_T) X(W_FC1) X(W_FC1_T) X(W_FC2) X(W_FC2_T) \
+    X(Q) X(QC) X(KV) X(OA) X(OAQ) X(LSE) X(S5) X(Y5_32) X(Y5) X(MEAN5) X(RSTD5) X(PRE) X(HID) X(S6) X(MEAN6) X(RSTD6) \
+    X(Y32) X(Y) X(YPOS) X(ATTN_WS) \
+    X(DY32) X(DY) X(DYPOS) X(DS32_6) X(DS6) X(DPRE) X(DY5) X(DS32_5) X(G5D) X(DOAQ) X(DOA) X(DQC) X(DQ) X(DKV) X(DELTA) \
+    X(DO32) X(DXQP) X(DMPOS) X(DMV) X(DQPOS) \
+    X(DW_IN) X(DB_IN) X(DW_O) X(DB_O) X(DG5) X(DBT5) X(DW_FC1) X(DB_FC1) X(DW_FC2) X(DB_FC2) X(DG6) X(DBT6)
+#define SVOL_SLOT_ENUM_VH(n) SVOL_VH_##n,
+#define SVOL_SLOT_ENUM_QS(n) SVOL_QS_##n,
+#define SVOL_SLOT_ENUM_QC(n) SVOL_QC_##n,
+enum { SVOL_VH_SLOTS(SVOL_SLOT_ENUM_VH) SVOL_VH_COUNT };
+enum { SVOL_QS_SLOTS(SVOL_SLOT_ENUM_QS) SVOL_QS_COUNT };
+enum { SVOL_QC_SLOTS(SVOL_SLOT_ENUM_QC) SVOL_QC_COUNT };
+
+int svol_video_half_fwd(const int64_t* dims, void* const* slots, void* stream);
+int svol_video_half_bwd(const int64_t* dims, void* const* slots, int phase, void* stream);
+int svol_video_half_wgrad(const int64_t* dims, void* const* slots, void* stream);
+int svol_query_self_fwd(const int64_t* dims, void* const* slots, void* stream);
+int svol_query_self_bwd(const int64_t* dims, void* const* slots, void* stream);
+int svol_query_self_wgrad(const int64_t* dims, void* const* slots, void* stream);
+int svol_query_cross_fwd(const int64_t* dims, void* const* slots, void* stream);
+int svol_query_cross_bwd(const int64_t* dims, void* const* slots, void* stream);
+int svol_query_cross_wgrad(const int64_t* dims, void* const* slots, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

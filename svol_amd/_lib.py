@@ -61,6 +61,16 @@ SIGNATURES = {
     'svol_match_cost': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _f32, _f32, _f32, _p, _p],
     'svol_lsap_batched': [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p],
     'svol_set_loss': [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _f32, _p, _i32, _p, _p, _i32, _p],
+    # composite block programs: (dims int64[], slots void*[], [phase,] stream)
+    'svol_video_half_fwd': [_p, _p, _p],
+    'svol_video_half_bwd': [_p, _p, _int, _p],
+    'svol_video_half_wgrad': [_p, _p, _p],
+    'svol_query_self_fwd': [_p, _p, _p],
+    'svol_query_self_bwd': [_p, _p, _p],
+    'svol_query_self_wgrad': [_p, _p, _p],
+    'svol_query_cross_fwd': [_p, _p, _p],
+    'svol_query_cross_bwd': [_p, _p, _p],
+    'svol_query_cross_wgrad': [_p, _p, _p],
 }
 
 _LIB = None
@@ -88,6 +98,8 @@ def lib():
             f.restype = _int
             f.argtypes = at
         L.svol_attn_ws_bytes.restype = _i64
+        L.svol_block_slot_names.restype = ctypes.c_char_p
+        L.svol_block_slot_names.argtypes = [_int]
         _LIB = L
     return _LIB
 

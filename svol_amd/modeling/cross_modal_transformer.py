@@ -29,7 +29,7 @@ import os
 import torch
 from torch import nn
 
-from .. import ops
+from .. import blocks, ops
 
 D_FF = 2048  # the reference hard-codes dim_feedforward=2048 here and ignores --dim_feedforward
 
@@ -145,6 +145,8 @@ class CrossModalTransformerLayer(nn.Module):
 
     def video_half(self, mem32, skch32, pos, u=None):
         """the "encoder-like" half, :122-143 -> (fp32 stream, compute-dtype copy, copy + pos)."""
+        if blocks.ENABLED:   # one C call for the whole half (svol_video_half_fwd), same kernels in the same order
+            return blocks.video_half(self, mem32, pos, self.gate_vectors(skch32) if u is None else u, pos.dtype)
         h = self.nhead
         n = lambda m: (m.weight, m.bias)
         mha = lambda m: (m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias)
@@ -155,10 +157,13 @@ class CrossModalTransformerLayer(nn.Module):
 
     def query_half(self, out, m, mpos, qpos, kbias):
         """the "decoder-like" half, :145-158: object queries attend to themselves, then to the video tokens."""
-        return self.query_cross(self.query_self(out, qpos), m, mpos, qpos, kbias)
+        return self.query_cross(self.query_self(out, qpos, m.dtype), m, mpos, qpos, kbias)
 
-    def query_self(self, out, qpos):
-        """:145-147: query self-attention + norm4 — needs only the previous layer's queries, not this layer's video tokens."""
+    def query_self(self, out, qpos, dt=None):
+        """:145-147: query self-attention + norm4 — needs only the previous layer's queries, not this layer's video tokens.
+        dt: element type of the video tokens (the block plans are keyed by it)."""
+        if blocks.ENABLED:
+            return blocks.query_self(self, out, qpos, dt if dt is not None else qpos.dtype, qpos.dtype)
         n = lambda m_: (m_.weight, m_.bias)
         mha = lambda m_: (m_.in_proj_weight, m_.in_proj_bias, m_.out_proj.weight, m_.out_proj.bias)
         o32, o, opos = out
@@ -169,6 +174,8 @@ class CrossModalTransformerLayer(nn.Module):
         n = lambda m_: (m_.weight, m_.bias)
         mha = lambda m_: (m_.in_proj_weight, m_.in_proj_bias, m_.out_proj.weight, m_.out_proj.bias)
         mlp = lambda m_: (m_.fc1.weight, m_.fc1.bias, m_.fc2.weight, m_.fc2.bias)
+        if blocks.ENABLED:
+            return blocks.query_cross(self, out, m, mpos, kbias, qpos, m.dtype, qpos.dtype)
         o32, o, opos = out
         o32, o = ops.cross_attn_ln(o32, o, opos, mpos, m, *mha(self.content_token_cross_attn), *n(self.norm5), None, self.nhead,
                                    kbias)
@@ -234,7 +241,7 @@ class CrossModalTransformer(nn.Module):
             # issued and runs under it; only the cross-attention waits for the video tokens (the last layer's tail is shorter
             # by that block)
             with torch.cuda.stream(side):
-                out_sa = layer.query_self(out, qpos)
+                out_sa = layer.query_self(out, qpos, vid_pos.dtype)
             m32, m, mpos = layer.video_half(mem32, src_skch32, vid_pos, u)
             side.wait_stream(main)
             m.record_stream(side)

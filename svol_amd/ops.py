@@ -220,17 +220,41 @@ def _wgrad_stream(dev):
 
 
 def flush_wgrad():
-    """issue every queued weight-gradient GEMM on the weight-gradient stream (behind the event recorded when it was queued)."""
+    """issue every queued weight-gradient launch (callables that put it on the weight-gradient stream behind the event recorded when
+    it was queued)."""
     if not _WGRAD_PENDING:
         return
     items = list(_WGRAD_PENDING)
     _WGRAD_PENDING.clear()
-    for A, B, out, colsum, ev in items:
-        ws = _wgrad_stream(A.device)
-        ws.wait_event(ev)
-        gemm_tn(A, B, out=out, colsum=colsum, stream=ws.cuda_stream)   # (explicit handle: no current-stream switch on the host)
-        A.record_stream(ws)
-        B.record_stream(ws)
+    for it in items:
+        it()
+
+
+_FLUSH_ARMED = [False]
+
+
+def _final_flush():
+    _FLUSH_ARMED[0] = False
+    flush_wgrad()
+
+
+def arm_wgrad_flush():
+    """called when something is queued during a backward: make the autograd engine drain the queue before ``backward()`` returns, so
+    a caller that never reaches ``BucketedGradAllReduce.finish()`` (an exception, a skipped batch) cannot leak a failed step's
+    weight-gradient GEMMs into the next step's freshly zeroed buckets."""
+    if _FLUSH_ARMED[0]:
+        return
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_final_flush)
+        _FLUSH_ARMED[0] = True
+    except RuntimeError:   # not inside a backward pass: finish() / the next flush point drains the queue
+        pass
+
+
+def drop_pending_wgrad():
+    """a new step starts: whatever a FAILED backward left queued must not run into this step's buffers."""
+    _WGRAD_PENDING.clear()
+    _FLUSH_ARMED[0] = False
 
 
 def gemm_tn_sink(A, B, out, colsum=None):
@@ -239,16 +263,21 @@ def gemm_tn_sink(A, B, out, colsum=None):
     if not WGRAD_ASYNC or (not WGRAD_IN_CAPTURE and torch.cuda.is_current_stream_capturing()):
         return gemm_tn(A, B, out=out, colsum=colsum)
     cur = _current_stream_obj()
+    ev = torch.cuda.Event()
+    ev.record(cur)
+
+    def later():
+        ws = _wgrad_stream(A.device)
+        ws.wait_event(ev)
+        gemm_tn(A, B, out=out, colsum=colsum, stream=ws.cuda_stream)   # (explicit handle: no current-stream switch on the host)
+        A.record_stream(ws)
+        B.record_stream(ws)
+
     if WGRAD_DEFER and _BIG_ATTN['left'] > 0 and not torch.cuda.is_current_stream_capturing():
-        ev = torch.cuda.Event()
-        ev.record(cur)
-        _WGRAD_PENDING.append((A, B, out, colsum, ev))
-        return out
-    ws = _wgrad_stream(A.device)
-    ws.wait_stream(cur)
-    gemm_tn(A, B, out=out, colsum=colsum, stream=ws.cuda_stream)   # (explicit handle: no current-stream switch on the host)
-    A.record_stream(ws)
-    B.record_stream(ws)
+        _WGRAD_PENDING.append(later)
+        arm_wgrad_flush()
+    else:
+        later()
     return out
 
 
@@ -470,6 +499,8 @@ class _WeightCache:
 
     def new_epoch(self):
         _BIG_ATTN['left'] = 0   # a new forward starts (see gemm_tn_sink)
+        if not torch.is_grad_enabled() or not _FLUSH_ARMED[0]:
+            drop_pending_wgrad()   # (an armed flush belongs to a backward that is still running: leave it alone)
         if self.static:
             return
         self.epoch += 1
@@ -615,10 +646,13 @@ weights = _WeightCache()
 # autograd runs the AccumulateGrad node with an undefined gradient after the producing Function has finished.
 # ----------------------------------------------------------------------------
 class GradSink:
-    __slots__ = ('view',)
+    """view: the parameter's slice of a flat gradient bucket.  owner / bucket: who to tell that the gradient is complete when the
+    producing Function keeps the parameter OUT of the autograd graph (svol_amd.blocks: no AccumulateGrad node, no hook) —
+    ``owner.params_done(bucket, n)``."""
+    __slots__ = ('view', 'owner', 'bucket')
 
-    def __init__(self, view):
-        self.view = view
+    def __init__(self, view, owner=None, bucket=-1):
+        self.view, self.owner, self.bucket = view, owner, bucket
 
 
 def _claim(p, needed=True):

@@ -106,7 +106,7 @@ class BucketedGradAllReduce:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
                 # the svol kernels accumulate weight / bias / LayerNorm gradients straight into the bucket view
                 # (svol_amd.ops "gradient sinks"); the hook above still fires for them
-                p._svol_sink = GradSink(p.grad)
+                p._svol_sink = GradSink(p.grad, self, bi)
 
     def _make_bucket(self, params):
         # every tensor starts on a 16-byte boundary (the kernels take 16-byte vector accesses on gradients and — FlatAdamW —
@@ -129,6 +129,15 @@ class BucketedGradAllReduce:
             if b['pending'] == 0:
                 self._launch(b)
         return hook
+
+    def params_done(self, bi, n=1):
+        """`n` parameters of bucket `bi` have their complete gradient enqueued (or queued for the weight-gradient stream): what the
+        per-parameter hooks do, for producers that write into the bucket without an autograd edge to the parameter (svol_amd.blocks)."""
+        b = self.buckets[bi]
+        self.fire_order.extend([bi] * n)
+        b['pending'] -= n
+        if b['pending'] == 0:
+            self._launch(b)
 
     def _producer_streams(self):
         """every stream a gradient of a bucket can have been written on: the caller's compute stream (video half,
@@ -168,6 +177,8 @@ class BucketedGradAllReduce:
         """Zero the flat buckets (replaces optimizer.zero_grad(); keeps the grad views alive)."""
         if self.on_gpu:
             self.main_stream = torch.cuda.current_stream(self.device)
+            from . import ops
+            ops.drop_pending_wgrad()   # weight-gradient launches a failed backward left queued must not land in the zeroed buckets
         self.fire_order = []
         for b in self.buckets:
             b['flat'].zero_()

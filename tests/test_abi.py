@@ -24,7 +24,12 @@ def test_header_symbols_exported():
     assert len(names) >= 18
     for n in names:
         assert hasattr(L, n), f'{n} declared in include/svol_hip.h but not exported'
-    assert set(_lib.SIGNATURES) | {'svol_abi_version', 'svol_strerror'} == set(names)
+    assert set(_lib.SIGNATURES) | {'svol_abi_version', 'svol_strerror', 'svol_block_slot_names'} == set(names)
+    # the composite block programs reject null tables before any launch
+    for fn in ('svol_video_half_fwd', 'svol_query_self_fwd', 'svol_query_cross_fwd', 'svol_query_cross_wgrad'):
+        assert getattr(L, fn)(0, 0, 0) == -1
+    for blk, first in ((0, 'X32'), (1, 'O32'), (2, 'O32')):
+        assert L.svol_block_slot_names(blk).decode().split(',')[0] == first
     assert L.svol_abi_version() == 3
     assert b'invalid' in L.svol_strerror(-1)
 
