@@ -77,7 +77,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
+    ap.add_argument('--loss-scale', type=float, default=None,
+                    help='static loss scale (default: 1024 with --dtype fp16 — fp16 gradients of ~1e-6 underflow otherwise; the reference '
+                         'uses apex amp dynamic scaling for fp16 — else 1); folded back out inside the AdamW kernel')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true',
                     help='N=1 only: replay the whole step as one captured hipGraph (removes the ~15 ms/step of host issue time, '
@@ -190,6 +193,10 @@ def main():
         pix_video = torch.randn((B, T, 3, 224, 224), device=dev, generator=g)
         pix_sketch = torch.randn((B, 1, 3, 224, 224), device=dev, generator=g)
 
+    loss_scale = a.loss_scale if a.loss_scale is not None else (1024.0 if a.dtype == 'fp16' else 1.0)
+    if not use_graph:
+        opt.loss_scale = loss_scale
+
     def step():
         reducer.zero_grad()
         if backbone is not None:
@@ -198,8 +205,8 @@ def main():
         out = model(inp['src_sketch'], inp['src_sketch_mask'], inp['src_video'], inp['src_video_mask'])
         ld = crit(out, tg)
         loss = crit.weighted_total()  # = sum(ld[k] * wd[k] for k in ld if k in wd) (train.py:227-228), one multiply + one reduction
-        loss.backward()
-        reducer.finish()
+        (loss * loss_scale if loss_scale != 1.0 else loss).backward()
+        reducer.finish(mean=use_graph)   # the 1 / world of the gradient mean rides FlatAdamW's update kernel
         opt.step()
         return loss
 
@@ -221,8 +228,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host_ms = []
     for _ in range(a.steps):
+        ts = time.perf_counter()
         loss = step()
+        host_ms.append((time.perf_counter() - ts) * 1e3)
     t_issued = time.perf_counter() - t0   # the host has ISSUED every step; the GPU is still running them
     torch.cuda.synchronize()
     if world > 1:
@@ -322,7 +332,11 @@ def main():
             'n_ranks_seen': n_ranks_seen, 'dist_backend': backend if world > 1 else None,
             'final_loss': final_loss,
             # host time to ISSUE a step (Python + launches, no sync): when it approaches ms_per_step the run is host-bound
-            'host_issue_ms_per_step': t_issued / a.steps * 1e3,
+            # median over the timed steps: once the host is ~10 steps ahead the HIP queue pushes back and a step's host time becomes
+            # the GPU's (the mean includes those; both are reported)
+            'host_issue_ms_per_step': sorted(host_ms)[len(host_ms) // 2],
+            'host_issue_ms_per_step_mean': t_issued / a.steps * 1e3,
+            'host_issue_ms_first_last': [round(x, 2) for x in host_ms[:3] + host_ms[-3:]],
             'launch_mode': 'hipGraph replay (whole step captured)' if use_graph else 'eager',
         }
         if roof:

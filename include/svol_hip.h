@@ -30,6 +30,8 @@ extern "C" {
 
 #define SVOL_F32 0
 #define SVOL_BF16 1
+#define SVOL_F16 2  /* fp16 operands (v_mfma_*_f16), fp32 accumulate / statistics: the GEMM, LayerNorm, gate and attention entry
+                       points of the SVANet path; the ViT / ResNet / enc-dec-only entry points take SVOL_F32 / SVOL_BF16 */
 
 #define SVOL_OK 0
 #define SVOL_E_INVALID (-1)     /* null pointer / bad size / misaligned          */

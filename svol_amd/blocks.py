@@ -26,7 +26,7 @@ from . import _lib, ops
 ENABLED = os.environ.get('SVOL_NO_BLOCKS') is None
 VH, QS, QC = 0, 1, 2
 _F32, _BF16 = 0, 1
-_ESZ = {torch.float32: 4, torch.bfloat16: 2}
+_ESZ = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2}
 _SLOTS = {}
 
 
@@ -106,12 +106,11 @@ def _scratch(dev, nbytes):
 
 
 def _dims(B, L, N, D, H, F, dt, qdt, ws_bytes):
-    return (ctypes.c_int64 * 9)(B, L, N, D, H, F, _F32 if dt == torch.float32 else _BF16, _F32 if qdt == torch.float32 else _BF16,
-                                ws_bytes)
+    return (ctypes.c_int64 * 9)(B, L, N, D, H, F, ops._DT[dt], ops._DT[qdt], ws_bytes)
 
 
 def _attn_ws_bytes(B, H, Lq, Lk, dh, dt):
-    n = _lib.lib().svol_attn_ws_bytes(B, H, Lq, Lk, dh) if dt == torch.bfloat16 else 0
+    n = _lib.lib().svol_attn_ws_bytes(B, H, Lq, Lk, dh) if dt != torch.float32 else 0
     return max(int(n), 0)
 
 
@@ -164,7 +163,7 @@ class BlockPlan:
             self.keep += [wc, wt]
 
         def qscale(dtype, n):
-            if dtype != torch.bfloat16:
+            if dtype == torch.float32:
                 return None
             q = ops._qscale(D, ops.LOG2E / math.sqrt(D // layer.nhead), dev)
             self.keep.append(q)

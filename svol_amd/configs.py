@@ -6,8 +6,8 @@ reference command line parses unchanged.  Differences, all additive:
 
 * the table below is data, parsed on demand — ``configs.args`` is resolved lazily
   on first attribute access (the reference parses at import time, configs.py:179);
-* ``--compute_dtype {bf16,fp32}`` selects the kernel element type (the
-  reference's only precision knob is apex ``--opt-level``; ``O0`` = fp32);
+* ``--compute_dtype {bf16,fp16,fp32}`` selects the kernel element type (the
+  reference's only precision knob is apex ``--opt-level``; ``O0`` = fp32; fp16: the SVANet head only, BASELINE configs[4]);
 * ``--backbone features`` feeds pre-extracted frame / sketch features straight
   to the head (the measured boundary, SURVEY.md D3);
 * ``--enc_layers --dec_layers --mode --feat_dim`` and ``--sketch_head svanet_variants``: what the reference's enc/dec
@@ -103,7 +103,7 @@ _OPTIONS = [
 
 # additive, build-specific options (not part of the reference surface)
 _EXTRA = [
-    (('--compute_dtype',), dict(type=str, default='bf16', choices=['bf16', 'fp32'],
+    (('--compute_dtype',), dict(type=str, default='bf16', choices=['bf16', 'fp16', 'fp32'],
                                 help='element type of the HIP kernels (fp32 accumulate either way)')),
     (('--input_vid_dim',), dict(type=int, default=512, help='feature width with --backbone features')),
     (('--input_skch_dim',), dict(type=int, default=512, help='feature width with --backbone features')),

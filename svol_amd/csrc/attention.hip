@@ -432,12 +432,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
 
 int check_common(int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t dh, int dtype) {
     if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || dh <= 0) return SVOL_E_INVALID;
-    if (dtype != SVOL_BF16 && dtype != SVOL_F32) return SVOL_E_INVALID;
+    if (!svol_is16(dtype) && dtype != SVOL_F32) return SVOL_E_INVALID;
     if (dh > 32 || dh % 8) return SVOL_E_UNSUPPORTED;
     if (B > 65535 || H > 65535 || Lq > (1 << 24) || Lk > (1 << 24)) return SVOL_E_UNSUPPORTED;
     return SVOL_OK;
 }
-bool ld_ok(int64_t ld, int dtype) { return ld % (dtype == SVOL_BF16 ? 8 : 4) == 0; }
+bool ld_ok(int64_t ld, int dtype) { return ld % (svol_is16(dtype) ? 8 : 4) == 0; }
 
 }  // namespace
 
@@ -452,6 +452,15 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
                               hipStream_t s);
 
 int64_t svol_attn_ws_floats_bf16(int B, int H, int Lq, int Lk, int dh);
+// the same kernels compiled with fp16 operands (attention_bf16.hip with -DSVOL_H16_FP16)
+int svol_attn_fwd_f16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
+                             int64_t ldo, float* lse2, const float* kbias, int B, int H, int Lq, int Lk, int dh, float scale,
+                             float premul, float* ws, int64_t ws_bytes, hipStream_t s);
+int svol_attn_bwd_f16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                             const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta,
+                             const float* kbias, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int B,
+                             int H, int Lq, int Lk, int dh, float scale, float premul, float* ws, int64_t ws_bytes,
+                             hipStream_t s);
 
 extern "C" {
 
@@ -474,9 +483,10 @@ int svol_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const 
     p.B = (int)B; p.H = (int)H; p.Lq = (int)Lq; p.Lk = (int)Lk; p.dh = (int)dh; p.scale = scale; p.premul = q_premul;
     dim3 grid((unsigned)((Lq + 127) / 128), (unsigned)H, (unsigned)B);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == SVOL_BF16)
-        return svol_attn_fwd_bf16_launch(q, ldq, k, ldk, v, ldv, o, ldo, lse2, kbias, (int)B, (int)H, (int)Lq, (int)Lk, (int)dh,
-                                         scale, q_premul, aligned16(ws) ? (float*)ws : nullptr, ws_bytes, s);
+    if (svol_is16(dtype))
+        return (dtype == SVOL_BF16 ? svol_attn_fwd_bf16_launch : svol_attn_fwd_f16_launch)(
+            q, ldq, k, ldk, v, ldv, o, ldo, lse2, kbias, (int)B, (int)H, (int)Lq, (int)Lk, (int)dh, scale, q_premul,
+            aligned16(ws) ? (float*)ws : nullptr, ws_bytes, s);
     hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), 0, s, p);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
@@ -505,10 +515,10 @@ int svol_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const 
     dim3 gd((unsigned)((total + 255) / 256));
     dim3 gq((unsigned)((Lq + 127) / 128), (unsigned)H, (unsigned)B);
     dim3 gk((unsigned)((Lk + 127) / 128), (unsigned)H, (unsigned)B);
-    if (dtype == SVOL_BF16)
-        return svol_attn_bwd_bf16_launch(q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse2, delta, kbias, dq, lddq, dk, lddk, dv,
-                                         lddv, (int)B, (int)H, (int)Lq, (int)Lk, (int)dh, scale, q_premul,
-                                         aligned16(ws) ? (float*)ws : nullptr, ws_bytes, s);
+    if (svol_is16(dtype))
+        return (dtype == SVOL_BF16 ? svol_attn_bwd_bf16_launch : svol_attn_bwd_f16_launch)(
+            q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse2, delta, kbias, dq, lddq, dk, lddk, dv, lddv, (int)B, (int)H, (int)Lq,
+            (int)Lk, (int)dh, scale, q_premul, aligned16(ws) ? (float*)ws : nullptr, ws_bytes, s);
     hipLaunchKernelGGL(attn_delta_kernel<float>, gd, dim3(256), 0, s, p);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, gq, dim3(256), 0, s, p);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<float>, gk, dim3(256), 0, s, p);

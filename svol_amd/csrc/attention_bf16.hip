@@ -47,14 +47,14 @@ struct Args {
     unsigned *nl2, *nd2;          // [B,H,Lq] -lse2 / -delta as (hi, lo) bf16 pairs: written by the fast dQ kernel, DMA'd by the dK/dV kernel
 };
 
-typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+typedef __attribute__((address_space(3))) h16x4* lds_bf16x4_ptr;
 
 __device__ __forceinline__ int img_off(int row, int ch) { return row * 64 + ((ch ^ ((row >> 2) & 3)) << 4); }
 
 struct Stage { uint4 v[2]; };
 
 // 128 rows x 4 chunks = 512 chunks, 2 per thread
-__device__ __forceinline__ void load_regs(Stage& s, const bf16_t* g, int64_t ld, int row0, int limit, int dh, int tid) {
+__device__ __forceinline__ void load_regs(Stage& s, const h16_t* g, int64_t ld, int row0, int limit, int dh, int tid) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int c = tid + 256 * i, row = c >> 2, ch = c & 3;
@@ -76,20 +76,20 @@ __device__ __forceinline__ void store_lds(char* img, const Stage& s, int tid) {
 // slot ^ ((row >> 2) & 3) = (i & 3) ^ ((i >> 4) & 3) of that row (img_off).  Rows must exist (callers: full tiles only).
 typedef __attribute__((address_space(3))) void* lds_vptr;
 typedef const __attribute__((address_space(1))) void* gbl_vptr;
-__device__ __forceinline__ void dma_piece(char* img, const bf16_t* g, int64_t ld, int row0, int piece, int lane) {
+__device__ __forceinline__ void dma_piece(char* img, const h16_t* g, int64_t ld, int row0, int piece, int lane) {
     const int row = 16 * piece + (lane >> 2);
     const int ch = (lane & 3) ^ ((lane >> 4) & 3);
-    const bf16_t* src = g + (int64_t)(row0 + row) * ld + ch * 8;
+    const h16_t* src = g + (int64_t)(row0 + row) * ld + ch * 8;
     __builtin_amdgcn_global_load_lds((gbl_vptr)src, (lds_vptr)(img + piece * 1024), 16, 0, 0);
 }
 // a whole 128-row tile by the four waves of a workgroup (two pieces each); `wave` must be wave-uniform (readfirstlane)
-__device__ __forceinline__ void dma_tile(char* img, const bf16_t* g, int64_t ld, int row0, int wave, int lane) {
+__device__ __forceinline__ void dma_tile(char* img, const h16_t* g, int64_t ld, int row0, int wave, int lane) {
     dma_piece(img, g, ld, row0, 2 * wave, lane);
     dma_piece(img, g, ld, row0, 2 * wave + 1, lane);
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-__device__ __forceinline__ void load_lane_block(uint4 (&out)[2], const bf16_t* g, int64_t ld, int row, bool valid, int dh,
+__device__ __forceinline__ void load_lane_block(uint4 (&out)[2], const h16_t* g, int64_t ld, int row, bool valid, int dh,
                                                 int h) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -113,8 +113,8 @@ __device__ __forceinline__ void read_tr(uint4 (&a)[2], const char* img, int sub,
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int r1 = 32 * sub + 16 * s + 4 * hh + q;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + img_off(r1, ch) + inner));
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + img_off(r1 + 8, ch) + inner));
+        const h16x4 lo = SVOL_DS_READ_TR16_H16((lds_bf16x4_ptr)(img + img_off(r1, ch) + inner));
+        const h16x4 hi = SVOL_DS_READ_TR16_H16((lds_bf16x4_ptr)(img + img_off(r1 + 8, ch) + inner));
         a[s] = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     }
 }
@@ -136,6 +136,10 @@ __device__ __forceinline__ void mfma_results_ready(f32x16& a, f32x16& b, f32x16&
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
+__device__ __forceinline__ void mfma_results_ready2(f32x16& a, f32x16& b) {
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a), "+v"(b));
+}
+
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll
@@ -147,7 +151,7 @@ __device__ __forceinline__ f32x16 mma_first(const uint4 (&a)[2], const uint4 (&b
     f32x16 acc = zero16();
 #pragma unroll
     for (int s = 0; s < 2; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[s]), __builtin_bit_cast(bf16x8, b[s]), acc, 0, 0,
+        acc = SVOL_MFMA_32x32x16_H16(__builtin_bit_cast(h16x8, a[s]), __builtin_bit_cast(h16x8, b[s]), acc, 0, 0,
                                                       0);
     return acc;
 }
@@ -155,24 +159,24 @@ __device__ __forceinline__ f32x16 mma_first(const uint4 (&a)[2], const uint4 (&b
 __device__ __forceinline__ void mma_second(f32x16& acc, const uint4 (&a)[2], const f32x16& x) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        bf16x8 b;
+        h16x8 b;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) b[j] = (bf16_t)x[8 * s + j];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[s]), b, acc, 0, 0, 0);
+        for (int j = 0; j < 8; ++j) b[j] = (h16_t)x[8 * s + j];
+        acc = SVOL_MFMA_32x32x16_H16(__builtin_bit_cast(h16x8, a[s]), b, acc, 0, 0, 0);
     }
 }
 
-__device__ __forceinline__ void store_acc(const f32x16& acc, bf16_t* out, int64_t ld, int row, bool valid, int dh, int h,
+__device__ __forceinline__ void store_acc(const f32x16& acc, h16_t* out, int64_t ld, int row, bool valid, int dh, int h,
                                           float mul) {
     if (!valid) return;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int d0 = 8 * g + 4 * h;
         if (d0 < dh) {
-            bf16x4 v;
+            h16x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(acc[4 * g + e] * mul);
-            *reinterpret_cast<bf16x4*>(out + (int64_t)row * ld + d0) = v;
+            for (int e = 0; e < 4; ++e) v[e] = (h16_t)(acc[4 * g + e] * mul);
+            *reinterpret_cast<h16x4*>(out + (int64_t)row * ld + d0) = v;
         }
     }
 }
@@ -199,9 +203,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(Args p) {
     const int qt = blockIdx.x / p.ksplit, sp = blockIdx.x % p.ksplit;
     const int qrow = qt * 128 + wave * 32 + r;
     const bool qvalid = qrow < p.Lq;
-    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
-    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
-    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
+    const h16_t* Q = reinterpret_cast<const h16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
+    const h16_t* K = reinterpret_cast<const h16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
+    const h16_t* V = reinterpret_cast<const h16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
     const float* kb = p.kbias ? p.kbias + (int64_t)b * p.Lk : nullptr;
     const float c = p.premul != 0.f ? 1.f : p.scale * LOG2E;
 
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(Args p) {
         return;
     }
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
-    bf16_t* Oo = reinterpret_cast<bf16_t*>(p.out_o) + (int64_t)b * p.Lq * p.ldo + hh * p.dh;
+    h16_t* Oo = reinterpret_cast<h16_t*>(p.out_o) + (int64_t)b * p.Lq * p.ldo + hh * p.dh;
     store_acc(O, Oo, p.ldo, qrow, qvalid, p.dh, h, inv);
     if (qvalid && h == 0) p.lse2[((int64_t)b * p.H + hh) * p.Lq + qrow] = m2 + __builtin_amdgcn_logf(lt);
 }
@@ -351,14 +355,14 @@ __global__ void attn_combine_bf16(Args p) {
         }
     }
     const float inv = L > 0.f ? 1.f / L : 0.f;
-    bf16_t* o = reinterpret_cast<bf16_t*>(p.out_o) + row * p.ldo + hh * p.dh;
+    h16_t* o = reinterpret_cast<h16_t*>(p.out_o) + row * p.ldo + hh * p.dh;
 #pragma unroll
     for (int d = 0; d < 32; d += 4) {
         if (d < p.dh) {
-            bf16x4 v;
+            h16x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(acc[d + e] * inv);
-            *reinterpret_cast<bf16x4*>(o + d) = v;
+            for (int e = 0; e < 4; ++e) v[e] = (h16_t)(acc[d + e] * inv);
+            *reinterpret_cast<h16x4*>(o + d) = v;
         }
     }
     p.lse2[((int64_t)b * p.H + hh) * p.Lq + q] = M + __builtin_amdgcn_logf(L);
@@ -371,11 +375,11 @@ __global__ void attn_delta_bf16(Args p) {
     const int hh = (int)(idx % p.H);
     const int64_t row = idx / p.H;
     const int b = (int)(row / p.Lq), q = (int)(row % p.Lq);
-    const bf16_t* o = reinterpret_cast<const bf16_t*>(p.o) + row * p.ldo + hh * p.dh;
-    const bf16_t* d = reinterpret_cast<const bf16_t*>(p.d_o) + row * p.lddo + hh * p.dh;
+    const h16_t* o = reinterpret_cast<const h16_t*>(p.o) + row * p.ldo + hh * p.dh;
+    const h16_t* d = reinterpret_cast<const h16_t*>(p.d_o) + row * p.lddo + hh * p.dh;
     float s = 0.f;
     for (int i = 0; i < p.dh; i += 8) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(o + i), c = *reinterpret_cast<const bf16x8*>(d + i);
+        const h16x8 a = *reinterpret_cast<const h16x8*>(o + i), c = *reinterpret_cast<const h16x8*>(d + i);
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)c[e];
     }
@@ -394,13 +398,13 @@ __global__ void attn_dq_finish_bf16(Args p) {
     const int hh = (int)(idx % p.H);
     const int64_t row = idx / p.H;
     const float* z = p.ws_dq + row * (p.H * p.dh) + hh * p.dh;
-    bf16_t* o = reinterpret_cast<bf16_t*>(p.dq) + row * p.lddq + hh * p.dh;
+    h16_t* o = reinterpret_cast<h16_t*>(p.dq) + row * p.lddq + hh * p.dh;
     for (int i = 0; i < p.dh; i += 4) {
         const f32x4 t = *reinterpret_cast<const f32x4*>(z + i);
-        bf16x4 v;
+        h16x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(t[e] * p.scale);
-        *reinterpret_cast<bf16x4*>(o + i) = v;
+        for (int e = 0; e < 4; ++e) v[e] = (h16_t)(t[e] * p.scale);
+        *reinterpret_cast<h16x4*>(o + i) = v;
     }
 }
 
@@ -419,10 +423,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(Args p) {
     const int qt = blockIdx.x / p.ksplit, sp = blockIdx.x % p.ksplit;
     const int qrow = qt * 128 + wave * 32 + r;
     const bool qvalid = qrow < p.Lq;
-    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
-    const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
-    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
-    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
+    const h16_t* Q = reinterpret_cast<const h16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
+    const h16_t* dO = reinterpret_cast<const h16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
+    const h16_t* K = reinterpret_cast<const h16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
+    const h16_t* V = reinterpret_cast<const h16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
     const float* kb = p.kbias ? p.kbias + (int64_t)b * p.Lk : nullptr;
     const float c = p.premul != 0.f ? 1.f : p.scale * LOG2E;
 
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(Args p) {
         }
         return;
     }
-    bf16_t* dQo = reinterpret_cast<bf16_t*>(p.dq) + (int64_t)b * p.Lq * p.lddq + hh * p.dh;
+    h16_t* dQo = reinterpret_cast<h16_t*>(p.dq) + (int64_t)b * p.Lq * p.lddq + hh * p.dh;
     store_acc(dQ, dQo, p.lddq, qrow, qvalid, p.dh, h, p.scale);
 }
 
@@ -520,10 +524,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(Args p) {
     const int b = blockIdx.z, hh = blockIdx.y;
     const int krow = blockIdx.x * 128 + wave * 32 + r;
     const bool kvalid = krow < p.Lk;
-    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
-    const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
-    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
-    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
+    const h16_t* Q = reinterpret_cast<const h16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
+    const h16_t* dO = reinterpret_cast<const h16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
+    const h16_t* K = reinterpret_cast<const h16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
+    const h16_t* V = reinterpret_cast<const h16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
     const float c = p.premul != 0.f ? 1.f : p.scale * LOG2E;
     const float kbl = kvalid ? (p.kbias ? p.kbias[(int64_t)b * p.Lk + krow] * LOG2E : 0.f) : -INFINITY;
     const float* lse_g = p.lse2 + ((int64_t)b * p.H + hh) * p.Lq;
@@ -598,8 +602,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(Args p) {
         }
         __syncthreads();
     }
-    bf16_t* dKo = reinterpret_cast<bf16_t*>(p.dk) + (int64_t)b * p.Lk * p.lddk + hh * p.dh;
-    bf16_t* dVo = reinterpret_cast<bf16_t*>(p.dv) + (int64_t)b * p.Lk * p.lddv + hh * p.dh;
+    h16_t* dKo = reinterpret_cast<h16_t*>(p.dk) + (int64_t)b * p.Lk * p.lddk + hh * p.dh;
+    h16_t* dVo = reinterpret_cast<h16_t*>(p.dv) + (int64_t)b * p.Lk * p.lddv + hh * p.dh;
     store_acc(dK, dKo, p.lddk, krow, kvalid, p.dh, h, p.premul != 0.f ? p.scale / p.premul : p.scale);
     store_acc(dV, dVo, p.lddv, krow, kvalid, p.dh, h, 1.f);
 }
@@ -624,10 +628,10 @@ __device__ __forceinline__ f32x16 splat16(float x) {
 // the result feeds only the next MFMA's C (accumulate chain, no wait states needed).
 __device__ __forceinline__ f32x16 mma_first_c(const uint4 (&a)[2], const uint4 (&b)[2], const f32x16& c0) {
     f32x16 acc;
-    asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3"
+    asm("s_nop 1\n\tv_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %1, %2, %3"
         : "=&v"(acc)
-        : "v"(__builtin_bit_cast(bf16x8, a[0])), "v"(__builtin_bit_cast(bf16x8, b[0])), "v"(c0));
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, b[1]), acc, 0, 0,
+        : "v"(__builtin_bit_cast(h16x8, a[0])), "v"(__builtin_bit_cast(h16x8, b[0])), "v"(c0));
+    return SVOL_MFMA_32x32x16_H16(__builtin_bit_cast(h16x8, a[1]), __builtin_bit_cast(h16x8, b[1]), acc, 0, 0,
                                                    0);
 }
 // accumulator initialised from a per-ROW vector in LDS (row constants of the reg-side tile)
@@ -672,9 +676,9 @@ __device__ __forceinline__ void block_coords(const Args& p, int& xt, int& hh, in
 
 // x as two bf16 (hi = rn(x), lo = rn(x - hi)) packed in one dword: |x - hi - lo| <= 2^-17 |x|
 __device__ __forceinline__ unsigned split_bf16x2(float x) {
-    const bf16_t hi = (bf16_t)x;
+    const h16_t hi = (h16_t)x;
     const float rem = x - (float)hi;
-    const bf16_t lo = (bf16_t)rem;
+    const h16_t lo = (h16_t)rem;
     return (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
 }
 
@@ -686,10 +690,10 @@ __device__ __forceinline__ float key_bias_log2(const float* kb, int key, int Lk)
 // [1, 1, 0...] — the mixed tiles of the masked kernels pay one matrix instruction per 32x32 block and no vector work
 __device__ __forceinline__ f32x16 add_key_bias(const f32x16& S, const float* kb, int key, int Lk, int h) {
     const float bv = key_bias_log2(kb, key, Lk);
-    const unsigned pair = bv == -INFINITY ? 0x0000FF80u : split_bf16x2(bv);  // (-inf, 0): x - hi would be NaN
+    const unsigned pair = bv == -INFINITY ? SVOL_H16_NINF_LO : split_bf16x2(bv);  // (-inf, 0): x - hi would be NaN
     const uint4 a = h == 0 ? make_uint4(pair, 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
-    const uint4 o = h == 0 ? make_uint4(0x3F803F80u, 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, o), S, 0, 0, 0);
+    const uint4 o = h == 0 ? make_uint4(SVOL_H16_ONE2, 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+    return SVOL_MFMA_32x32x16_H16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, o), S, 0, 0, 0);
 }
 // flags[b][t] = 0 (the 128 keys of tile t all have zero bias), 2 (all at -inf or past Lk), 1 (anything else)
 __global__ __launch_bounds__(64) void attn_tile_flags_bf16(const float* __restrict__ kbias, int Lk, int nt, int* __restrict__ flags) {
@@ -716,9 +720,9 @@ __device__ __forceinline__ void attn_fwd_pre_body(const Args p) {
     block_coords(p, xt, hh, b);
     const int qrow = xt * 128 + wave * 32 + r;
     const bool qvalid = qrow < p.Lq;
-    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
-    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
-    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
+    const h16_t* Q = reinterpret_cast<const h16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
+    const h16_t* K = reinterpret_cast<const h16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
+    const h16_t* V = reinterpret_cast<const h16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
     const float* kb = (MASKED && p.kbias) ? p.kbias + (int64_t)b * p.Lk : nullptr;
 
     uint4 qb[2];
@@ -821,7 +825,7 @@ __device__ __forceinline__ void attn_fwd_pre_body(const Args p) {
     }
     const float lt = l + __shfl_xor(l, 32, 64);
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
-    bf16_t* Oo = reinterpret_cast<bf16_t*>(p.out_o) + (int64_t)b * p.Lq * p.ldo + hh * p.dh;
+    h16_t* Oo = reinterpret_cast<h16_t*>(p.out_o) + (int64_t)b * p.Lq * p.ldo + hh * p.dh;
     store_acc(O, Oo, p.ldo, qrow, qvalid, p.dh, h, inv);
     if (qvalid && h == 0) p.lse2[((int64_t)b * p.H + hh) * p.Lq + qrow] = m + __builtin_amdgcn_logf(lt);
 }
@@ -839,9 +843,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_pre(Args p) {
     block_coords(p, xt, hh, b);
     const int qrow = xt * 128 + wave * 32 + r;
     const bool qvalid = qrow < p.Lq;
-    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
-    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
-    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
+    const h16_t* Q = reinterpret_cast<const h16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
+    const h16_t* K = reinterpret_cast<const h16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
+    const h16_t* V = reinterpret_cast<const h16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
 
     uint4 qb[2];
     load_lane_block(qb, Q, p.ldq, qrow, qvalid, p.dh, h);
@@ -924,7 +928,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_pre(Args p) {
     }
     const float lt = l + __shfl_xor(l, 32, 64);
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
-    bf16_t* Oo = reinterpret_cast<bf16_t*>(p.out_o) + (int64_t)b * p.Lq * p.ldo + hh * p.dh;
+    h16_t* Oo = reinterpret_cast<h16_t*>(p.out_o) + (int64_t)b * p.Lq * p.ldo + hh * p.dh;
     store_acc(O, Oo, p.ldo, qrow, qvalid, p.dh, h, inv);
     if (qvalid && h == 0) p.lse2[((int64_t)b * p.H + hh) * p.Lq + qrow] = m + __builtin_amdgcn_logf(lt);
 }
@@ -950,9 +954,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_fast(Args p) {
     block_coords(p, xt, hh, b);
     const int qrow = xt * 128 + wave * 32 + r;
     const bool qvalid = qrow < p.Lq;
-    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
-    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
-    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
+    const h16_t* Q = reinterpret_cast<const h16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
+    const h16_t* K = reinterpret_cast<const h16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
+    const h16_t* V = reinterpret_cast<const h16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
     uint4 qb[2];
     load_lane_block(qb, Q, p.ldq, qrow, qvalid, p.dh, h);
     const int nt = p.Lk / KT;     // launcher guarantees Lk % KT == 0 and dh == 32
@@ -1011,11 +1015,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_fast(Args p) {
         __syncthreads();
     }
     const float lt = l + __shfl_xor(l, 32, 64);
-    const int bad = __syncthreads_or(qvalid && !(lt < 1.0e30f));   // inf / NaN: some score left the anchor's range
+    const int bad = __syncthreads_or(qvalid && !(lt < SVOL_H16_PSUM_MAX));   // inf / NaN (fp16: any P near 65504): a score left the anchor's range
     if (tid == 0) p.redo[blockIdx.x] = bad ? 1 : 0;
     if (bad) return;              // attn_fwd_bf16_pre (next launch on the stream) recomputes this workgroup
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
-    bf16_t* Oo = reinterpret_cast<bf16_t*>(p.out_o) + (int64_t)b * p.Lq * p.ldo + hh * p.dh;
+    h16_t* Oo = reinterpret_cast<h16_t*>(p.out_o) + (int64_t)b * p.Lq * p.ldo + hh * p.dh;
     store_acc(O, Oo, p.ldo, qrow, qvalid, p.dh, h, inv);
     if (qvalid && h == 0) p.lse2[((int64_t)b * p.H + hh) * p.Lq + qrow] = m + __builtin_amdgcn_logf(lt);
 }
@@ -1031,11 +1035,11 @@ __device__ __forceinline__ void attn_bwd_dq_pre_body(const Args& p) {
     const int r = lane & 31, h = lane >> 5;
     int xt, hh, b;
     block_coords(p, xt, hh, b);
-    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
-    const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
-    const bf16_t* O = reinterpret_cast<const bf16_t*>(p.o) + (int64_t)b * p.Lq * p.ldo + hh * p.dh;
-    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
-    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
+    const h16_t* Q = reinterpret_cast<const h16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
+    const h16_t* dO = reinterpret_cast<const h16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
+    const h16_t* O = reinterpret_cast<const h16_t*>(p.o) + (int64_t)b * p.Lq * p.ldo + hh * p.dh;
+    const h16_t* K = reinterpret_cast<const h16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
+    const h16_t* V = reinterpret_cast<const h16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
 
     int qrow[2];
     bool qvalid[2];
@@ -1061,7 +1065,7 @@ __device__ __forceinline__ void attn_bwd_dq_pre_body(const Args& p) {
             load_lane_block(ob, O, p.ldo, qrow[u], qvalid[u], p.dh, h);
 #pragma unroll
             for (int s_ = 0; s_ < 2; ++s_) {
-                const bf16x8 a = __builtin_bit_cast(bf16x8, ob[s_]), c = __builtin_bit_cast(bf16x8, dob[u][s_]);
+                const h16x8 a = __builtin_bit_cast(h16x8, ob[s_]), c = __builtin_bit_cast(h16x8, dob[u][s_]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dl += (float)a[e] * (float)c[e];
             }
@@ -1110,13 +1114,17 @@ __device__ __forceinline__ void attn_bwd_dq_pre_body(const Args& p) {
             f32x16 S0 = mma_first_c(ka, qb[0], Cl[0]);
             f32x16 S1, dP1;
             if (!single) S1 = mma_first_c(ka, qb[1], Cl[1]);
-            const f32x16 dP0 = mma_first_c(va, dob[0], Cd[0]);
+            f32x16 dP0 = mma_first_c(va, dob[0], Cd[0]);
             if (!single) dP1 = mma_first_c(va, dob[1], Cd[1]);
             read_tr(kt, kimg, sub, lane);
             if (MASKED && flag == 1) {
                 S0 = add_key_bias(S0, kb, t * KT + sub * 32 + r, p.Lk, h);
                 if (!single) S1 = add_key_bias(S1, kb, t * KT + sub * 32 + r, p.Lk, h);
             }
+            // hipcc (ROCm 7.2) pads an MFMA write -> VALU read only inside a basic block: with `single` the branch around the second
+            // block's products lands straight on the first v_exp (fp16 build: S0[3] was read the instruction after the bias MFMA
+            // issued — the masked key's bias was silently missing for accumulator row 3).  Rare paths only (tail tile / mixed tile):
+            if (single || (MASKED && flag == 1)) mfma_results_ready2(S0, dP0);
 #pragma unroll
             for (int i = 0; i < 16; ++i) S0[i] = __builtin_amdgcn_exp2f(S0[i]) * dP0[i];
             mma_second(dQ[0], kt, S0);
@@ -1132,7 +1140,7 @@ __device__ __forceinline__ void attn_bwd_dq_pre_body(const Args& p) {
         }
         __syncthreads();
     }
-    bf16_t* dQo = reinterpret_cast<bf16_t*>(p.dq) + (int64_t)b * p.Lq * p.lddq + hh * p.dh;
+    h16_t* dQo = reinterpret_cast<h16_t*>(p.dq) + (int64_t)b * p.Lq * p.lddq + hh * p.dh;
 #pragma unroll
     for (int u = 0; u < 2; ++u) store_acc(dQ[u], dQo, p.lddq, qrow[u], qvalid[u], p.dh, h, p.scale);
 }
@@ -1159,10 +1167,10 @@ __device__ __forceinline__ void attn_bwd_dkdv_pre_body(const Args& p) {
     block_coords(p, xt, hh, b);
     const int krow = xt * 128 + wave * 32 + r;
     const bool kvalid = krow < p.Lk;
-    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
-    const bf16_t* dO = reinterpret_cast<const bf16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
-    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
-    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
+    const h16_t* Q = reinterpret_cast<const h16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
+    const h16_t* dO = reinterpret_cast<const h16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
+    const h16_t* K = reinterpret_cast<const h16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
+    const h16_t* V = reinterpret_cast<const h16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
     const float* lse_g = p.lse2 + ((int64_t)b * p.H + hh) * p.Lq;
     const float* dl_g = p.delta + ((int64_t)b * p.H + hh) * p.Lq;
 
@@ -1176,23 +1184,23 @@ __device__ __forceinline__ void attn_bwd_dkdv_pre_body(const Args& p) {
     auto load_stats = [&](int row0) {
         if (tid < KT) {
             const int qi = row0 + tid;
-            rl = qi < p.Lq ? -lse_g[qi] : -3.0e38f;  // finite (it meets a 0 in the MFMA), still exp2 -> 0
+            rl = qi < p.Lq ? -lse_g[qi] : SVOL_H16_NEG_BIG;  // finite IN THE OPERAND TYPE (it meets a 0 in the MFMA), still exp2 -> 0
             rd = qi < p.Lq ? -dl_g[qi] : 0.f;
         }
     };
     auto store_stats = [&](int buf) {
         if (tid < KT) { sL[buf * KT + tid] = split_bf16x2(rl); sD[buf * KT + tid] = split_bf16x2(rd); }
     };
-    const uint4 ones = h == 0 ? make_uint4(0x3F803F80u, 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);  // [1, 1, 0...]
+    const uint4 ones = h == 0 ? make_uint4(SVOL_H16_ONE2, 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);  // [1, 1, 0...]
     // MASKED: the key bias is a per-LANE constant here (keys are the columns of the score tile).  It rides the same extra
     // MFMA as -lse: the query side gets [hi, lo, 1, 1, 0...] and this key's side [1, 1, bias_hi, bias_lo, 0...] — no
     // per-score instruction at all.  Keys past Lk get -inf (p = 0).  A wave whose 32 keys are all masked only helps staging.
     float kbl = 0.f;
     if (MASKED) kbl = kvalid ? (p.kbias ? p.kbias[(int64_t)b * p.Lk + krow] * LOG2E : 0.f) : -INFINITY;
     const bool wave_dead = MASKED && __all(kbl == -INFINITY);
-    const unsigned kb_pair = kbl == -INFINITY ? 0x0000FF80u : split_bf16x2(kbl);  // (-inf, 0): x - hi would be NaN
-    const uint4 ones_s = (MASKED && h == 0) ? make_uint4(0x3F803F80u, kb_pair, 0u, 0u) : ones;
-    const unsigned q_one = MASKED ? 0x3F803F80u : 0u;
+    const unsigned kb_pair = kbl == -INFINITY ? SVOL_H16_NINF_LO : split_bf16x2(kbl);  // (-inf, 0): x - hi would be NaN
+    const uint4 ones_s = (MASKED && h == 0) ? make_uint4(SVOL_H16_ONE2, kb_pair, 0u, 0u) : ones;
+    const unsigned q_one = MASKED ? SVOL_H16_ONE2 : 0u;
     const unsigned* nl_h = DMA ? p.nl2 + ((int64_t)b * p.H + hh) * p.Lq : nullptr;
     const unsigned* nd_h = DMA ? p.nd2 + ((int64_t)b * p.H + hh) * p.Lq : nullptr;
     auto dma_stats = [&](int buf, int row0) {   // wave 0: -lse pairs, wave 1: -delta pairs; 32 lanes x 16 bytes = 128 queries
@@ -1242,15 +1250,15 @@ __device__ __forceinline__ void attn_bwd_dkdv_pre_body(const Args& p) {
             const uint4 el = make_uint4(nl[sub * 32 + r], q_one, 0u, 0u);
             const uint4 ed = make_uint4(nd[sub * 32 + r], 0u, 0u, 0u);
             read_rows(a, qimg, sub * 32 + r, h);
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, el), __builtin_bit_cast(bf16x8, ones_s),
+            S = SVOL_MFMA_32x32x16_H16(__builtin_bit_cast(h16x8, el), __builtin_bit_cast(h16x8, ones_s),
                                                         zero16(), 0, 0, 0);
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, kbk[0]), S, 0, 0, 0);
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, kbk[1]), S, 0, 0, 0);  // score - lse[q]
+            S = SVOL_MFMA_32x32x16_H16(__builtin_bit_cast(h16x8, a[0]), __builtin_bit_cast(h16x8, kbk[0]), S, 0, 0, 0);
+            S = SVOL_MFMA_32x32x16_H16(__builtin_bit_cast(h16x8, a[1]), __builtin_bit_cast(h16x8, kbk[1]), S, 0, 0, 0);  // score - lse[q]
             read_rows(a, doimg, sub * 32 + r, h);
-            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ed), __builtin_bit_cast(bf16x8, ones),
+            dP = SVOL_MFMA_32x32x16_H16(__builtin_bit_cast(h16x8, ed), __builtin_bit_cast(h16x8, ones),
                                                          zero16(), 0, 0, 0);
-            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, vbk[0]), dP, 0, 0, 0);
-            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, vbk[1]), dP, 0, 0, 0);  // dO V^T - delta[q]
+            dP = SVOL_MFMA_32x32x16_H16(__builtin_bit_cast(h16x8, a[0]), __builtin_bit_cast(h16x8, vbk[0]), dP, 0, 0, 0);
+            dP = SVOL_MFMA_32x32x16_H16(__builtin_bit_cast(h16x8, a[1]), __builtin_bit_cast(h16x8, vbk[1]), dP, 0, 0, 0);  // dO V^T - delta[q]
         };
         f32x16 S, dP, Sn, dPn;
         if (!wave_dead) first_products(0, S, dP);
@@ -1276,8 +1284,8 @@ __device__ __forceinline__ void attn_bwd_dkdv_pre_body(const Args& p) {
         if (DMA) dma_wait_all();
         __syncthreads();
     }
-    bf16_t* dKo = reinterpret_cast<bf16_t*>(p.dk) + (int64_t)b * p.Lk * p.lddk + hh * p.dh;
-    bf16_t* dVo = reinterpret_cast<bf16_t*>(p.dv) + (int64_t)b * p.Lk * p.lddv + hh * p.dh;
+    h16_t* dKo = reinterpret_cast<h16_t*>(p.dk) + (int64_t)b * p.Lk * p.lddk + hh * p.dh;
+    h16_t* dVo = reinterpret_cast<h16_t*>(p.dv) + (int64_t)b * p.Lk * p.lddv + hh * p.dh;
     store_acc(dK, dKo, p.lddk, krow, kvalid, p.dh, h, p.scale / p.premul);
     store_acc(dV, dVo, p.lddv, krow, kvalid, p.dh, h, 1.f);
 }

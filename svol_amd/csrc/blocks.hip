@@ -18,11 +18,11 @@ struct Dims {
         : B(d[SVOL_DIM_B]), L(d[SVOL_DIM_L]), N(d[SVOL_DIM_N]), D(d[SVOL_DIM_D]), H(d[SVOL_DIM_H]), F(d[SVOL_DIM_F]),
           ws_bytes(d[SVOL_DIM_ATTN_WS_BYTES]), dt((int)d[SVOL_DIM_DTYPE]), qdt((int)d[SVOL_DIM_QDTYPE]) {}
     bool ok() const {
-        return B > 0 && D > 0 && H > 0 && D % H == 0 && (dt == SVOL_F32 || dt == SVOL_BF16) && (qdt == SVOL_F32 || qdt == SVOL_BF16);
+        return B > 0 && D > 0 && H > 0 && D % H == 0 && (dt == SVOL_F32 || svol_is16(dt)) && (qdt == SVOL_F32 || svol_is16(qdt));
     }
 };
 
-inline int esz(int dtype) { return dtype == SVOL_BF16 ? 2 : 4; }
+inline int esz(int dtype) { return svol_is16(dtype) ? 2 : 4; }
 // element offset into a typed buffer
 inline void* at(void* p, int64_t elems, int dtype) { return p ? static_cast<char*>(p) + elems * esz(dtype) : nullptr; }
 inline const void* at(const void* p, int64_t elems, int dtype) { return p ? static_cast<const char*>(p) + elems * esz(dtype) : nullptr; }
@@ -30,7 +30,7 @@ inline float* f32(void* p) { return static_cast<float*>(p); }
 
 // the attention kernels' scale conventions (svol_amd/ops.py AttnLNFn): bf16 q leaves its projection pre-multiplied by d_h^-1/2 log2(e)
 inline float attn_scale(int64_t dh) { return (float)(1.0 / sqrt((double)dh)); }
-inline float attn_premul(int64_t dh, int dtype) { return dtype == SVOL_BF16 ? (float)(1.4426950408889634 / sqrt((double)dh)) : 0.f; }
+inline float attn_premul(int64_t dh, int dtype) { return svol_is16(dtype) ? (float)(1.4426950408889634 / sqrt((double)dh)) : 0.f; }
 
 // plain C = A B^T (+ bias) (* colscale)
 inline int nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* colscale,

@@ -9,8 +9,79 @@ typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// ---- the 16-bit operand type of a translation unit ---------------------------------------------------------------------------
+// The MFMA-path files (gemm_bf16 / gemm_ws_bf16 / gemm_n256_bf16 / gemm_tn_bf16 / attention_bf16 .hip) are written against
+// h16_t and compiled TWICE (svol_amd/build.py): as they are — h16_t = bf16, v_mfma_*_bf16 — and with -DSVOL_H16_FP16 — h16_t =
+// fp16, v_mfma_*_f16 (same rate, 11 mantissa bits, 5 exponent bits) — with their external launchers renamed *_bf16* -> *_f16*.
+// One source per kernel family, two operand types (BASELINE configs[4] is stated in fp16).
+#ifdef SVOL_H16_FP16
+typedef f16_t h16_t;
+typedef f16x8 h16x8;
+typedef f16x4 h16x4;
+typedef f16x2 h16x2;
+#define SVOL_MFMA_16x16x32_H16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define SVOL_MFMA_32x32x16_H16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define SVOL_DS_READ_TR16_H16 svol_ds_read_tr16_f16
+#define SVOL_H16_ASM "f16"
+#define SVOL_H16_ONE2 0x3C003C00u      /* (1.0, 1.0) */
+#define SVOL_H16_NINF_LO 0x0000FC00u   /* (-inf, 0) */
+#define SVOL_H16_DTYPE SVOL_F16
+#define SVOL_H16_NEG_BIG (-6.0e4f)   /* most negative row constant that is still finite as an fp16 operand */
+#define SVOL_H16_PSUM_MAX 3.0e4f   /* a softmax numerator that would not fit fp16 (65504) makes the row sum exceed this */
+#define svol_gemm_nt_bf16_fast svol_gemm_nt_f16_fast
+#define svol_gemm_tn_bf16_fast svol_gemm_tn_f16_fast
+#define svol_gemm_ws_bf16 svol_gemm_ws_f16
+#define svol_gemm_n256_bf16 svol_gemm_n256_f16
+#define svol_attn_fwd_bf16_launch svol_attn_fwd_f16_launch
+#define svol_attn_bwd_bf16_launch svol_attn_bwd_f16_launch
+#define svol_attn_ws_floats_bf16 svol_attn_ws_floats_f16
+#else
+typedef bf16_t h16_t;
+typedef bf16x8 h16x8;
+typedef bf16x4 h16x4;
+typedef bf16x2 h16x2;
+#define SVOL_MFMA_16x16x32_H16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define SVOL_MFMA_32x32x16_H16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define SVOL_DS_READ_TR16_H16 __builtin_amdgcn_ds_read_tr16_b64_v4bf16
+#define SVOL_H16_ASM "bf16"
+#define SVOL_H16_ONE2 0x3F803F80u
+#define SVOL_H16_NINF_LO 0x0000FF80u
+#define SVOL_H16_DTYPE SVOL_BF16
+#define SVOL_H16_NEG_BIG (-3.0e38f)
+#define SVOL_H16_PSUM_MAX 1.0e30f
+#endif
+// (the v4f16 form of the builtin is typed on __fp16, not _Float16: go through the 16-bit integer form)
+typedef __attribute__((ext_vector_type(4))) short i16x4;
+__device__ __forceinline__ f16x4 svol_ds_read_tr16_f16(__attribute__((address_space(3))) f16x4* p) {
+    return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)p));
+}
+static inline bool svol_is16(int dtype) { return dtype == SVOL_BF16 || dtype == SVOL_F16; }
+
+// per-type MFMA / transposed-LDS-read for kernels that are C++ templates on the element type (gemm.hip, attention.hip)
+template <typename T> struct H16;
+template <> struct H16<bf16_t> {
+    typedef bf16x8 v8;
+    typedef bf16x4 v4;
+    typedef __attribute__((address_space(3))) bf16x4* lds_v4_ptr;
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ v4 read_tr(lds_v4_ptr p) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p); }
+};
+template <> struct H16<f16_t> {
+    typedef f16x8 v8;
+    typedef f16x4 v4;
+    typedef __attribute__((address_space(3))) f16x4* lds_v4_ptr;
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ v4 read_tr(lds_v4_ptr p) { return svol_ds_read_tr16_f16(p); }
+};
 
 #define SVOL_CHECK_LAUNCH()                                   \
     do {                                                      \
@@ -33,9 +104,11 @@ __device__ __forceinline__ HalfPair swap_halves(unsigned x) {
 // ---- scalar conversions ---------------------------------------------------
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+__device__ __forceinline__ float to_f32(f16_t x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float x) { return (f16_t)x; }
 
 // ---- 4-element vector access (8 B for bf16, 16 B for f32) ------------------
 template <typename T> struct Vec4;
@@ -52,6 +125,14 @@ template <> struct Vec4<bf16_t> {
     __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<bf16x4*>(p) = v; }
     __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
     __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16_t)x; }
+};
+
+template <> struct Vec4<f16_t> {
+    f16x4 v;
+    __device__ __forceinline__ void load(const f16_t* p) { v = *reinterpret_cast<const f16x4*>(p); }
+    __device__ __forceinline__ void store(f16_t* p) const { *reinterpret_cast<f16x4*>(p) = v; }
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (f16_t)x; }
 };
 
 // ---- wave-level reductions (64 lanes) --------------------------------------

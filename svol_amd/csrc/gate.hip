@@ -601,7 +601,7 @@ int svol_gate_fwd(const float* x32, const void* pos, const float* u, const float
     if (!x32 || !pos || !u || !gamma || !beta || (!y && !y32) || !a || !mean || !rstd || !ws) return SVOL_E_INVALID;
     if (B <= 0 || L <= 0 || D <= 0 || H <= 0) return SVOL_E_INVALID;
     if (D % 4 || D > GP * 256 || H > GH || B > 65535 || L > (1 << 24)) return SVOL_E_UNSUPPORTED;
-    if (dtype != SVOL_BF16 && dtype != SVOL_F32) return SVOL_E_INVALID;
+    if (!svol_is16(dtype) && dtype != SVOL_F32) return SVOL_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int np_ = D <= 256 ? 1 : (D <= 512 ? 2 : 4);
     float* scores = ws;
@@ -622,6 +622,7 @@ int svol_gate_fwd(const float* x32, const void* pos, const float* u, const float
         else hipLaunchKernelGGL((gate_apply_kernel<TT, 4>), dim3(g3), dim3(256), 0, s, x32, (const TT*)pos, scores, mx, sm, gamma, beta, y32, (TT*)y, (TT*)ypos, a, mean, rstd, (int)L, (int)D, (int)H, M); \
     } while (0)
     if (dtype == SVOL_BF16) SVOL_GATE_FWD(bf16_t);
+    else if (dtype == SVOL_F16) SVOL_GATE_FWD(f16_t);
     else SVOL_GATE_FWD(float);
 #undef SVOL_GATE_FWD
     SVOL_CHECK_LAUNCH();
@@ -637,7 +638,7 @@ int svol_gate_bwd(const float* dy32, const void* dy, const void* dy2, const floa
         return SVOL_E_INVALID;
     if (B <= 0 || L <= 0 || D <= 0 || H <= 0) return SVOL_E_INVALID;
     if (D % 4 || D > GP * 256 || H > GH || B > 65535 || L > (1 << 24)) return SVOL_E_UNSUPPORTED;
-    if (dtype != SVOL_BF16 && dtype != SVOL_F32) return SVOL_E_INVALID;
+    if (!svol_is16(dtype) && dtype != SVOL_F32) return SVOL_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int np_ = D <= 256 ? 1 : (D <= 512 ? 2 : 4);
     const float* scores = ws;
@@ -661,6 +662,7 @@ int svol_gate_bwd(const float* dy32, const void* dy, const void* dy2, const floa
         else hipLaunchKernelGGL((gate_bwd_apply_kernel<TT, 4>), g3, dim3(256), 0, s, x32, (const TT*)pos, u, scores, mx, sm, da, cc, dx32, du, (int)L, (int)D, (int)H, rpw3); \
     } while (0)
     if (dtype == SVOL_BF16) SVOL_GATE_BWD(bf16_t);
+    else if (dtype == SVOL_F16) SVOL_GATE_BWD(f16_t);
     else SVOL_GATE_BWD(float);
 #undef SVOL_GATE_BWD
     SVOL_CHECK_LAUNCH();

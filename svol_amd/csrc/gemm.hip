@@ -20,11 +20,15 @@ namespace {
 
 template <typename T> struct Tr;
 template <> struct Tr<bf16_t> { static constexpr int EPC = 8; };  // elements per 16-byte chunk
+template <> struct Tr<f16_t> { static constexpr int EPC = 8; };
 template <> struct Tr<float> { static constexpr int EPC = 4; };
 
 __device__ __forceinline__ void mma_chunk(f32x4& acc, const uint4& a, const uint4& b, bf16_t) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc,
                                                   0, 0, 0);
+}
+__device__ __forceinline__ void mma_chunk(f32x4& acc, const uint4& a, const uint4& b, f16_t) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
 __device__ __forceinline__ void mma_chunk(f32x4& acc, const uint4& a, const uint4& b, float) {
     f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
@@ -163,6 +167,7 @@ struct TnArgs {
 
 template <typename T> struct TnCfg;
 template <> struct TnCfg<bf16_t> { static constexpr int CT = 64, STRIDE = 288, CPR = 16; };  // chunks per row
+template <> struct TnCfg<f16_t> { static constexpr int CT = 64, STRIDE = 288, CPR = 16; };
 template <> struct TnCfg<float> { static constexpr int CT = 32, STRIDE = 576, CPR = 32; };
 
 template <typename T>
@@ -226,35 +231,35 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
         __syncthreads();
         if (m0 + CT < m_end) load_tile(m0 + CT);
         if constexpr (sizeof(T) == 2) {
-            typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+            typedef H16<T> HT;
+            typedef typename HT::lds_v4_ptr lds_v4_ptr;
+            typedef typename HT::v8 v8;
+            typedef typename HT::v4 v4;
             const int q = fr >> 2, pp = fr & 3;
 #pragma unroll
             for (int ks = 0; ks < CT / 32; ++ks) {
                 const int row = ks * 32 + 4 * fq + q;
-                bf16x8 af[4], bfr[4];
+                v8 af[4], bfr[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int colA = wn * 64 + t * 16 + 4 * pp, colB = wk * 64 + t * 16 + 4 * pp;
-                    bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(sA + row * S + colA * 2));
-                    bf16x4 a1 =
-                        __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(sA + (row + 16) * S + colA * 2));
-                    bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(sB + row * S + colB * 2));
-                    bf16x4 b1 =
-                        __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(sB + (row + 16) * S + colB * 2));
+                    v4 a0 = HT::read_tr((lds_v4_ptr)(sA + row * S + colA * 2));
+                    v4 a1 = HT::read_tr((lds_v4_ptr)(sA + (row + 16) * S + colA * 2));
+                    v4 b0 = HT::read_tr((lds_v4_ptr)(sB + row * S + colB * 2));
+                    v4 b1 = HT::read_tr((lds_v4_ptr)(sB + (row + 16) * S + colB * 2));
                     af[t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
                     bfr[t] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                    for (int kt = 0; kt < 4; ++kt)
-                        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
+                    for (int kt = 0; kt < 4; ++kt) acc[nt][kt] = HT::mfma16(af[nt], bfr[kt], acc[nt][kt]);
                 if (do_cs) {
-                    bf16x8 ones;
+                    v8 ones;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
+                    for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) cs[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], ones, cs[nt], 0, 0, 0);
+                    for (int nt = 0; nt < 4; ++nt) cs[nt] = HT::mfma16(af[nt], ones, cs[nt]);
                 }
             }
         } else {
@@ -564,6 +569,13 @@ int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ld
                            int64_t ldaux, float* colsum, int epi, const float* colscale, int64_t M, int64_t N, int64_t K,
                            int64_t kwrap, hipStream_t s);
 
+int svol_gemm_tn_f16_fast(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
+                          int64_t Mc, int64_t N, int64_t K, hipStream_t s);
+int svol_gemm_nt_f16_fast(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
+                          int act, void* pre, int64_t ldp, const void* res, int64_t ldr, int out_f32, const void* aux,
+                          int64_t ldaux, float* colsum, int epi, const float* colscale, int64_t M, int64_t N, int64_t K,
+                          int64_t kwrap, hipStream_t s);
+
 extern "C" {
 
 int svol_abi_version(void) { return 3; }
@@ -584,8 +596,8 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* A2, int64_t n_sp
                         void* stream) {
     if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return SVOL_E_INVALID;
     if (M == 0 || N == 0) return SVOL_OK;
-    const int epc = dtype == SVOL_BF16 ? 8 : 4;
-    if (dtype != SVOL_BF16 && dtype != SVOL_F32) return SVOL_E_INVALID;
+    const int epc = svol_is16(dtype) ? 8 : 4;
+    if (!svol_is16(dtype) && dtype != SVOL_F32) return SVOL_E_INVALID;
     if (K % epc || lda % epc || ldb % epc) return SVOL_E_UNSUPPORTED;
     if (!aligned16(A) || !aligned16(B) || (A2 && !aligned16(A2))) return SVOL_E_INVALID;
     if (A2 && (n_split % 128)) return SVOL_E_UNSUPPORTED;
@@ -594,9 +606,9 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* A2, int64_t n_sp
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
     if (grid.y > 65535u) return SVOL_E_UNSUPPORTED;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == SVOL_BF16 && !A2) {
-        const int rc = svol_gemm_nt_bf16_fast(A, lda, B, ldb, C, ldc, bias, act, pre_act_out, ldp, residual, ldr, out_f32, nullptr,
-                                              0, nullptr, 0, colscale, M, N, K, kwrap, s);
+    if (svol_is16(dtype) && !A2) {
+        const int rc = (dtype == SVOL_BF16 ? svol_gemm_nt_bf16_fast : svol_gemm_nt_f16_fast)(
+            A, lda, B, ldb, C, ldc, bias, act, pre_act_out, ldp, residual, ldr, out_f32, nullptr, 0, nullptr, 0, colscale, M, N, K, kwrap, s);
         if (rc != SVOL_E_UNSUPPORTED) return rc;
     }
     if (dtype == SVOL_F32 && !A2 && kwrap == K && skinny_f32_ok(M, N, K, lda, ldb, ldc, A, B, C) && (!residual || (ldr % 4 == 0 && aligned16(residual))) &&
@@ -613,6 +625,9 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* A2, int64_t n_sp
     if (dtype == SVOL_BF16) {
         if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, p);
+    } else if (dtype == SVOL_F16) {
+        if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<f16_t, float>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<f16_t, f16_t>), grid, dim3(256), 0, s, p);
     } else if (small) {
         hipLaunchKernelGGL((gemm_nt_kernel<float, float, 64>), g64, dim3(256), 0, s, p);
     } else {
@@ -643,9 +658,9 @@ int svol_gemm_nt_dact(const void* A, int64_t lda, const void* B, int64_t ldb, vo
     if (act != SVOL_ACT_GELU && act != SVOL_ACT_RELU) return SVOL_E_INVALID;
     if (M == 0 || N == 0) return SVOL_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == SVOL_BF16) {
-        const int rc = svol_gemm_nt_bf16_fast(A, lda, B, ldb, C, ldc, nullptr, act, nullptr, 0, nullptr, 0, 0, aux, ldaux, colsum, 1,
-                                              nullptr, M, N, K, K, s);
+    if (svol_is16(dtype)) {
+        const int rc = (dtype == SVOL_BF16 ? svol_gemm_nt_bf16_fast : svol_gemm_nt_f16_fast)(
+            A, lda, B, ldb, C, ldc, nullptr, act, nullptr, 0, nullptr, 0, 0, aux, ldaux, colsum, 1, nullptr, M, N, K, K, s);
         if (rc != SVOL_E_UNSUPPORTED) return rc;
     }
     if (dtype == SVOL_F32 && skinny_f32_ok(M, N, K, lda, ldb, ldc, A, B, C) && ldaux % 4 == 0 && aligned16(aux)) {
@@ -675,17 +690,18 @@ int svol_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* 
                  int64_t N, int64_t K, int dtype, void* stream) {
     if (!A || !B || !C || Mc < 0 || N <= 0 || K <= 0) return SVOL_E_INVALID;
     if (Mc == 0) return SVOL_OK;
-    if (dtype != SVOL_BF16 && dtype != SVOL_F32) return SVOL_E_INVALID;
+    if (!svol_is16(dtype) && dtype != SVOL_F32) return SVOL_E_INVALID;
     static const bool no_fast_tn = getenv("SVOL_TN_GENERIC") != nullptr;
-    if (dtype == SVOL_BF16 && !no_fast_tn) {
-        const int rc = svol_gemm_tn_bf16_fast(A, lda, B, ldb, C, ldc, colsum, Mc, N, K, reinterpret_cast<hipStream_t>(stream));
+    if (svol_is16(dtype) && !no_fast_tn) {
+        const int rc = (dtype == SVOL_BF16 ? svol_gemm_tn_bf16_fast : svol_gemm_tn_f16_fast)(A, lda, B, ldb, C, ldc, colsum, Mc, N, K,
+                                                                                              reinterpret_cast<hipStream_t>(stream));
         if (rc != SVOL_E_UNSUPPORTED) return rc;
     }
-    const int epc = dtype == SVOL_BF16 ? 8 : 4;
+    const int epc = svol_is16(dtype) ? 8 : 4;
     if (N % epc || K % epc || lda % epc || ldb % epc) return SVOL_E_UNSUPPORTED;
     if (!aligned16(A) || !aligned16(B)) return SVOL_E_INVALID;
     if (Mc > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return SVOL_E_UNSUPPORTED;
-    const int ct = dtype == SVOL_BF16 ? 64 : 32;
+    const int ct = svol_is16(dtype) ? 64 : 32;
     const int64_t tiles = ((N + 127) / 128) * ((K + 127) / 128);
     // split the contraction so that ~TARGET workgroups exist, chunk a multiple of CT
     // (measured on MI355X: the fp32 atomics of the final accumulation dominate small outputs, so few, long-running
@@ -712,6 +728,7 @@ int svol_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* 
     dim3 grid((unsigned)(splits * tiles));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SVOL_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+    else if (dtype == SVOL_F16) hipLaunchKernelGGL(gemm_tn_kernel<f16_t>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 0, s, p);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
@@ -731,6 +748,8 @@ int svol_colsum(const void* X, int64_t ldx, float* out, int64_t M, int64_t N, in
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SVOL_BF16)
         hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, ldx, out, (int)M, (int)N, rpb);
+    else if (dtype == SVOL_F16)
+        hipLaunchKernelGGL(colsum_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)X, ldx, out, (int)M, (int)N, rpb);
     else if (dtype == SVOL_F32)
         hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)X, ldx, out, (int)M, (int)N, rpb);
     else return SVOL_E_INVALID;
@@ -746,15 +765,22 @@ int svol_cast(const void* src, int dtype_src, void* dst, int dtype_dst, int64_t 
     if (dtype_src == SVOL_F32 && dtype_dst == SVOL_BF16 && n % 8 == 0 && aligned16(src) && aligned16(dst) && n / 8 / 256 < (1ll << 31))
         hipLaunchKernelGGL(cast_f32_bf16_vec8_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, s, (const float*)src,
                            (bf16_t*)dst, n / 8);
-    else if (dtype_src == SVOL_F32 && dtype_dst == SVOL_BF16)
-        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(g), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, n);
-    else if (dtype_src == SVOL_BF16 && dtype_dst == SVOL_F32)
-        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, n);
-    else if (dtype_src == SVOL_F32 && dtype_dst == SVOL_F32)
-        hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, s, (const float*)src, (float*)dst, n);
-    else if (dtype_src == SVOL_BF16 && dtype_dst == SVOL_BF16)
-        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
-    else return SVOL_E_INVALID;
+    else {
+#define SVOL_CAST(TS, TD) hipLaunchKernelGGL((cast_kernel<TS, TD>), dim3(g), dim3(256), 0, s, (const TS*)src, (TD*)dst, n)
+#define SVOL_CAST_FROM(TS)                                      \
+    do {                                                        \
+        if (dtype_dst == SVOL_F32) SVOL_CAST(TS, float);        \
+        else if (dtype_dst == SVOL_BF16) SVOL_CAST(TS, bf16_t); \
+        else if (dtype_dst == SVOL_F16) SVOL_CAST(TS, f16_t);   \
+        else return SVOL_E_INVALID;                             \
+    } while (0)
+        if (dtype_src == SVOL_F32) SVOL_CAST_FROM(float);
+        else if (dtype_src == SVOL_BF16) SVOL_CAST_FROM(bf16_t);
+        else if (dtype_src == SVOL_F16) SVOL_CAST_FROM(f16_t);
+        else return SVOL_E_INVALID;
+#undef SVOL_CAST_FROM
+#undef SVOL_CAST
+    }
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }
@@ -767,6 +793,8 @@ int svol_cast_transpose(const float* src, void* dst, void* dstT, int dtype, int6
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SVOL_BF16)
         hipLaunchKernelGGL(cast_transpose_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, (bf16_t*)dstT, (int)R, (int)C);
+    else if (dtype == SVOL_F16)
+        hipLaunchKernelGGL(cast_transpose_kernel<f16_t>, grid, dim3(256), 0, s, src, (f16_t*)dst, (f16_t*)dstT, (int)R, (int)C);
     else if (dtype == SVOL_F32)
         hipLaunchKernelGGL(cast_transpose_kernel<float>, grid, dim3(256), 0, s, src, (float*)dst, (float*)dstT, (int)R, (int)C);
     else return SVOL_E_INVALID;
@@ -790,6 +818,7 @@ int svol_cast_transpose_multi(const void* descs, int32_t n_desc, int64_t total_t
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const CastDesc* d = reinterpret_cast<const CastDesc*>(descs);
     if (dtype == SVOL_BF16) hipLaunchKernelGGL(cast_transpose_multi_kernel<bf16_t>, dim3((unsigned)total_tiles), dim3(256), 0, s, d, n_desc);
+    else if (dtype == SVOL_F16) hipLaunchKernelGGL(cast_transpose_multi_kernel<f16_t>, dim3((unsigned)total_tiles), dim3(256), 0, s, d, n_desc);
     else if (dtype == SVOL_F32) hipLaunchKernelGGL(cast_transpose_multi_kernel<float>, dim3((unsigned)total_tiles), dim3(256), 0, s, d, n_desc);
     else return SVOL_E_INVALID;
     SVOL_CHECK_LAUNCH();
@@ -803,6 +832,8 @@ int svol_act_bwd(const void* dy, const void* aux, void* dpre, int act, int64_t n
     const int g = grid_1d(n, 256);
     if (dtype == SVOL_BF16)
         hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)aux, (bf16_t*)dpre, act, n);
+    else if (dtype == SVOL_F16)
+        hipLaunchKernelGGL(act_bwd_kernel<f16_t>, dim3(g), dim3(256), 0, s, (const f16_t*)dy, (const f16_t*)aux, (f16_t*)dpre, act, n);
     else if (dtype == SVOL_F32)
         hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)dy, (const float*)aux, (float*)dpre, act, n);
     else return SVOL_E_INVALID;

@@ -23,8 +23,8 @@
 namespace {
 
 struct FastArgs {
-    const bf16_t* A; const bf16_t* B; void* C;
-    const float* bias; const float* colscale; bf16_t* pre; const void* res; const bf16_t* aux; float* colsum;
+    const h16_t* A; const h16_t* B; void* C;
+    const float* bias; const float* colscale; h16_t* pre; const void* res; const h16_t* aux; float* colsum;
     int64_t lda, ldb, ldc, ldp, ldr, ldaux;
     int M, N, K, act, epi;
     // implicit-GEMM convolution (CONV instantiation): A is an NHWC activation [n, cH, cW, cC]; row m of the GEMM is output pixel
@@ -53,16 +53,16 @@ template <> struct Out4<float> {
     static __device__ __forceinline__ f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
     static __device__ __forceinline__ void store(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
 };
-template <> struct Out4<bf16_t> {
-    static __device__ __forceinline__ f32x4 load(const bf16_t* p) {
-        const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+template <> struct Out4<h16_t> {
+    static __device__ __forceinline__ f32x4 load(const h16_t* p) {
+        const h16x4 t = *reinterpret_cast<const h16x4*>(p);
         return f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
     }
-    static __device__ __forceinline__ void store(bf16_t* p, const f32x4& v) {
-        bf16x4 t;
+    static __device__ __forceinline__ void store(h16_t* p, const f32x4& v) {
+        h16x4 t;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = (bf16_t)v[e];
-        *reinterpret_cast<bf16x4*>(p) = t;
+        for (int e = 0; e < 4; ++e) t[e] = (h16_t)v[e];
+        *reinterpret_cast<h16x4*>(p) = t;
     }
 };
 
@@ -161,8 +161,8 @@ __device__ __forceinline__ void gemm_nt_bf16_body(const FastArgs& p) {
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, nf[nt]),
-                                                                          __builtin_bit_cast(bf16x8, mf[mt]), acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = SVOL_MFMA_16x16x32_H16(__builtin_bit_cast(h16x8, nf[nt]),
+                                                                          __builtin_bit_cast(h16x8, mf[mt]), acc[nt][mt], 0, 0, 0);
         }
     }
 
@@ -201,10 +201,10 @@ __device__ __forceinline__ void gemm_nt_bf16_body(const FastArgs& p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = (v[e] + bias4[e]) * scale4[e];
                     if (p.pre) {
-                        if (colv) Out4<bf16_t>::store(p.pre + (int64_t)m * p.ldp + ncol, v);
+                        if (colv) Out4<h16_t>::store(p.pre + (int64_t)m * p.ldp + ncol, v);
                         else
                             for (int e = 0; e < 4; ++e)
-                                if (ncol + e < p.N) p.pre[(int64_t)m * p.ldp + ncol + e] = (bf16_t)v[e];
+                                if (ncol + e < p.N) p.pre[(int64_t)m * p.ldp + ncol + e] = (h16_t)v[e];
                     }
                     if (p.act == SVOL_ACT_RELU) {
 #pragma unroll
@@ -232,7 +232,7 @@ __device__ __forceinline__ void gemm_nt_bf16_body(const FastArgs& p) {
                     }
                 } else {  // epi 1: v = acc * gelu'(aux), column sums of v
                     if (colv) {
-                        const f32x4 a = Out4<bf16_t>::load(p.aux + (int64_t)m * p.ldaux + ncol);
+                        const f32x4 a = Out4<h16_t>::load(p.aux + (int64_t)m * p.ldaux + ncol);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] *= dact_fast(a[e], p.act);
                     } else {
@@ -269,11 +269,11 @@ __device__ __forceinline__ void gemm_nt_bf16_body(const FastArgs& p) {
 
 // concrete kernels (one per output type x K-step)
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_f32_k64(FastArgs p) { gemm_nt_bf16_body<float, 64>(p); }
-__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_b16_k64(FastArgs p) { gemm_nt_bf16_body<bf16_t, 64>(p); }
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_b16_k64(FastArgs p) { gemm_nt_bf16_body<h16_t, 64>(p); }
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_f32_k32(FastArgs p) { gemm_nt_bf16_body<float, 32>(p); }
-__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_b16_k32(FastArgs p) { gemm_nt_bf16_body<bf16_t, 32>(p); }
-__global__ __launch_bounds__(256, 2) void conv_nhwc_bf16_k64(FastArgs p) { gemm_nt_bf16_body<bf16_t, 64, true>(p); }
-__global__ __launch_bounds__(256, 2) void conv_nhwc_bf16_k32(FastArgs p) { gemm_nt_bf16_body<bf16_t, 32, true>(p); }
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_b16_k32(FastArgs p) { gemm_nt_bf16_body<h16_t, 32>(p); }
+__global__ __launch_bounds__(256, 2) void conv_nhwc_bf16_k64(FastArgs p) { gemm_nt_bf16_body<h16_t, 64, true>(p); }
+__global__ __launch_bounds__(256, 2) void conv_nhwc_bf16_k32(FastArgs p) { gemm_nt_bf16_body<h16_t, 32, true>(p); }
 
 // ---------------------------------------------------------------------------------------------------
 // Skinny-M variant (the query stream: M = B * num_queries = 800 rows at the benchmark size).  A 128x128
@@ -295,9 +295,9 @@ __device__ __forceinline__ void gemm_nt_bf16_skinny_body(const FastArgs& p) {
     const bool va = bm + r < p.M, vb0 = bn + r < p.N, vb1 = bn + 32 + r < p.N;
     // the contraction index may be permuted freely as long as both operands agree: lane (r, h) takes the 32
     // consecutive elements [h*32, h*32+32) of each 64-element batch, 8 per MFMA
-    const bf16_t* pa = p.A + (int64_t)(bm + r) * p.lda + (wave * kslice) % p.kwrap + h * 32;  // (kwrap % kslice == 0: launcher)
-    const bf16_t* pb0 = p.B + (int64_t)(bn + r) * p.ldb + wave * kslice + h * 32;
-    const bf16_t* pb1 = pb0 + (int64_t)32 * p.ldb;
+    const h16_t* pa = p.A + (int64_t)(bm + r) * p.lda + (wave * kslice) % p.kwrap + h * 32;  // (kwrap % kslice == 0: launcher)
+    const h16_t* pb0 = p.B + (int64_t)(bn + r) * p.ldb + wave * kslice + h * 32;
+    const h16_t* pb1 = pb0 + (int64_t)32 * p.ldb;
     const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
     uint4 a[4], b0[4], b1[4], na[4], nb0[4], nb1[4];
     auto load = [&](uint4 (&xa)[4], uint4 (&xb0)[4], uint4 (&xb1)[4], int bt) {
@@ -316,8 +316,8 @@ __device__ __forceinline__ void gemm_nt_bf16_skinny_body(const FastArgs& p) {
         if (bt + 1 < nb) load(na, nb0, nb1, bt + 1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b0[i]), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b1[i]), acc1, 0, 0, 0);
+            acc0 = SVOL_MFMA_32x32x16_H16(__builtin_bit_cast(h16x8, a[i]), __builtin_bit_cast(h16x8, b0[i]), acc0, 0, 0, 0);
+            acc1 = SVOL_MFMA_32x32x16_H16(__builtin_bit_cast(h16x8, a[i]), __builtin_bit_cast(h16x8, b1[i]), acc1, 0, 0, 0);
         }
         if (bt + 1 < nb) {
 #pragma unroll
@@ -358,8 +358,8 @@ __device__ __forceinline__ void gemm_nt_bf16_skinny_body(const FastArgs& p) {
                 if (p.colscale) v[e] *= p.colscale[n0 + e];
             }
             if (p.pre) {
-                Out4<bf16_t>::store(p.pre + (int64_t)m * p.ldp + n0, f32x4{v[0], v[1], v[2], v[3]});
-                Out4<bf16_t>::store(p.pre + (int64_t)m * p.ldp + n0 + 4, f32x4{v[4], v[5], v[6], v[7]});
+                Out4<h16_t>::store(p.pre + (int64_t)m * p.ldp + n0, f32x4{v[0], v[1], v[2], v[3]});
+                Out4<h16_t>::store(p.pre + (int64_t)m * p.ldp + n0 + 4, f32x4{v[4], v[5], v[6], v[7]});
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -380,8 +380,8 @@ __device__ __forceinline__ void gemm_nt_bf16_skinny_body(const FastArgs& p) {
         }
     } else {  // epi 1: v = acc * gelu'(aux), column sums of v
         if (mv) {
-            const bf16_t* X = p.aux + (int64_t)m * p.ldaux + n0;
-            const f32x4 x0 = Out4<bf16_t>::load(X), x1 = Out4<bf16_t>::load(X + 4);
+            const h16_t* X = p.aux + (int64_t)m * p.ldaux + n0;
+            const f32x4 x0 = Out4<h16_t>::load(X), x1 = Out4<h16_t>::load(X + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] *= dact_fast(x0[e], p.act); v[4 + e] *= dact_fast(x1[e], p.act); }
         } else {
@@ -407,7 +407,7 @@ __device__ __forceinline__ void gemm_nt_bf16_skinny_body(const FastArgs& p) {
     }
 }
 __global__ __launch_bounds__(256) void gemm_nt_bf16_skinny_f32(FastArgs p) { gemm_nt_bf16_skinny_body<float>(p); }
-__global__ __launch_bounds__(256) void gemm_nt_bf16_skinny_b16(FastArgs p) { gemm_nt_bf16_skinny_body<bf16_t>(p); }
+__global__ __launch_bounds__(256) void gemm_nt_bf16_skinny_b16(FastArgs p) { gemm_nt_bf16_skinny_body<h16_t>(p); }
 
 }  // namespace
 
@@ -435,7 +435,7 @@ int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ld
     if (res && ((ldr * celt) % (4 * celt) || (reinterpret_cast<uintptr_t>(res) % (4 * celt)))) return SVOL_E_UNSUPPORTED;
     if (pre && (ldp % 4 || (reinterpret_cast<uintptr_t>(pre) % 8))) return SVOL_E_UNSUPPORTED;
     if (aux && (ldaux % 4 || (reinterpret_cast<uintptr_t>(aux) % 8))) return SVOL_E_UNSUPPORTED;
-    FastArgs p{(const bf16_t*)A, (const bf16_t*)B, C, bias, colscale, (bf16_t*)pre, res, (const bf16_t*)aux, colsum,
+    FastArgs p{(const h16_t*)A, (const h16_t*)B, C, bias, colscale, (h16_t*)pre, res, (const h16_t*)aux, colsum,
                lda, ldb, ldc, ldp, ldr, ldaux, (int)M, (int)N, (int)K, act, epi};
     p.kwrap = (int)kwrap;
     if (kwrap == K) {   // K = 256, tall M: weight-stationary kernel (gemm_ws_bf16.hip)
@@ -470,6 +470,7 @@ int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ld
     return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
 }
 
+#ifndef SVOL_H16_FP16   // (the ResNet extractor is a bf16 / fp32 path)
 // Implicit-GEMM convolution on NHWC bf16 activations: y[(n,ho,wo), co] = act(sum_{ky,kx,c} x[n, ho*s-p+ky,
 // wo*s-p+kx, c] * w[co, (ky,kx,c)] + bias[co] (+ residual)), the 128x128 tile kernel above with the A operand gathered by the
 // LDS-DMA loads themselves (padding = out-of-range buffer offsets, which read as zero).  C % 32 == 0.
@@ -488,7 +489,7 @@ extern "C" int svol_conv_nhwc(const void* x, const void* w, int64_t ldw, void* y
     const int64_t a_bytes = N * H * W * C * 2;
     if (a_bytes >= 0x7ffffff0ll || M >= (1ll << 31) || (int64_t)128 * ldw * 2 >= (1ll << 31)) return SVOL_E_UNSUPPORTED;
     if (act != SVOL_ACT_NONE && act != SVOL_ACT_RELU && act != SVOL_ACT_RELU_RES) return SVOL_E_UNSUPPORTED;
-    FastArgs p{(const bf16_t*)x, (const bf16_t*)w, y, bias, nullptr, nullptr, residual, nullptr, nullptr,
+    FastArgs p{(const h16_t*)x, (const h16_t*)w, y, bias, nullptr, nullptr, residual, nullptr, nullptr,
                0, ldw, Cout, 0, Cout, 0, (int)M, (int)Cout, (int)K, act, 0,
                (int)H, (int)W, (int)C, (int)kw, (int)stride, (int)pad, (int)Ho, (int)Wo, a_bytes, (int)K};
     dim3 grid((unsigned)((Cout + 127) / 128), (unsigned)((M + 127) / 128));
@@ -498,4 +499,4 @@ extern "C" int svol_conv_nhwc(const void* x, const void* w, int64_t ldw, void* y
     else hipLaunchKernelGGL(conv_nhwc_bf16_k32, grid, dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
 }
-
+#endif

@@ -19,7 +19,7 @@
 namespace {
 
 struct N256Args {
-    const bf16_t* A; const bf16_t* W; void* C;
+    const h16_t* A; const h16_t* W; void* C;
     const float* bias; const float* res;
     int64_t lda, ldw, ldc, ldr;
     int M, K, act, nrt;  // nrt: row tiles per column group (padded to a multiple of 8 when there are several groups)
@@ -142,8 +142,8 @@ __device__ __forceinline__ void gemm_n256_body(const N256Args& p) {
         for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
-                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[nt]),
-                                                                      __builtin_bit_cast(bf16x8, af[mt]), acc[nt][mt], 0, 0, 0);
+                acc[nt][mt] = SVOL_MFMA_16x16x32_H16(__builtin_bit_cast(h16x8, wf[nt]),
+                                                                      __builtin_bit_cast(h16x8, af[mt]), acc[nt][mt], 0, 0, 0);
     };
     int kt = 0;
     for (; kt + 3 <= nk; kt += 3) {
@@ -188,10 +188,10 @@ __device__ __forceinline__ void gemm_n256_body(const N256Args& p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                bf16x8 o;
+                h16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-                *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n0) = o;
+                for (int e = 0; e < 8; ++e) o[e] = (h16_t)v[e];
+                *reinterpret_cast<h16x8*>(reinterpret_cast<h16_t*>(p.C) + (int64_t)m * p.ldc + n0) = o;
             }
         }
     }
@@ -220,7 +220,7 @@ int svol_gemm_n256_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, 
     int64_t nrt = (M + BM - 1) / BM;
     if (ncg > 1) nrt = (nrt + 7) / 8 * 8;
     if (nrt * ncg > (1ll << 30)) return SVOL_E_UNSUPPORTED;
-    N256Args p{(const bf16_t*)A, (const bf16_t*)W, C, bias, (const float*)res, lda, ldw, ldc, ldr, (int)M, (int)K, act, (int)nrt,
+    N256Args p{(const h16_t*)A, (const h16_t*)W, C, bias, (const float*)res, lda, ldw, ldc, ldr, (int)M, (int)K, act, (int)nrt,
                (int)(kwrap / BK)};
     dim3 grid((unsigned)(nrt * ncg));
     if (out_f32) hipLaunchKernelGGL(gemm_n256_bf16_f32, grid, dim3(256), 0, s, p);

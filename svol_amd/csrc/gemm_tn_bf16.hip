@@ -23,7 +23,7 @@
 namespace {
 
 struct TnFastArgs {
-    const bf16_t* A; const bf16_t* B; float* C; float* colsum;
+    const h16_t* A; const h16_t* B; float* C; float* colsum;
     int64_t lda, ldb, ldc;
     int Mc, N, K, m_chunk, ktiles, splits;
 };
@@ -32,7 +32,7 @@ constexpr int CT = 32;            // rows per slab
 constexpr int STG = 4;            // ring slots
 constexpr int OPB = CT * 256;     // bytes per operand slab
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
-typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+typedef __attribute__((address_space(3))) h16x4* lds_bf16x4_ptr;
 
 // physical byte offset of element (row, col) inside a slab image
 __device__ __forceinline__ int phys(int row, int col) {
@@ -92,9 +92,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_dma(TnFastArgs p) {
     f32x4 cs[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 ones;
+    h16x8 ones;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
+    for (int j = 0; j < 8; ++j) ones[j] = (h16_t)1.0f;
 
     // fragment addresses: transposed read of rows 4*fq + q (+16), 4 columns at 4*pp of 16-column tile t
     const int q = fr >> 2, pp = fr & 3;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_dma(TnFastArgs p) {
         // the fragment reads are inline asm on purpose: hipcc cannot tell which ring slot an LDS-DMA wrote, so any
         // LDS read it can see gets an s_waitcnt vmcnt(0) in front of it, which would drain the slabs in flight
         const unsigned sl = (unsigned)(size_t)(lds_void_ptr)smem + (unsigned)((t % STG) * (2 * OPB));
-        bf16x4 a0[4], a1[4], b0[4], b1[4];
+        h16x4 a0[4], a1[4], b0[4], b1[4];
         asm volatile(
             "ds_read_b64_tr_b16 %0, %16\n\t"
             "ds_read_b64_tr_b16 %1, %16 offset:4096\n\t"
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_dma(TnFastArgs p) {
             : "v"(sl + offA[0]), "v"(sl + offA[1]), "v"(sl + offA[2]), "v"(sl + offA[3]), "v"(sl + offB[0]),
               "v"(sl + offB[1]), "v"(sl + offB[2]), "v"(sl + offB[3])
             : "memory");
-        bf16x8 af[4], bfr[4];
+        h16x8 af[4], bfr[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             af[i] = __builtin_shufflevector(a0[i], a1[i], 0, 1, 2, 3, 4, 5, 6, 7);
@@ -154,10 +154,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_dma(TnFastArgs p) {
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
-                acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
+                acc[nt][kt] = SVOL_MFMA_16x16x32_H16(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
         if (do_cs) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) cs[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], ones, cs[nt], 0, 0, 0);
+            for (int nt = 0; nt < 4; ++nt) cs[nt] = SVOL_MFMA_16x16x32_H16(af[nt], ones, cs[nt], 0, 0, 0);
         }
     }
     // C[n][k] += acc: row (output n) = nt*16 + fq*4 + r, col (output k) = kt*16 + fr
@@ -205,7 +205,7 @@ int svol_gemm_tn_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ld
     if (splits * tiles > (1ll << 30)) return SVOL_E_UNSUPPORTED;
     const int64_t ldmax = lda > ldb ? lda : ldb;
     if (chunk * ldmax * 2 >= (1ll << 31)) return SVOL_E_UNSUPPORTED;  // 32-bit buffer offsets
-    TnFastArgs p{(const bf16_t*)A, (const bf16_t*)B, C, colsum, lda, ldb, ldc, (int)Mc, (int)N, (int)K, (int)chunk,
+    TnFastArgs p{(const h16_t*)A, (const h16_t*)B, C, colsum, lda, ldb, ldc, (int)Mc, (int)N, (int)K, (int)chunk,
                  (int)((K + 127) / 128), (int)splits};
     hipLaunchKernelGGL(gemm_tn_bf16_dma, dim3((unsigned)(splits * tiles)), dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;

@@ -24,8 +24,8 @@
 namespace {
 
 struct WsArgs {
-    const bf16_t* A; const bf16_t* W; void* C;
-    const float* bias; const float* colscale; bf16_t* pre; const void* res; const bf16_t* aux; float* colsum;
+    const h16_t* A; const h16_t* W; void* C;
+    const float* bias; const float* colscale; h16_t* pre; const void* res; const h16_t* aux; float* colsum;
     int64_t lda, ldw, ldc, ldp, ldr, ldaux;
     int M, N, act, tiles_per_wg, nchunk;
 };
@@ -104,7 +104,7 @@ __device__ __forceinline__ void gemm_ws_body(const WsArgs& p) {
             voffX[j] = (int)(((int64_t)row * p.ldr + (((s & 48) | ((s ^ row) & 15))) * 4) * 4);
         }
     } else if constexpr (MODE == 2) {  // aux plane: like the A plane (bf16, 256 columns)
-        const bf16_t* X = p.aux + (int64_t)row_base * p.ldaux + cg0;
+        const h16_t* X = p.aux + (int64_t)row_base * p.ldaux + cg0;
         const int cols = min(256, p.N - cg0);
         rX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)((((int64_t)rows_here - 1) * p.ldaux + cols) * 2), 0x00020000);
 #pragma unroll
@@ -136,7 +136,7 @@ __device__ __forceinline__ void gemm_ws_body(const WsArgs& p) {
     uint4 wf[4][8];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const bf16_t* wrow = p.W + (int64_t)(c0 + ws_col(t, fr)) * p.ldw + fq * 8;
+        const h16_t* wrow = p.W + (int64_t)(c0 + ws_col(t, fr)) * p.ldw + fq * 8;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) wf[t][ks] = active ? *reinterpret_cast<const uint4*>(wrow + ks * 32) : make_uint4(0, 0, 0, 0);
     }
@@ -197,8 +197,8 @@ __device__ __forceinline__ void gemm_ws_body(const WsArgs& p) {
         for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t][ks]),
-                                                                 __builtin_bit_cast(bf16x8, af[ks]), acc[t], 0, 0, 0);
+                acc[t] = SVOL_MFMA_16x16x32_H16(__builtin_bit_cast(h16x8, wf[t][ks]),
+                                                                 __builtin_bit_cast(h16x8, af[ks]), acc[t], 0, 0, 0);
         // ---- epilogue from the accumulators: this lane's row, two runs of 8 consecutive columns ----------
         const int m = row_base + j * TR + fr;
         float v[2][8];
@@ -215,13 +215,13 @@ __device__ __forceinline__ void gemm_ws_body(const WsArgs& p) {
                 if (p.pre) {
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
-                        bf16x8 o;
+                        h16x8 o;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[hf][e];
-                        *reinterpret_cast<bf16x8*>(p.pre + (int64_t)m * p.ldp + c0 + hf * 32 + fq * 8) = o;
+                        for (int e = 0; e < 8; ++e) o[e] = (h16_t)v[hf][e];
+                        *reinterpret_cast<h16x8*>(p.pre + (int64_t)m * p.ldp + c0 + hf * 32 + fq * 8) = o;
                     }
                 }
-                bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+                h16_t* C = reinterpret_cast<h16_t*>(p.C);
                 if (p.act == SVOL_ACT_GELU) {
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf)
@@ -235,10 +235,10 @@ __device__ __forceinline__ void gemm_ws_body(const WsArgs& p) {
                 }
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    bf16x8 o;
+                    h16x8 o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[hf][e];
-                    *reinterpret_cast<bf16x8*>(C + (int64_t)m * p.ldc + c0 + hf * 32 + fq * 8) = o;
+                    for (int e = 0; e < 8; ++e) o[e] = (h16_t)v[hf][e];
+                    *reinterpret_cast<h16x8*>(C + (int64_t)m * p.ldc + c0 + hf * 32 + fq * 8) = o;
                 }
             }
         } else if constexpr (MODE == 1) {
@@ -287,16 +287,16 @@ __device__ __forceinline__ void gemm_ws_body(const WsArgs& p) {
             const bool ok = active && m < p.M;
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-                const bf16x8 a8 = __builtin_bit_cast(bf16x8, ax[hf]);
-                bf16x8 o;
+                const h16x8 a8 = __builtin_bit_cast(h16x8, ax[hf]);
+                h16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float d = v[hf][e] * dact_fast((float)a8[e], p.act);  // rows past M: acc = 0 and aux = 0 (zero-filled slabs)
                     d = ok ? d : 0.f;
                     csum[hf][e] += d;
-                    o[e] = (bf16_t)d;
+                    o[e] = (h16_t)d;
                 }
-                if (ok) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + c0 + hf * 32 + fq * 8) = o;
+                if (ok) *reinterpret_cast<h16x8*>(reinterpret_cast<h16_t*>(p.C) + (int64_t)m * p.ldc + c0 + hf * 32 + fq * 8) = o;
             }
         }
     }
@@ -359,7 +359,7 @@ __device__ __forceinline__ void gemm_wsp_body(const WsArgs& p) {
     __amdgpu_buffer_rsrc_t rX = rA;
     int voffX[2] = {0, 0};
     if constexpr (MODE == 2) {
-        const bf16_t* X = p.aux + (int64_t)row_base * p.ldaux + cg0;
+        const h16_t* X = p.aux + (int64_t)row_base * p.ldaux + cg0;
         const int cols = min(256, p.N - cg0);
         rX = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)((((int64_t)rows_here - 1) * p.ldaux + cols) * 2), 0x00020000);
 #pragma unroll
@@ -385,7 +385,7 @@ __device__ __forceinline__ void gemm_wsp_body(const WsArgs& p) {
     uint4 wf[4][8];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const bf16_t* wrow = p.W + (int64_t)(c0 + ws_col(t, fr)) * p.ldw + fq * 8;
+        const h16_t* wrow = p.W + (int64_t)(c0 + ws_col(t, fr)) * p.ldw + fq * 8;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) wf[t][ks] = active ? *reinterpret_cast<const uint4*>(wrow + ks * 32) : make_uint4(0, 0, 0, 0);
     }
@@ -413,7 +413,7 @@ __device__ __forceinline__ void gemm_wsp_body(const WsArgs& p) {
     // the epilogue has no branch — one basic block with the MFMAs — and every wave issues the same number of stores;
     // per-lane offset constant, the slab advances the scalar offset (no address arithmetic in the loop)
     const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(reinterpret_cast<bf16_t*>(p.C) + (int64_t)row_base * p.ldc), 0,
+        (void*)(reinterpret_cast<h16_t*>(p.C) + (int64_t)row_base * p.ldc), 0,
         active ? (int)((((int64_t)rows_here - 1) * p.ldc + p.N) * 2) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(PRE ? p.pre + (int64_t)row_base * p.ldp : nullptr), 0,
@@ -459,8 +459,8 @@ __device__ __forceinline__ void gemm_wsp_body(const WsArgs& p) {
         for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t][ks]),
-                                                                 __builtin_bit_cast(bf16x8, af[ks]), acc[t], 0, 0, 0);
+                acc[t] = SVOL_MFMA_16x16x32_H16(__builtin_bit_cast(h16x8, wf[t][ks]),
+                                                                 __builtin_bit_cast(h16x8, af[ks]), acc[t], 0, 0, 0);
     };
     // epilogue of slab j from its accumulators (and, MODE 2, its aux fragment)
     auto epilogue = [&](int j, const f32x4 (&acc)[4], const u32x4_t (&axj)[2]) {
@@ -478,15 +478,15 @@ __device__ __forceinline__ void gemm_wsp_body(const WsArgs& p) {
                     if constexpr (SCALE) v[hf][e] *= scale8[hf][e];
                 }
             if constexpr (PRE) {
-                bf16x8 o[2];
+                h16x8 o[2];
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[hf][e] = (bf16_t)v[hf][e];
+                    for (int e = 0; e < 8; ++e) o[hf][e] = (h16_t)v[hf][e];
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[0]), rP, voffP, j * pstep, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[1]), rP, voffP + 64, j * pstep, 0);
             }
-            bf16x8 o[2];
+            h16x8 o[2];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -494,21 +494,21 @@ __device__ __forceinline__ void gemm_wsp_body(const WsArgs& p) {
                     float y = v[hf][e];
                     if constexpr (ACT == SVOL_ACT_GELU) y = gelu_fast(y);
                     if constexpr (ACT == SVOL_ACT_RELU) y = fmaxf(y, 0.f);
-                    o[hf][e] = (bf16_t)y;
+                    o[hf][e] = (h16_t)y;
                 }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[0]), rC, voffC, j * cstep, 0);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[1]), rC, voffC + 64, j * cstep, 0);
         } else {
-            bf16x8 o[2];
+            h16x8 o[2];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-                const bf16x8 a8 = __builtin_bit_cast(bf16x8, axj[hf]);
+                const h16x8 a8 = __builtin_bit_cast(h16x8, axj[hf]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     // rows past M and idle waves: acc = 0 (zero-filled slabs, zero W) and a finite derivative: d = 0
                     const float d = v[hf][e] * dact_fast((float)a8[e], ACT);
                     csum[hf][e] += d;
-                    o[hf][e] = (bf16_t)d;
+                    o[hf][e] = (h16_t)d;
                 }
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[0]), rC, voffC, j * cstep, 0);
@@ -631,7 +631,7 @@ int svol_gemm_ws_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, vo
         if (t8 >= 1 && (ntile + t8 - 1) / t8 == n8) { tpw = t8; nchunk = n8; }
     }
     if (nchunk * ncg > (1ll << 30)) return SVOL_E_UNSUPPORTED;
-    WsArgs p{(const bf16_t*)A, (const bf16_t*)W, C, bias, colscale, (bf16_t*)pre, res, (const bf16_t*)aux, colsum,
+    WsArgs p{(const h16_t*)A, (const h16_t*)W, C, bias, colscale, (h16_t*)pre, res, (const h16_t*)aux, colsum,
              lda, ldw, ldc, ldp, ldr, ldaux, (int)M, (int)N, act, (int)tpw, (int)nchunk};
     dim3 grid((unsigned)(ncg * nchunk));
     static const bool no_pipe = getenv("SVOL_WS_NO_PIPE") != nullptr;

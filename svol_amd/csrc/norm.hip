@@ -247,7 +247,7 @@ int svol_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float
     if (pos && pos_rows <= 0) return SVOL_E_INVALID;
     if (D % 4 || D > LN_MAX_PASSES * 256) return SVOL_E_UNSUPPORTED;
     if (dropout_p < 0.f || dropout_p >= 1.f) return SVOL_E_INVALID;
-    if (dtype != SVOL_BF16 && dtype != SVOL_F32) return SVOL_E_INVALID;
+    if (!svol_is16(dtype) && dtype != SVOL_F32) return SVOL_E_INVALID;
     if (M == 0) return SVOL_OK;
     const float inv_keep = 1.f / (1.f - dropout_p);
     const unsigned grid = (unsigned)((M + 3) / 4);
@@ -263,6 +263,8 @@ int svol_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float
     } while (0)
     if (dtype == SVOL_BF16 && x_f32) SVOL_LNF_NP(bf16_t, float);
     else if (dtype == SVOL_BF16) SVOL_LNF_NP(bf16_t, bf16_t);
+    else if (dtype == SVOL_F16 && x_f32) SVOL_LNF_NP(f16_t, float);
+    else if (dtype == SVOL_F16) SVOL_LNF_NP(f16_t, f16_t);
     else SVOL_LNF_NP(float, float);
 #undef SVOL_LNF_NP
 #undef SVOL_LNF
@@ -278,7 +280,7 @@ int svol_layernorm_bwd(const float* dy32, const void* dy, const void* dy2, const
         return SVOL_E_INVALID;
     if (D % 4 || D > LN_MAX_PASSES * 256) return SVOL_E_UNSUPPORTED;
     if (dropout_p < 0.f || dropout_p >= 1.f) return SVOL_E_INVALID;
-    if (dtype != SVOL_BF16 && dtype != SVOL_F32) return SVOL_E_INVALID;
+    if (!svol_is16(dtype) && dtype != SVOL_F32) return SVOL_E_INVALID;
     if (M == 0) return SVOL_OK;
     const float inv_keep = 1.f / (1.f - dropout_p);
     // ~2048 waves (512 workgroups); each wave walks `rpw` consecutive rows; one set of atomics per workgroup
@@ -302,6 +304,8 @@ int svol_layernorm_bwd(const float* dy32, const void* dy, const void* dy2, const
     } while (0)
     if (dtype == SVOL_BF16 && x_f32) SVOL_LNB_NP(bf16_t, float);
     else if (dtype == SVOL_BF16) SVOL_LNB_NP(bf16_t, bf16_t);
+    else if (dtype == SVOL_F16 && x_f32) SVOL_LNB_NP(f16_t, float);
+    else if (dtype == SVOL_F16) SVOL_LNB_NP(f16_t, f16_t);
     else SVOL_LNB_NP(float, float);
 #undef SVOL_LNB_NP
 #undef SVOL_LNB
@@ -317,6 +321,8 @@ int svol_posenc_sine(const float* mask, void* pos, int64_t B, int64_t L, int64_t
     dim3 grid((unsigned)((L + 63) / 64), (unsigned)B);
     if (dtype == SVOL_BF16)
         hipLaunchKernelGGL(posenc_kernel<bf16_t>, grid, dim3(256), 0, s, mask, (bf16_t*)pos, (int)L, (int)D);
+    else if (dtype == SVOL_F16)
+        hipLaunchKernelGGL(posenc_kernel<f16_t>, grid, dim3(256), 0, s, mask, (f16_t*)pos, (int)L, (int)D);
     else if (dtype == SVOL_F32)
         hipLaunchKernelGGL(posenc_kernel<float>, grid, dim3(256), 0, s, mask, (float*)pos, (int)L, (int)D);
     else return SVOL_E_INVALID;

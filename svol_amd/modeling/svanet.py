@@ -12,7 +12,7 @@ from .. import ops
 from .cross_modal_transformer import build_cross_modal_transformer
 from .position_encoding import build_position_encoding
 
-_DTYPES = {'bf16': torch.bfloat16, 'fp32': torch.float32, torch.bfloat16: torch.bfloat16,
+_DTYPES = {'bf16': torch.bfloat16, 'fp32': torch.float32, 'fp16': torch.float16, torch.float16: torch.float16, torch.bfloat16: torch.bfloat16,
            torch.float32: torch.float32}
 
 

@@ -36,7 +36,7 @@ from torch import nn
 
 from .. import ops
 
-_DTYPES = {'bf16': torch.bfloat16, 'fp32': torch.float32, torch.bfloat16: torch.bfloat16,
+_DTYPES = {'bf16': torch.bfloat16, 'fp32': torch.float32, 'fp16': torch.float16, torch.float16: torch.float16, torch.bfloat16: torch.bfloat16,
            torch.float32: torch.float32}
 
 

@@ -17,7 +17,7 @@ import torch
 from . import _lib
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_RELU_RES = 0, 1, 2, 3, 4
-_DT = {torch.float32: 0, torch.bfloat16: 1}
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}   # SVOL_F32 / SVOL_BF16 / SVOL_F16
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -378,7 +378,7 @@ def posenc_sine(mask_f32: torch.Tensor, D: int, dtype: torch.dtype) -> torch.Ten
 def _attn_ws(q, B, H, Lq, Lk, dh, masked):
     """scratch of the attention launches: partial results of the key-split (few queries, many keys), the key-tile classes of
     the masked fast kernels, or the per-workgroup redo flags of the fast unmasked forward; None when the library needs none."""
-    n = _lib.lib().svol_attn_ws_bytes(B, H, Lq, Lk, dh) if q.dtype == torch.bfloat16 else 0
+    n = _lib.lib().svol_attn_ws_bytes(B, H, Lq, Lk, dh) if q.dtype != torch.float32 else 0
     if n <= 0:
         return None
     return torch.empty((n // 4,), dtype=torch.float32, device=q.device)
@@ -509,6 +509,8 @@ class _WeightCache:
 
     def _refresh(self, key, st):
         dev, dtype = key
+        if dtype not in _DT:
+            return
         def alive(r, e):
             w = r()
             if w is None:
@@ -721,7 +723,7 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x2, y if act != ACT_NONE else None)
         ctx.WcT, ctx.act, ctx.shp, ctx.has_b = WcT, act, shp, b is not None
         ctx.need_dx = ctx.needs_input_grad[0]
-        epc = 8 if x.dtype == torch.bfloat16 else 4
+        epc = 4 if x.dtype == torch.float32 else 8
         ok = W.shape[0] % epc == 0
         ctx.sinks = (_claim(W, ok and ctx.needs_input_grad[1]), _claim(b, ok and ctx.needs_input_grad[2]))
         return y.view(*shp[:-1], W.shape[0])
@@ -739,7 +741,7 @@ class LinearFn(torch.autograd.Function):
             d = act_bwd(d, y, ctx.act)
         # out-features that are not a multiple of the 16-byte chunk (2-class / 4-coordinate heads):
         # zero-pad the contraction / column dimension
-        epc = 8 if d.dtype == torch.bfloat16 else 4
+        epc = 4 if d.dtype == torch.float32 else 8
         WcT = ctx.WcT
         Np = (N + epc - 1) // epc * epc
         if N % epc:
@@ -892,13 +894,13 @@ class AttnLNFn(torch.autograd.Function):
         # (xq / xq_pos fp32: q-projection, out-projection, residual and norm in exact fp32 GEMMs — a few hundred rows),
         # the L video tokens in bf16 (K / V projections and the attention core on the MFMA bf16 path).  q and O cross
         # the boundary through one rounding each.
-        mixed = (not self_attn) and dt == torch.float32 and xv.dtype == torch.bfloat16
+        mixed = (not self_attn) and dt == torch.float32 and xv.dtype != torch.float32
         dkv = xv.dtype if mixed else dt
         Wc, WcT = weights.get(W_in, dkv)
         Woc, WoT = weights.get(W_o, dt)
         # bf16: the projection GEMM emits q already multiplied by d_h^-1/2 * log2(e) (rounded once, in the fp32
         # epilogue), which lets the attention kernels exponentiate raw MFMA results
-        premul = (LOG2E / math.sqrt(dh)) if dkv == torch.bfloat16 else 0.0
+        premul = (LOG2E / math.sqrt(dh)) if dkv != torch.float32 else 0.0
         qscale = _qscale(d, premul, xq.device) if premul else None
         a_qp = xq_pos.reshape(B * Lq, d)
         a_q = xq.reshape(B * Lq, d)

@@ -95,6 +95,7 @@ class BucketedGradAllReduce:
             self._make_bucket(g)
         self._handles = []
         self._hooks = []
+        self.pending_scale = 1.0   # see finish(mean=False)
         self.fire_order: List[int] = []   # diagnostics: bucket index of every hook of the current step, in firing order
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         # the stream the caller computes on (the video half of the model, the criterion, the optimizer); re-read
@@ -189,8 +190,10 @@ class BucketedGradAllReduce:
                     raise RuntimeError('a parameter gradient was re-bound (zero_grad(set_to_none=True)?); use '
                                        'BucketedGradAllReduce.zero_grad() instead of optimizer.zero_grad()')
 
-    def finish(self):
-        """Wait for every in-flight bucket and turn sums into means.  Call after backward()."""
+    def finish(self, mean: bool = True):
+        """Wait for every in-flight bucket and turn sums into means.  Call after backward().
+        mean=False: leave the SUMS in the buckets and remember the factor (``pending_scale`` = 1 / world) for ``FlatAdamW.step()``,
+        which applies it inside its one pass over the gradients (no multiply launch per bucket)."""
         if self.on_gpu:
             # kernels that accumulate straight into the buckets (gradient sinks) may have run on the model's side
             # stream (query-stream / video-stream overlap): join it before anyone reads the buckets
@@ -210,8 +213,11 @@ class BucketedGradAllReduce:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         if self.world > 1:
             inv = 1.0 / self.world
-            for b in self.buckets:
-                b['flat'].mul_(inv)
+            if mean:
+                for b in self.buckets:
+                    b['flat'].mul_(inv)
+            else:
+                self.pending_scale = inv
         self._handles.clear()
 
     def bucket_fire_spans(self):
@@ -262,6 +268,9 @@ class FlatAdamW(torch.optim.Optimizer):
         super().__init__(plist, defaults)
         self.reducer = reducer
         self.t = 0
+        # the loss was multiplied by this before backward (fp16 operands: gradients of ~1e-6 underflow otherwise); divided back out
+        # inside the update kernel
+        self.loss_scale = 1.0
         self.flat = []      # per bucket: flat parameters / first / second moments
         self._slot = {}     # id(param) -> (bucket index, offset, numel)
         for bi, b in enumerate(reducer.buckets):
@@ -287,10 +296,12 @@ class FlatAdamW(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
         self.t += 1
+        gscale = float(self.reducer.pending_scale) / float(self.loss_scale)
+        self.reducer.pending_scale = 1.0
         for b, st in zip(self.reducer.buckets, self.flat):
             rc = _lib.lib().svol_adamw_flat(_ptr(st['p']), _ptr(b['flat']), _ptr(st['m']), _ptr(st['v']), st['p'].numel(),
                                             float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
-                                            float(g['weight_decay']), self.t, 1.0, _stream())
+                                            float(g['weight_decay']), self.t, gscale, _stream())
             _lib.check(rc, 'svol_adamw_flat')
         return loss
 

@@ -16,11 +16,13 @@ CASES = ['tiny_video', 'tiny_frame', 'cfg1_video', 'cfg1_frame', 'mid_video', 'm
 
 def main():
     mode = 'query stream bf16 (SVOL_QUERY_BF16=1)' if os.environ.get('SVOL_QUERY_BF16') else 'query stream fp32 (default)'
-    print(f'bf16 compute mode, {mode}\n')
+    dt = torch.float16 if os.environ.get('SVOL_TABLE_DTYPE') == 'fp16' else torch.bfloat16
+    split = 'single-bf16 V weights (SVOL_NO_SPLIT_V=1)' if os.environ.get('SVOL_NO_SPLIT_V') else 'split hi + lo V weights (default)'
+    print(f'{"fp16" if dt == torch.float16 else "bf16"} compute mode, {mode}' + (f', {split}' if dt == torch.bfloat16 else '') + '\n')
     print('| case | max abs logit err (final) | max abs box err (final) | aux logits | aux boxes | rms logit err | max golden logit |')
     print('|---|---|---|---|---|---|---|')
     for name in CASES:
-        z, meta, args, out, ld, tot, model, crit = G.run_head_case(name, torch.bfloat16)
+        z, meta, args, out, ld, tot, model, crit = G.run_head_case(name, dt)
         dl = out['pred_logits'].cpu() - torch.from_numpy(z['pred_logits'])
         db = out['pred_boxes'].cpu() - torch.from_numpy(z['pred_boxes'])
         al = ab = float('nan')

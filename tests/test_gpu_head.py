@@ -20,6 +20,15 @@ def test_head_golden(name, dtype):
     assert not bad, '\n'.join(f'{k}: err={e:.3e} tol={t:.1e}' for k, (e, t) in bad.items())
 
 
+@pytest.mark.parametrize('name', ['cfg1_video', 'cfg1_frame', 'mid32_video', 'cfg2_b1_video', 'cfg2_b1_video_pad'])
+def test_head_golden_fp16(name):
+    """fp16 operands (``--compute_dtype fp16``, BASELINE configs[4]'s stated dtype): the same goldens, outputs within 3e-3."""
+    from tests import gpu_checks as G
+    res = G.check_head_case(name, torch.float16)
+    bad = {k: v for k, v in res.items() if not (v[0] <= v[1])}
+    assert not bad, '\n'.join(f'{k}: err={e:.3e} tol={t:.1e}' for k, (e, t) in bad.items())
+
+
 @pytest.mark.parametrize('name', ['cfg1_video', 'cfg1_frame'])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
 def test_head_golden_gradient_sinks(name, dtype):
