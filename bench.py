@@ -45,7 +45,7 @@ def cpu_baseline(seconds_budget=30.0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    cores = max(1, min(cores, 16))  # a one-GPU box shares its host: 16 cores is this job's CPU share
+    cores = max(1, cores)   # every core of this job's affinity mask (a one-GPU box of the pool gives 16); stated in the result
     torch.set_num_threads(cores)
     args = syn.cfg2_args('video_matcher')
     B, T, P = 1, 32, 196
@@ -135,6 +135,18 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+    cores_rank = None
+    if world > 1:
+        # N Python issuers share one host: give every rank its own slice of the job's cores (main thread + autograd thread), so that
+        # a rank's launches are not descheduled behind another rank's — and report each rank's issue time (host_issue_ms_per_rank)
+        try:
+            aff = sorted(os.sched_getaffinity(0))
+            per = max(1, len(aff) // world)
+            mine = aff[(local_rank * per) % len(aff):(local_rank * per) % len(aff) + per]
+            os.sched_setaffinity(0, set(mine))
+            cores_rank = len(mine)
+        except (AttributeError, OSError):
+            pass
     n_ranks_seen = 1
     if world > 1:  # every rank of the job really is in the communicator (RCCL / gloo): sum of ones
         ones = torch.ones((1,), device=dev)
@@ -240,6 +252,14 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.timer.disable()
+    # host time to ISSUE one step, measured on an EMPTY queue right after the timed region (3 free-running steps): inside the timed
+    # region the host runs ahead until the HIP queue pushes back (a few steps), after which a step's host wall time is the GPU's
+    free_ms = []
+    for _ in range(3):
+        ts = time.perf_counter()
+        step()
+        free_ms.append((time.perf_counter() - ts) * 1e3)
+    torch.cuda.synchronize()
     if use_graph:
         # per-kernel durations cannot be bracketed inside a graph replay: time the SAME kernels with HIP events on
         # the launch stream over eager steps run right after the timed region (same process, same shapes, same data)
@@ -250,10 +270,15 @@ def main():
             eager_step()
         torch.cuda.synchronize()
         ops.timer.disable()
+    issue_per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine_t = torch.tensor([sorted(free_ms)[1]], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(allt, mine_t)
+        issue_per_rank = [round(float(x.item()), 2) for x in allt]
     final_loss = float(loss.detach())
     assert final_loss == final_loss, 'loss is NaN'
 
@@ -305,6 +330,17 @@ def main():
                                    % (os.path.basename(files[-1]), meta.get('git_head', 'n/a: round-1 file')))
             except (OSError, ValueError, KeyError, IndexError, AttributeError):
                 pass
+        # at d_h = 32 the attention core is bound by instruction ISSUE (softmax exp / VALU beside the MFMAs), not by the
+        # matrix pipe.  Floor per 32x32 score block from the guide's issue costs (MFMA 32x32x16: 32 cycles of pipe, 8 of issue; v_exp 8;
+        # other VALU 4; costs add per SIMD — profiles/round2_pmc_attention.md): forward 309, dQ pass 338, dK/dV pass 452 cycles.
+        CLK_GHZ, SIMDS = 2.4, 256 * 4
+        blocks = B * args.nheads * (L / 32.0) ** 2
+        floor_fwd_ms = blocks * 309 / (SIMDS * CLK_GHZ * 1e9) * 1e3
+        floor_bwd_ms = blocks * (338 + 452) / (SIMDS * CLK_GHZ * 1e9) * 1e3
+        issue = {'model': 'per 32x32 block: fwd 309, dQ 338, dK/dV 452 issue cycles per SIMD (exp 8, VALU 4, MFMA issue 8 + LDS), '
+                          '%d SIMDs at %.1f GHz' % (SIMDS, CLK_GHZ),
+                 'fwd_floor_ms': floor_fwd_ms, 'bwd_floor_ms': floor_bwd_ms,
+                 'fwd_frac_of_issue_floor': floor_fwd_ms / fwd[1], 'bwd_frac_of_issue_floor': floor_bwd_ms / bwd[1]}
         roof = {'bound': 'mfma', 'kernel': which, 'achieved': ach, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': ach / PEAK_BF16_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes per launch (HBM side)',
                 'traffic_source': traffic_src,
@@ -312,7 +348,8 @@ def main():
                 'attn_fwd_ms': fwd[1], 'attn_bwd_ms': bwd[1],
                 'attn_fwd_tflops': attn_fwd_flop / (fwd[1] * 1e-3) / 1e12,
                 'whole_step_tflops': fps * gf_frame / 1e3 / world,
-                'whole_step_frac_of_peak': fps * gf_frame / 1e3 / world / PEAK_BF16_MFMA_TFLOPS}
+                'whole_step_frac_of_peak': fps * gf_frame / 1e3 / world / PEAK_BF16_MFMA_TFLOPS,
+                'issue_bound_frac': (floor_bwd_ms / bwd[1]) if bwd[1] >= fwd[1] else (floor_fwd_ms / fwd[1]), 'issue_bound': issue}
 
     if rank == 0:
         res = {
@@ -332,13 +369,14 @@ def main():
             'n_ranks_seen': n_ranks_seen, 'dist_backend': backend if world > 1 else None,
             'final_loss': final_loss,
             # host time to ISSUE a step (Python + launches, no sync): when it approaches ms_per_step the run is host-bound
-            # median over the timed steps: once the host is ~10 steps ahead the HIP queue pushes back and a step's host time becomes
-            # the GPU's (the mean includes those; both are reported)
-            'host_issue_ms_per_step': sorted(host_ms)[len(host_ms) // 2],
-            'host_issue_ms_per_step_mean': t_issued / a.steps * 1e3,
-            'host_issue_ms_first_last': [round(x, 2) for x in host_ms[:3] + host_ms[-3:]],
+            'host_issue_ms_per_step': sorted(free_ms)[1],            # median of 3 steps issued into an empty queue (see above)
+            'host_wall_ms_per_step_in_timed_region': t_issued / a.steps * 1e3,   # includes queue back-pressure
+            'host_wall_ms_first_last': [round(x, 2) for x in host_ms[:3] + host_ms[-3:]],
             'launch_mode': 'hipGraph replay (whole step captured)' if use_graph else 'eager',
         }
+        if issue_per_rank is not None:
+            res['host_issue_ms_per_rank'] = issue_per_rank
+            res['host_cores_per_rank'] = cores_rank
         if roof:
             res['roofline'] = roof
         if world == 1 and not a.no_cpu_baseline:

@@ -161,7 +161,11 @@ __device__ __forceinline__ void mma_second(f32x16& acc, const uint4 (&a)[2], con
     for (int s = 0; s < 2; ++s) {
         h16x8 b;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) b[j] = (h16_t)x[8 * s + j];
+        for (int j = 0; j < 8; j += 2) {   // packed conversion (v_cvt_pk_*): the loop is issue-bound, one instruction per pair
+            const h16x2 pr = cvt_pk_h16(x[8 * s + j], x[8 * s + j + 1]);
+            b[j] = pr[0];
+            b[j + 1] = pr[1];
+        }
         acc = SVOL_MFMA_32x32x16_H16(__builtin_bit_cast(h16x8, a[s]), b, acc, 0, 0, 0);
     }
 }

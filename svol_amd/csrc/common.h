@@ -34,7 +34,7 @@ typedef f16x2 h16x2;
 #define SVOL_H16_NINF_LO 0x0000FC00u   /* (-inf, 0) */
 #define SVOL_H16_DTYPE SVOL_F16
 #define SVOL_H16_NEG_BIG (-6.0e4f)   /* most negative row constant that is still finite as an fp16 operand */
-#define SVOL_H16_PSUM_MAX 3.0e4f   /* a softmax numerator that would not fit fp16 (65504) makes the row sum exceed this */
+#define SVOL_H16_PSUM_MAX 6.5e4f   /* a softmax numerator that would not fit fp16 (65504) makes the row sum exceed this */
 #define svol_gemm_nt_bf16_fast svol_gemm_nt_f16_fast
 #define svol_gemm_tn_bf16_fast svol_gemm_tn_f16_fast
 #define svol_gemm_ws_bf16 svol_gemm_ws_f16
@@ -61,6 +61,16 @@ typedef bf16x2 h16x2;
 typedef __attribute__((ext_vector_type(4))) short i16x4;
 __device__ __forceinline__ f16x4 svol_ds_read_tr16_f16(__attribute__((address_space(3))) f16x4* p) {
     return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)p));
+}
+// two fp32 -> one packed pair of the TU's 16-bit type in ONE instruction (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32).  hipcc finds the bf16
+// form by itself from scalar casts; the fp16 form only from a vector conversion (scalar casts became 2 x v_cvt_f16_f32 + v_pack).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ h16x2 cvt_pk_h16(float a, float b) {
+#ifdef SVOL_H16_FP16
+    return __builtin_convertvector((f32x2){a, b}, f16x2);
+#else
+    return h16x2{(bf16_t)a, (bf16_t)b};
+#endif
 }
 static inline bool svol_is16(int dtype) { return dtype == SVOL_BF16 || dtype == SVOL_F16; }
 

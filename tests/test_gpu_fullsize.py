@@ -239,7 +239,7 @@ def test_fast_forward_flags_overflow_and_the_safe_kernel_repairs_it(dtype, qv, k
     first for 5 queries of one head.  Checked against fp64 on the whole tensor, and the flags are read back.
     fp16 operands add a second way to overflow: a softmax numerator above 65504 that is still finite in fp32 — the third case puts
     the hot score only 2^24 above the anchor, which the fp32 row sum survives and the fp16 P operand would not; the fp16 build
-    flags any row sum above 3e4."""
+    flags any row sum above 6.5e4."""
     import math
     from svol_amd import _lib
     B, H, L, dh = 1, 8, 384, 32

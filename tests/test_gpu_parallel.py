@@ -168,3 +168,24 @@ def test_bench_spawns_its_own_ranks():
     q = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--batch', '-1'], env=env,
                        capture_output=True, text=True, timeout=300, cwd=root)
     assert q.returncode != 0
+
+
+def test_bench_world4_gloo_rehearsal_reports_per_rank_issue_time():
+    """the N > 1 bench path rehearsed at world 4 with the FULL cfg2 model on the one card (gloo; RCCL wants one GPU
+    per rank): every rank pins itself to its own slice of the host cores and rank 0 reports each rank's host issue time — at N = 8
+    eight Python issuers share one host, and whether they keep their GPUs fed is what decides the scaling curve."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0', SVOL_DIST_BACKEND='gloo')
+    root = os.path.dirname(HERE)
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4', '--steps', '2', '--warmup', '1',
+                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l_ for l_ in p.stdout.splitlines() if l_.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 4 and res['n_ranks_seen'] == 4 and res['config']['global_batch'] == 32
+    assert len(res['host_issue_ms_per_rank']) == 4 and all(0 < x < 1000 for x in res['host_issue_ms_per_rank'])
+    assert res['host_cores_per_rank'] >= 1
+    print('world-4 gloo rehearsal: ms/step', res['ms_per_step'], 'issue per rank', res['host_issue_ms_per_rank'],
+          'cores per rank', res['host_cores_per_rank'])
