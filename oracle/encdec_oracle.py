@@ -7,7 +7,10 @@ CPU restatement (plain torch tensor arithmetic on state-dict tensors, no nn.Modu
   svanet_variant_forward  lib/modeling/svanet_variants.py:74-247 (concat_to_seq / append_to_seq / concat_to_qry)
   sketch_detr_forward     lib/modeling/sketch_detr.py:47-75
 
-Eval-mode semantics (every dropout is the identity).  Only ``tests/`` may import this module; the product
+Eval-mode semantics by default (every dropout is the identity); with ``drop=MaskFeed(...)`` the training-mode forward of the
+Transformer with GIVEN keep masks, consumed in the order the reference calls dropout (attention probabilities inside
+nn.MultiheadAttention, dropout1, [cross-attention probabilities, dropout2,] FFN dropout, dropout2 / dropout3 —
+transformer.py:165-208,225-283).  Only ``tests/`` may import this module; the product
 (``svol_amd``) never does.  Parity is PINNED: tests/test_oracle_encdec.py checks these functions against fixtures the
 reference itself produced (tests/golden/make_golden_encdec.py imports /root/reference on CPU).
 """
@@ -18,6 +21,28 @@ import torch
 from .svol_oracle import _ln, _mha_p, input_proj, layer_norm, linear, mha, position_embedding_sine  # noqa: F401
 
 
+class MaskFeed:
+    """keep masks (already scaled: 0 or 1/(1-p)) handed out in call order; the tensor shapes must match the calls.
+    seq_first: the masks of the [B,L,d] activations are stored in the reference's [L,B,d] element order (masks recorded from the
+    reference itself); the attention-probability masks are [B*h, Lq, Lk] = batch-first in both worlds."""
+
+    def __init__(self, masks, seq_first=False):
+        self.masks, self.i, self.seq_first = list(masks), 0, seq_first
+
+    def __call__(self, x):
+        m = self.masks[self.i]
+        self.i += 1
+        assert m.numel() == x.numel(), (self.i - 1, tuple(m.shape), tuple(x.shape))
+        if self.seq_first and x.dim() == 3:
+            B, L, D = x.shape
+            m = m.reshape(L, B, D).transpose(0, 1)
+        return x * m.reshape(x.shape).to(x.dtype)
+
+
+def _id(x):
+    return x
+
+
 def _act(x, activation: str):
     if activation == 'relu':
         return torch.relu(x)
@@ -26,45 +51,48 @@ def _act(x, activation: str):
     raise RuntimeError(activation)
 
 
-def _ffn(x, sd, p, activation):
-    return linear(_act(linear(x, sd[p + 'linear1.weight'], sd[p + 'linear1.bias']), activation),
+def _ffn(x, sd, p, activation, dr=_id):
+    return linear(dr(_act(linear(x, sd[p + 'linear1.weight'], sd[p + 'linear1.bias']), activation)),
                   sd[p + 'linear2.weight'], sd[p + 'linear2.bias'])
 
 
-def encoder_layer(sd, p, h, src, pad_mask, pos, pre_norm, activation='relu'):
-    """TransformerEncoderLayer.forward_post / forward_pre, transformer.py:175-208 (batch-first)."""
+def encoder_layer(sd, p, h, src, pad_mask, pos, pre_norm, activation='relu', drop=None):
+    """TransformerEncoderLayer.forward_post / forward_pre, transformer.py:175-208 (batch-first).  drop: MaskFeed or None."""
+    dr = drop if drop is not None else _id
     if not pre_norm:
         qk = src + pos
-        o, _ = mha(qk, qk, src, *_mha_p(sd, p + 'self_attn'), h, key_padding_mask=pad_mask)
-        src = _ln(src + o, sd, p + 'norm1')
-        return _ln(src + _ffn(src, sd, p, activation), sd, p + 'norm2')
+        o, _ = mha(qk, qk, src, *_mha_p(sd, p + 'self_attn'), h, key_padding_mask=pad_mask, p_drop=drop)
+        src = _ln(src + dr(o), sd, p + 'norm1')
+        return _ln(src + dr(_ffn(src, sd, p, activation, dr)), sd, p + 'norm2')
     s2 = _ln(src, sd, p + 'norm1')
     qk = s2 + pos
-    o, _ = mha(qk, qk, s2, *_mha_p(sd, p + 'self_attn'), h, key_padding_mask=pad_mask)
-    src = src + o
-    return src + _ffn(_ln(src, sd, p + 'norm2'), sd, p, activation)
+    o, _ = mha(qk, qk, s2, *_mha_p(sd, p + 'self_attn'), h, key_padding_mask=pad_mask, p_drop=drop)
+    src = src + dr(o)
+    return src + dr(_ffn(_ln(src, sd, p + 'norm2'), sd, p, activation, dr))
 
 
-def decoder_layer(sd, p, h, tgt, memory, pad_mask, pos, query_pos, pre_norm, activation='relu'):
+def decoder_layer(sd, p, h, tgt, memory, pad_mask, pos, query_pos, pre_norm, activation='relu', drop=None):
     """TransformerDecoderLayer.forward_post / forward_pre, transformer.py:229-283.  Returns (tgt, att [B,N,L])."""
+    dr = drop if drop is not None else _id
     if not pre_norm:
         qk = tgt + query_pos
-        o, _ = mha(qk, qk, tgt, *_mha_p(sd, p + 'self_attn'), h)
-        tgt = _ln(tgt + o, sd, p + 'norm1')
-        o, att = mha(tgt + query_pos, memory + pos, memory, *_mha_p(sd, p + 'multihead_attn'), h, key_padding_mask=pad_mask)
-        tgt = _ln(tgt + o, sd, p + 'norm2')
-        return _ln(tgt + _ffn(tgt, sd, p, activation), sd, p + 'norm3'), att
+        o, _ = mha(qk, qk, tgt, *_mha_p(sd, p + 'self_attn'), h, p_drop=drop)
+        tgt = _ln(tgt + dr(o), sd, p + 'norm1')
+        o, att = mha(tgt + query_pos, memory + pos, memory, *_mha_p(sd, p + 'multihead_attn'), h, key_padding_mask=pad_mask,
+                     p_drop=drop)
+        tgt = _ln(tgt + dr(o), sd, p + 'norm2')
+        return _ln(tgt + dr(_ffn(tgt, sd, p, activation, dr)), sd, p + 'norm3'), att
     t2 = _ln(tgt, sd, p + 'norm1')
     qk = t2 + query_pos
-    o, _ = mha(qk, qk, t2, *_mha_p(sd, p + 'self_attn'), h)
-    tgt = tgt + o
+    o, _ = mha(qk, qk, t2, *_mha_p(sd, p + 'self_attn'), h, p_drop=drop)
+    tgt = tgt + dr(o)
     t2 = _ln(tgt, sd, p + 'norm2')
-    o, att = mha(t2 + query_pos, memory + pos, memory, *_mha_p(sd, p + 'multihead_attn'), h, key_padding_mask=pad_mask)
-    tgt = tgt + o
-    return tgt + _ffn(_ln(tgt, sd, p + 'norm3'), sd, p, activation), att
+    o, att = mha(t2 + query_pos, memory + pos, memory, *_mha_p(sd, p + 'multihead_attn'), h, key_padding_mask=pad_mask, p_drop=drop)
+    tgt = tgt + dr(o)
+    return tgt + dr(_ffn(_ln(tgt, sd, p + 'norm3'), sd, p, activation, dr)), att
 
 
-def transformer_forward(sd, prefix, args, src, pad_mask, query_embed, pos_embed, activation='relu'):
+def transformer_forward(sd, prefix, args, src, pad_mask, query_embed, pos_embed, activation='relu', drop=None):
     """Transformer.forward, transformer.py:43-81, with return_intermediate_dec=True (build_transformer :321).
     src [B,L,d]; pad_mask [B,L] bool True on pads; query_embed [N,d] or [N,B,d]; pos_embed [B,L,d].
     Returns (hs [n_dec,B,N,d], memory [B,L,d], att [n_dec,B,N,L])."""
@@ -76,14 +104,14 @@ def transformer_forward(sd, prefix, args, src, pad_mask, query_embed, pos_embed,
         query_pos = query_embed.unsqueeze(0).expand(B, -1, -1)
     memory = src
     for i in range(args.enc_layers):
-        memory = encoder_layer(sd, f'{prefix}encoder.layers.{i}.', h, memory, pad_mask, pos_embed, pre, activation)
+        memory = encoder_layer(sd, f'{prefix}encoder.layers.{i}.', h, memory, pad_mask, pos_embed, pre, activation, drop)
     if pre:  # encoder_norm only exists with normalize_before (:26)
         memory = _ln(memory, sd, prefix + 'encoder.norm')
     tgt = torch.zeros_like(query_pos)
     hs, atts = [], []
     for i in range(args.dec_layers):
         tgt, att = decoder_layer(sd, f'{prefix}decoder.layers.{i}.', h, tgt, memory, pad_mask, pos_embed, query_pos, pre,
-                                 activation)
+                                 activation, drop)
         hs.append(_ln(tgt, sd, prefix + 'decoder.norm'))  # the shared decoder norm on every layer's output (:139-147)
         atts.append(att)
     return torch.stack(hs), memory, torch.stack(atts)
@@ -112,7 +140,7 @@ def _sketch_queries(sd, args, src_sketch, bs):
     return input_proj(query, sd, 'input_query_proj', args.n_input_proj)
 
 
-def svanet_variant_forward(sd, args, src_sketch, src_sketch_mask, src_video, src_video_mask, return_hs=False):
+def svanet_variant_forward(sd, args, src_sketch, src_sketch_mask, src_video, src_video_mask, return_hs=False, drop=None):
     """SVANet.forward of svanet_variants.py (:74-84 dispatch; :86-134, :136-188, :190-247)."""
     d = args.hidden_dim
     dtype = src_video.dtype
@@ -136,7 +164,7 @@ def svanet_variant_forward(sd, args, src_sketch, src_sketch_mask, src_video, src
         query = _sketch_queries(sd, args, src_sketch, src_video.shape[0])
     else:
         raise NotImplementedError
-    hs, memory, att = transformer_forward(sd, 'transformer.', args, src, ~mask, query, pos)
+    hs, memory, att = transformer_forward(sd, 'transformer.', args, src, ~mask, query, pos, drop=drop)
     res = _heads(sd, args, hs)
     if return_hs:
         return res, hs, memory, att

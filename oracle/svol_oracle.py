@@ -83,7 +83,7 @@ def position_embedding_sine(mask_bool, d: int, dtype=torch.float32, temperature:
 
 
 def mha(q_in, k_in, v_in, in_w, in_b, out_w, out_b, h: int, key_padding_mask=None,
-        need_output: bool = True):
+        need_output: bool = True, p_drop=None):
     """torch.nn.MultiheadAttention forward (batch-first restatement), as used
     4x per layer (cross_modal_transformer.py:86-97): packed in_proj, q scaled
     by d_h**-0.5 after projection, softmax over keys, out_proj.  Returns
@@ -99,6 +99,8 @@ def mha(q_in, k_in, v_in, in_w, in_b, out_w, out_b, h: int, key_padding_mask=Non
     if key_padding_mask is not None:
         s = s.masked_fill(key_padding_mask[:, None, None, :], float('-inf'))
     p = torch.softmax(s, dim=-1)
+    if p_drop is not None:  # training mode: F.multi_head_attention_forward drops the softmax OUTPUT (and returns the dropped weights)
+        p = p_drop(p)
     w_mean = p.mean(1)
     if not need_output:
         return None, w_mean

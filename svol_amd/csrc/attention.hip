@@ -176,7 +176,17 @@ struct AttnArgs {
     int B, H, Lq, Lk, dh;
     float scale;
     float premul;
+    // attention-probability dropout (nn.MultiheadAttention(dropout=p) in training mode, transformer.py:158-160,216-222): the
+    // softmax numerators that feed P V are multiplied by a stateless keep mask (0 or 1/(1-p)) of the element index
+    // ((b*H + h)*Lq + q)*Lk + key — the row sums / lse stay those of the undropped softmax; backward regenerates the mask
+    float drop_p, drop_inv;
+    uint64_t drop_seed;
 };
+
+// keep-mask scale of score element (row, key); rowbase = ((b*H + h)*Lq + q) * Lk
+__device__ __forceinline__ float attn_drop(uint64_t seed, uint64_t rowbase, int key, float p, float inv) {
+    return dropout_scale(seed, rowbase + (uint64_t)key, p, inv);
+}
 
 template <typename T> struct Smem {
     static constexpr int NAT = 64 * AT<T>::NAT_ROW;
@@ -251,6 +261,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
             m = m_new;
 #pragma unroll
             for (int i = 0; i < 16; ++i) O[i] *= alpha;
+            if (p.drop_p > 0.f) {
+                const uint64_t rb = (((uint64_t)b * p.H + hh) * p.Lq + (qvalid ? qrow : 0)) * (uint64_t)p.Lk;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        S[4 * g + e] *= attn_drop(p.drop_seed, rb, kt + sub * 32 + 8 * g + 4 * h + e, p.drop_p, p.drop_inv);
+            }
             uint4 va[AT<T>::NA];
             read_tr<T>(va, sVt, r, h, sub);
             mma_second<T>(O, va, S);
@@ -342,7 +360,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float pe = __builtin_amdgcn_exp2f(S[4 * g + e] * sc + bb[e] - lse);
-                    S[4 * g + e] = pe * (dP[4 * g + e] - dl) * p.scale;
+                    float dpe = dP[4 * g + e];
+                    if (p.drop_p > 0.f)
+                        dpe *= attn_drop(p.drop_seed, (((uint64_t)b * p.H + hh) * p.Lq + (qvalid ? qrow : 0)) * (uint64_t)p.Lk,
+                                         kt + sub * 32 + 8 * g + 4 * h + e, p.drop_p, p.drop_inv);
+                    S[4 * g + e] = pe * (dpe - dl) * p.scale;
                 }
             }
             read_tr<T>(a, sKt, r, h, sub);
@@ -410,15 +432,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) S[4 * g + e] = __builtin_amdgcn_exp2f(S[4 * g + e] * sc + kbl - ls[e]);
             }
+            f32x16 MS;   // keep-mask scales of this block (all ones without dropout)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) MS[i] = 1.f;
+            if (p.drop_p > 0.f) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int qi = min(qt + sub * 32 + 8 * g + 4 * h + e, p.Lq - 1);
+                        MS[4 * g + e] = attn_drop(p.drop_seed, (((uint64_t)b * p.H + hh) * p.Lq + qi) * (uint64_t)p.Lk, kvalid ? krow : 0,
+                                                  p.drop_p, p.drop_inv);
+                    }
+            }
             read_tr<T>(a, sdOt, r, h, sub);
-            mma_second<T>(dV, a, S);  // dV^T += dO^T P
+            {
+                f32x16 Pd = S;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) Pd[i] *= MS[i];
+                mma_second<T>(dV, a, Pd);  // dV^T += dO^T (P . mask)
+            }
             read_nat<T>(a, sdO, sub * 32 + r, h);
             mma_first<T>(dP, a, vbk);  // dP[q][key] = dO V^T
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 dd = *reinterpret_cast<const f32x4*>(sdl + sub * 32 + 8 * g + 4 * h);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) S[4 * g + e] = S[4 * g + e] * (dP[4 * g + e] - dd[e]) * p.scale;
+                for (int e = 0; e < 4; ++e) S[4 * g + e] = S[4 * g + e] * (dP[4 * g + e] * MS[4 * g + e] - dd[e]) * p.scale;
             }
             read_tr<T>(a, sQt, r, h, sub);
             mma_second<T>(dK, a, S);  // dK^T += Q^T dS
@@ -444,23 +484,23 @@ bool ld_ok(int64_t ld, int dtype) { return ld % (svol_is16(dtype) ? 8 : 4) == 0;
 // bf16 fast path (attention_bf16.hip)
 int svol_attn_fwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                               int64_t ldo, float* lse2, const float* kbias, int B, int H, int Lq, int Lk, int dh, float scale,
-                              float premul, float* ws, int64_t ws_bytes, hipStream_t s);
+                              float premul, float* ws, int64_t ws_bytes, float drop_p, uint64_t drop_seed, hipStream_t s);
 int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                               const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta,
                               const float* kbias, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int B,
                               int H, int Lq, int Lk, int dh, float scale, float premul, float* ws, int64_t ws_bytes,
-                              hipStream_t s);
+                              float drop_p, uint64_t drop_seed, hipStream_t s);
 
 int64_t svol_attn_ws_floats_bf16(int B, int H, int Lq, int Lk, int dh);
 // the same kernels compiled with fp16 operands (attention_bf16.hip with -DSVOL_H16_FP16)
 int svol_attn_fwd_f16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                              int64_t ldo, float* lse2, const float* kbias, int B, int H, int Lq, int Lk, int dh, float scale,
-                             float premul, float* ws, int64_t ws_bytes, hipStream_t s);
+                             float premul, float* ws, int64_t ws_bytes, float drop_p, uint64_t drop_seed, hipStream_t s);
 int svol_attn_bwd_f16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                              const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta,
                              const float* kbias, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int B,
                              int H, int Lq, int Lk, int dh, float scale, float premul, float* ws, int64_t ws_bytes,
-                             hipStream_t s);
+                             float drop_p, uint64_t drop_seed, hipStream_t s);
 
 extern "C" {
 
@@ -469,10 +509,12 @@ int64_t svol_attn_ws_bytes(int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t
     return 4 * svol_attn_ws_floats_bf16((int)B, (int)H, (int)Lq, (int)Lk, (int)dh);
 }
 
-int svol_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
-                  int64_t ldo, float* lse2, const float* kbias, int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t dh,
-                  float scale, float q_premul, void* ws, int64_t ws_bytes, int dtype, void* stream) {
+static int attn_fwd_impl(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
+                         int64_t ldo, float* lse2, const float* kbias, int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t dh,
+                         float scale, float q_premul, void* ws, int64_t ws_bytes, float drop_p, uint64_t drop_seed, int dtype,
+                         void* stream) {
     if (!q || !k || !v || !o || !lse2) return SVOL_E_INVALID;
+    if (!(drop_p >= 0.f && drop_p < 1.f)) return SVOL_E_INVALID;
     int rc = check_common(B, H, Lq, Lk, dh, dtype);
     if (rc) return rc;
     if (!ld_ok(ldq, dtype) || !ld_ok(ldk, dtype) || !ld_ok(ldv, dtype) || !ld_ok(ldo, dtype)) return SVOL_E_UNSUPPORTED;
@@ -481,22 +523,39 @@ int svol_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const 
     p.q = q; p.k = k; p.v = v; p.out_o = o; p.lse2 = lse2; p.kbias = kbias;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.B = (int)B; p.H = (int)H; p.Lq = (int)Lq; p.Lk = (int)Lk; p.dh = (int)dh; p.scale = scale; p.premul = q_premul;
+    p.drop_p = drop_p; p.drop_inv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; p.drop_seed = drop_seed;
     dim3 grid((unsigned)((Lq + 127) / 128), (unsigned)H, (unsigned)B);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (svol_is16(dtype))
         return (dtype == SVOL_BF16 ? svol_attn_fwd_bf16_launch : svol_attn_fwd_f16_launch)(
             q, ldq, k, ldk, v, ldv, o, ldo, lse2, kbias, (int)B, (int)H, (int)Lq, (int)Lk, (int)dh, scale, q_premul,
-            aligned16(ws) ? (float*)ws : nullptr, ws_bytes, s);
+            aligned16(ws) ? (float*)ws : nullptr, ws_bytes, drop_p, drop_seed, s);
     hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), 0, s, p);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }
 
-int svol_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
-                  int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta, const float* kbias, void* dq,
-                  int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int64_t B, int64_t H, int64_t Lq, int64_t Lk,
-                  int64_t dh, float scale, float q_premul, void* ws, int64_t ws_bytes, int dtype, void* stream) {
+int svol_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
+                  int64_t ldo, float* lse2, const float* kbias, int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t dh,
+                  float scale, float q_premul, void* ws, int64_t ws_bytes, int dtype, void* stream) {
+    return attn_fwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, lse2, kbias, B, H, Lq, Lk, dh, scale, q_premul, ws, ws_bytes, 0.f, 0, dtype,
+                         stream);
+}
+int svol_attn_fwd_dropout(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
+                          int64_t ldo, float* lse2, const float* kbias, int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t dh,
+                          float scale, float q_premul, void* ws, int64_t ws_bytes, float dropout_p, uint64_t seed, int dtype,
+                          void* stream) {
+    return attn_fwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, lse2, kbias, B, H, Lq, Lk, dh, scale, q_premul, ws, ws_bytes, dropout_p, seed,
+                         dtype, stream);
+}
+
+static int attn_bwd_impl(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
+                         int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta, const float* kbias, void* dq,
+                         int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int64_t B, int64_t H, int64_t Lq, int64_t Lk,
+                         int64_t dh, float scale, float q_premul, void* ws, int64_t ws_bytes, float drop_p, uint64_t drop_seed,
+                         int dtype, void* stream) {
     if (!q || !k || !v || !o || !d_o || !lse2 || !delta || !dq || !dk || !dv) return SVOL_E_INVALID;
+    if (!(drop_p >= 0.f && drop_p < 1.f)) return SVOL_E_INVALID;
     int rc = check_common(B, H, Lq, Lk, dh, dtype);
     if (rc) return rc;
     if (!ld_ok(ldq, dtype) || !ld_ok(ldk, dtype) || !ld_ok(ldv, dtype) || !ld_ok(ldo, dtype) || !ld_ok(lddo, dtype) ||
@@ -510,6 +569,7 @@ int svol_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const 
     p.dq = dq; p.dk = dk; p.dv = dv;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
     p.B = (int)B; p.H = (int)H; p.Lq = (int)Lq; p.Lk = (int)Lk; p.dh = (int)dh; p.scale = scale; p.premul = q_premul;
+    p.drop_p = drop_p; p.drop_inv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; p.drop_seed = drop_seed;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t total = B * Lq * H;
     dim3 gd((unsigned)((total + 255) / 256));
@@ -518,12 +578,28 @@ int svol_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const 
     if (svol_is16(dtype))
         return (dtype == SVOL_BF16 ? svol_attn_bwd_bf16_launch : svol_attn_bwd_f16_launch)(
             q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse2, delta, kbias, dq, lddq, dk, lddk, dv, lddv, (int)B, (int)H, (int)Lq,
-            (int)Lk, (int)dh, scale, q_premul, aligned16(ws) ? (float*)ws : nullptr, ws_bytes, s);
+            (int)Lk, (int)dh, scale, q_premul, aligned16(ws) ? (float*)ws : nullptr, ws_bytes, drop_p, drop_seed, s);
     hipLaunchKernelGGL(attn_delta_kernel<float>, gd, dim3(256), 0, s, p);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, gq, dim3(256), 0, s, p);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<float>, gk, dim3(256), 0, s, p);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
+}
+
+int svol_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
+                  int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta, const float* kbias, void* dq,
+                  int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int64_t B, int64_t H, int64_t Lq, int64_t Lk,
+                  int64_t dh, float scale, float q_premul, void* ws, int64_t ws_bytes, int dtype, void* stream) {
+    return attn_bwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse2, delta, kbias, dq, lddq, dk, lddk, dv, lddv, B, H, Lq, Lk, dh,
+                         scale, q_premul, ws, ws_bytes, 0.f, 0, dtype, stream);
+}
+int svol_attn_bwd_dropout(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
+                          int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta, const float* kbias, void* dq,
+                          int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int64_t B, int64_t H, int64_t Lq, int64_t Lk,
+                          int64_t dh, float scale, float q_premul, void* ws, int64_t ws_bytes, float dropout_p, uint64_t seed,
+                          int dtype, void* stream) {
+    return attn_bwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse2, delta, kbias, dq, lddq, dk, lddk, dv, lddv, B, H, Lq, Lk, dh,
+                         scale, q_premul, ws, ws_bytes, dropout_p, seed, dtype, stream);
 }
 
 }  // extern "C"

@@ -45,7 +45,13 @@ struct Args {
     int tail_last;                // != 0 (with head_xcd): every head's LAST x tile is dispatched after all the others
     int* redo;                    // [grid] written by attn_fwd_bf16_fast (1 = a row sum overflowed), read by the safe kernel behind it
     unsigned *nl2, *nd2;          // [B,H,Lq] -lse2 / -delta as (hi, lo) bf16 pairs: written by the fast dQ kernel, DMA'd by the dK/dV kernel
+    // attention-probability dropout (general kernels only; see attention.hip AttnArgs): keep mask of ((b*H + h)*Lq + q)*Lk + key
+    float drop_p, drop_inv;
+    uint64_t drop_seed;
 };
+__device__ __forceinline__ float attn_drop(uint64_t seed, uint64_t rowbase, int key, float p, float inv) {
+    return dropout_scale(seed, rowbase + (uint64_t)key, p, inv);
+}
 
 typedef __attribute__((address_space(3))) h16x4* lds_bf16x4_ptr;
 
@@ -293,6 +299,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(Args p) {
                 ls[sub] += S[sub][i];
             }
         l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
+        if (p.drop_p > 0.f) {   // row sums stay those of the undropped softmax; only what feeds P V is masked
+            const uint64_t rb = (((uint64_t)b * p.H + hh) * p.Lq + (qvalid ? qrow : 0)) * (uint64_t)p.Lk;
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        S[sub][4 * g + e] *= attn_drop(p.drop_seed, rb, t * KT + sub * 32 + 8 * g + 4 * h + e, p.drop_p, p.drop_inv);
+        }
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
             uint4 va[2];
@@ -467,7 +483,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(Args p) {
             read_rows(a, kimg, sub * 32 + r, h);
             f32x16 S = mma_first(a, qb);
             read_rows(a, vimg, sub * 32 + r, h);
-            const f32x16 dP = mma_first(a, dob);
+            f32x16 dP = mma_first(a, dob);
+            if (p.drop_p > 0.f) {
+                const uint64_t rb = (((uint64_t)b * p.H + hh) * p.Lq + (qvalid ? qrow : 0)) * (uint64_t)p.Lk;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        dP[4 * g + e] *= attn_drop(p.drop_seed, rb, t * KT + sub * 32 + 8 * g + 4 * h + e, p.drop_p, p.drop_inv);
+            }
             if (MASKED) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -587,9 +611,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(Args p) {
                     S[4 * g + e] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[4 * g + e], c, KBIAS ? kbl + ls[e] : ls[e]));
             }
             read_tr(a, doimg, sub, lane);
-            mma_second(dV, a, S);  // dV^T += dO^T P
+            f32x16 MS;   // keep-mask scales of this block
+#pragma unroll
+            for (int i = 0; i < 16; ++i) MS[i] = 1.f;
+            if (p.drop_p > 0.f) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int qi = min(t * KT + sub * 32 + 8 * g + 4 * h + e, p.Lq - 1);
+                        MS[4 * g + e] = attn_drop(p.drop_seed, (((uint64_t)b * p.H + hh) * p.Lq + qi) * (uint64_t)p.Lk, kvalid ? krow : 0,
+                                                  p.drop_p, p.drop_inv);
+                    }
+                f32x16 Pd = S;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) Pd[i] *= MS[i];
+                mma_second(dV, a, Pd);  // dV^T += dO^T (P . mask)
+            } else {
+                mma_second(dV, a, S);  // dV^T += dO^T P
+            }
             read_rows(a, doimg, sub * 32 + r, h);
-            const f32x16 dP = mma_first(a, vbk);  // dP[q][key] = dO V^T
+            f32x16 dP = mma_first(a, vbk);  // dP[q][key] = dO V^T
+            if (p.drop_p > 0.f) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dP[i] *= MS[i];
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 dl = *reinterpret_cast<const f32x4*>(dd + sub * 32 + 8 * g + 4 * h);
@@ -1342,8 +1388,9 @@ static void bind_ws(Args& p, float* ws) {
 
 int svol_attn_fwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                               int64_t ldo, float* lse2, const float* kbias, int B, int H, int Lq, int Lk, int dh, float scale,
-                              float premul, float* ws, int64_t ws_bytes, hipStream_t s) {
+                              float premul, float* ws, int64_t ws_bytes, float drop_p, uint64_t drop_seed, hipStream_t s) {
     Args p{};
+    p.drop_p = drop_p; p.drop_inv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; p.drop_seed = drop_seed;
     p.q = q; p.k = k; p.v = v; p.out_o = o; p.lse2 = lse2; p.kbias = kbias;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.dh = dh; p.scale = scale; p.premul = premul;
@@ -1351,8 +1398,8 @@ int svol_attn_fwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
     // pre-multiplied q: the fast kernels; masked launches with few queries keep the key-split path below
     static const bool no_pre_masked = getenv("SVOL_ATTN_NO_PRE_MASKED") != nullptr;
     const int ntk = (Lk + KT - 1) / KT;
-    const bool pre = premul != 0.f && (!masked || (!no_pre_masked && pre_masked_ok(B, H, Lq, Lk, dh) && ws &&
-                                                   ws_bytes >= (int64_t)B * ntk * 4));
+    const bool pre = premul != 0.f && drop_p == 0.f &&   // (attention dropout lives in the general kernels only)
+                     (!masked || (!no_pre_masked && pre_masked_ok(B, H, Lq, Lk, dh) && ws && ws_bytes >= (int64_t)B * ntk * 4));
     p.ksplit = (ws && !pre) ? plan_ksplit(B, H, Lq, Lk, dh, ws_bytes / 4, &p.tiles_per_split) : 1;
     if (p.ksplit == 1) p.tiles_per_split = ntk;
     else bind_ws(p, ws);
@@ -1388,8 +1435,9 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
                               const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta,
                               const float* kbias, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int B,
                               int H, int Lq, int Lk, int dh, float scale, float premul, float* ws, int64_t ws_bytes,
-                              hipStream_t s) {
+                              float drop_p, uint64_t drop_seed, hipStream_t s) {
     Args p{};
+    p.drop_p = drop_p; p.drop_inv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; p.drop_seed = drop_seed;
     p.q = q; p.k = k; p.v = v; p.o = o; p.d_o = d_o; p.lse2 = const_cast<float*>(lse2); p.delta = delta; p.kbias = kbias;
     p.dq = dq; p.dk = dk; p.dv = dv;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
@@ -1398,8 +1446,8 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
     const bool masked = kbias != nullptr || (Lk % KT) != 0;
     static const bool no_pre_masked = getenv("SVOL_ATTN_NO_PRE_MASKED") != nullptr;
     const int ntk = (Lk + KT - 1) / KT;
-    const bool pre = premul != 0.f && (!masked || (!no_pre_masked && pre_masked_ok(B, H, Lq, Lk, dh) && ws &&
-                                                   ws_bytes >= (int64_t)B * ntk * 4));
+    const bool pre = premul != 0.f && drop_p == 0.f &&
+                     (!masked || (!no_pre_masked && pre_masked_ok(B, H, Lq, Lk, dh) && ws && ws_bytes >= (int64_t)B * ntk * 4));
     p.ksplit = (ws && !pre) ? plan_ksplit(B, H, Lq, Lk, dh, ws_bytes / 4, &p.tiles_per_split) : 1;
     if (p.ksplit == 1) p.tiles_per_split = ntk;
     else bind_ws(p, ws);

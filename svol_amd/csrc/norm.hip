@@ -235,6 +235,22 @@ __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ m
     }
 }
 
+
+// ---- stand-alone dropout (the enc/dec Transformer's residual / FFN dropouts, transformer.py:165-215,225-295) -------------------------
+// Stateless keep mask of the element index (dropout_scale, common.h): forward and backward regenerate the same mask from (seed, i).
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p, float inv_keep,
+                                                      uint64_t seed) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) y[i] = from_f32<T>(to_f32(x[i]) * dropout_scale(seed, (uint64_t)i, p, inv_keep));
+}
+__global__ __launch_bounds__(256) void dropout_add_kernel(const float* __restrict__ t, const float* __restrict__ res, float* __restrict__ out,
+                                                          int64_t n, float p, float inv_keep, uint64_t seed) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = res[i] + t[i] * dropout_scale(seed, (uint64_t)i, p, inv_keep);
+}
 }  // namespace
 
 extern "C" {
@@ -309,6 +325,32 @@ int svol_layernorm_bwd(const float* dy32, const void* dy, const void* dy2, const
     else SVOL_LNB_NP(float, float);
 #undef SVOL_LNB_NP
 #undef SVOL_LNB
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream) {
+    if (!x || !y || n < 0 || !(p >= 0.f && p < 1.f)) return SVOL_E_INVALID;
+    if (n == 0) return SVOL_OK;
+    const float inv = 1.f / (1.f - p);
+    int64_t g = (n + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == SVOL_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3((unsigned)g), dim3(256), 0, s, (const float*)x, (float*)y, n, p, inv, seed);
+    else if (dtype == SVOL_BF16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, n, p, inv, seed);
+    else if (dtype == SVOL_F16) hipLaunchKernelGGL(dropout_kernel<f16_t>, dim3((unsigned)g), dim3(256), 0, s, (const f16_t*)x, (f16_t*)y, n, p, inv, seed);
+    else return SVOL_E_INVALID;
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_dropout_add(const float* t32, const float* res32, float* out32, int64_t n, float p, uint64_t seed, void* stream) {
+    if (!t32 || !res32 || !out32 || n < 0 || !(p >= 0.f && p < 1.f)) return SVOL_E_INVALID;
+    if (n == 0) return SVOL_OK;
+    int64_t g = (n + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(dropout_add_kernel, dim3((unsigned)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), t32, res32, out32, n, p,
+                       1.f / (1.f - p), seed);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }

@@ -18,8 +18,11 @@ same fused blocks as the cross-modal transformer:
 The residual stream is fp32 throughout (as in the cross-modal transformer); GEMM / attention operands are in the
 compute dtype.  Differences from the reference, all documented in DESIGN.md:
 
-* dropout: the kernels have no attention-probability / residual / FFN dropout.  ``dropout > 0`` is accepted (the
-  reference default is 0.1) but a TRAINING-mode forward then raises; ``eval()`` or ``dropout=0`` run.
+* dropout (training mode, reference default 0.1): attention-probability dropout inside the attention kernels
+  (``svol_attn_fwd_dropout``), the residual dropouts (``svol_dropout_add``) and the FFN hidden dropout (``svol_dropout``), all
+  stateless masks of (seed, element index) that backward regenerates; the masks of a step are a function of
+  ``(drop_base_seed, step, layer, site)``.  The returned attention WEIGHTS are those of the undropped softmax (torch
+  returns the dropped ones; no consumer in the reference reads them).
 * activation: ``relu`` (the only one ``build_transformer`` can select, :312-322) and ``gelu``; ``glu`` raises.
 * ``att_weights`` carry no gradient (every consumer in the reference discards them: sketch_detr.py:62,
   svanet_variants.py:107-116); ``need_weights=False`` skips computing them.
@@ -55,11 +58,17 @@ _n = lambda m: (m.weight, m.bias)
 _mha = lambda m: (m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias)
 
 
-def _check_dropout(mod):
-    if mod.training and mod.dropout_p > 0.0:
-        raise NotImplementedError(
-            f'{type(mod).__name__}: dropout={mod.dropout_p} in training mode — the HIP attention / FFN blocks have no '
-            'dropout; build with dropout=0.0 (--dropout 0) or call .eval()')
+def _drop(mod, seed, site_a, site_b):
+    """(p, seed_a, seed_b) of one block of layer `mod` in training mode, else None.  seed: the step's base seed (Transformer.forward),
+    None outside a Transformer (then a per-layer counter stands in).  Sites 0..5 of a layer: self-attention probabilities / its
+    residual dropout1, cross-attention probabilities / dropout2, FFN hidden dropout / the FFN's residual dropout."""
+    if not (mod.training and mod.dropout_p > 0.0):
+        return None
+    if seed is None:
+        mod._own_step = getattr(mod, '_own_step', 0) + 1
+        seed = (0x5EED << 40) + (mod._own_step << 20)
+    base = seed + (getattr(mod, 'layer_id', 0) << 4)
+    return (mod.dropout_p, base + site_a, base + site_b)
 
 
 class TransformerEncoderLayer(nn.Module):
@@ -74,28 +83,30 @@ class TransformerEncoderLayer(nn.Module):
         self.normalize_before = normalize_before
         self.nhead, self.dropout_p = nhead, float(dropout)
 
-    def _ffn(self, x32, x, norm, pos_out):
+    def _ffn(self, x32, x, norm, pos_out, seed=None):
         g, b = _n(norm) if norm is not None else (None, None)
         return ops.mlp_ln(x32, x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, g, b,
-                          pos_out, self.act)
+                          pos_out, self.act, _drop(self, seed, 4, 5))
 
-    def forward_post(self, state, pos, kbias):
+    def forward_post(self, state, pos, kbias, seed=None):
         """state = (x32, x, x + pos) -> same triple (transformer.py:175-194)."""
         x32, x, xpos = state
-        y32, y = ops.self_attn_ln(x32, x, xpos, *_mha(self.self_attn), *_n(self.norm1), None, self.nhead, kbias)
-        return self._ffn(y32, y, self.norm2, pos)
+        y32, y = ops.self_attn_ln(x32, x, xpos, *_mha(self.self_attn), *_n(self.norm1), None, self.nhead, kbias,
+                                  _drop(self, seed, 0, 1))
+        return self._ffn(y32, y, self.norm2, pos, seed)
 
-    def forward_pre(self, x32, pos, kbias):
+    def forward_pre(self, x32, pos, kbias, seed=None):
         """x32 -> x32 (transformer.py:196-208)."""
         dt = pos.dtype
         y, ypos = ops.ln_stream(x32, *_n(self.norm1), pos, dt)
-        s32 = ops.self_attn_ln(x32, y, ypos, *_mha(self.self_attn), None, None, None, self.nhead, kbias)
+        s32 = ops.self_attn_ln(x32, y, ypos, *_mha(self.self_attn), None, None, None, self.nhead, kbias, _drop(self, seed, 0, 1))
         y2 = ops.ln_stream(s32, *_n(self.norm2), None, dt)
-        return self._ffn(s32, y2, None, None)
+        return self._ffn(s32, y2, None, None, seed)
 
-    def forward(self, state, pos, kbias):
-        _check_dropout(self)
-        return self.forward_pre(state, pos, kbias) if self.normalize_before else self.forward_post(state, pos, kbias)
+    def forward(self, state, pos, kbias, seed=None):
+        if self.normalize_before:
+            return self.forward_pre(state, pos, kbias, seed)
+        return self.forward_post(state, pos, kbias, seed)
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -112,38 +123,38 @@ class TransformerDecoderLayer(nn.Module):
         self.normalize_before = normalize_before
         self.nhead, self.dropout_p = nhead, float(dropout)
 
-    def _ffn(self, x32, x, norm, pos_out):
+    def _ffn(self, x32, x, norm, pos_out, seed=None):
         g, b = _n(norm) if norm is not None else (None, None)
         return ops.mlp_ln(x32, x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, g, b,
-                          pos_out, self.act)
+                          pos_out, self.act, _drop(self, seed, 4, 5))
 
-    def forward_post(self, state, mem, mempos, qpos, kbias, need_weights):
+    def forward_post(self, state, mem, mempos, qpos, kbias, need_weights, seed=None):
         """state = (t32, t, t + query_pos) -> (same triple, att | None)   (transformer.py:229-250)."""
         t32, t, tpos = state
-        a32, a, apos = ops.self_attn_ln(t32, t, tpos, *_mha(self.self_attn), *_n(self.norm1), qpos, self.nhead)
+        a32, a, apos = ops.self_attn_ln(t32, t, tpos, *_mha(self.self_attn), *_n(self.norm1), qpos, self.nhead, None,
+                                        _drop(self, seed, 0, 1))
         r = ops.cross_attn_ln(a32, a, apos, mempos, mem, *_mha(self.multihead_attn), *_n(self.norm2), None, self.nhead,
-                              kbias, need_weights)
+                              kbias, need_weights, _drop(self, seed, 2, 3))
         c32, c = r[0], r[1]
         att = r[2] if need_weights else None
-        return self._ffn(c32, c, self.norm3, qpos), att
+        return self._ffn(c32, c, self.norm3, qpos, seed), att
 
-    def forward_pre(self, t32, mem, mempos, qpos, kbias, need_weights):
+    def forward_pre(self, t32, mem, mempos, qpos, kbias, need_weights, seed=None):
         """t32 -> (t32, att | None)   (transformer.py:252-283)."""
         dt = mem.dtype
         y, ypos = ops.ln_stream(t32, *_n(self.norm1), qpos, dt)
-        s32 = ops.self_attn_ln(t32, y, ypos, *_mha(self.self_attn), None, None, None, self.nhead)
+        s32 = ops.self_attn_ln(t32, y, ypos, *_mha(self.self_attn), None, None, None, self.nhead, None, _drop(self, seed, 0, 1))
         y2, y2pos = ops.ln_stream(s32, *_n(self.norm2), qpos, dt)
         r = ops.cross_attn_ln(s32, y2, y2pos, mempos, mem, *_mha(self.multihead_attn), None, None, None, self.nhead,
-                              kbias, need_weights)
+                              kbias, need_weights, _drop(self, seed, 2, 3))
         c32, att = (r[0], r[1]) if need_weights else (r, None)
         y3 = ops.ln_stream(c32, *_n(self.norm3), None, dt)
-        return self._ffn(c32, y3, None, None), att
+        return self._ffn(c32, y3, None, None, seed), att
 
-    def forward(self, state, mem, mempos, qpos, kbias, need_weights=False):
-        _check_dropout(self)
+    def forward(self, state, mem, mempos, qpos, kbias, need_weights=False, seed=None):
         if self.normalize_before:
-            return self.forward_pre(state, mem, mempos, qpos, kbias, need_weights)
-        return self.forward_post(state, mem, mempos, qpos, kbias, need_weights)
+            return self.forward_pre(state, mem, mempos, qpos, kbias, need_weights, seed)
+        return self.forward_post(state, mem, mempos, qpos, kbias, need_weights, seed)
 
 
 def _get_clones(module, N):
@@ -154,12 +165,14 @@ class TransformerEncoder(nn.Module):
     def __init__(self, encoder_layer, num_layers, norm=None, return_intermediate=False):
         super().__init__()
         self.layers = _get_clones(encoder_layer, num_layers)
+        for i, l_ in enumerate(self.layers):
+            l_.layer_id = i            # (dropout seeds: every layer draws its own masks)
         self.num_layers = num_layers
         self.norm = norm
         if return_intermediate:  # never requested by the reference's builder (transformer.py:27-29)
             raise NotImplementedError('encoder return_intermediate')
 
-    def forward(self, src32, pos, kbias):
+    def forward(self, src32, pos, kbias, seed=None):
         """src32 [B,L,d] fp32, pos [B,L,d] compute dtype, kbias [B,L] fp32 additive key mask or None ->
         (memory32 [B,L,d] fp32, memory, memory + pos) — what the decoder's cross-attention reads."""
         dt = pos.dtype
@@ -167,7 +180,7 @@ class TransformerEncoder(nn.Module):
         if pre:
             x32 = src32
             for layer in self.layers:
-                x32 = layer(x32, pos, kbias)
+                x32 = layer(x32, pos, kbias, seed)
             if self.norm is not None:  # the builder gives the pre-norm encoder a closing norm (:26)
                 return ops.ln_stream(x32, *_n(self.norm), pos, dt, True)
             x = ops.cast_ag(x32, dt)
@@ -175,7 +188,7 @@ class TransformerEncoder(nn.Module):
         x = ops.cast_ag(src32, dt)
         state = (src32, x, x + pos)  # layer 0's q = k = src + pos (:183); later layers get it from the norm2 epilogue
         for layer in self.layers:
-            state = layer(state, pos, kbias)
+            state = layer(state, pos, kbias, seed)
         if self.norm is not None:
             return ops.ln_stream(state[0], *_n(self.norm), pos, dt, True)
         return state
@@ -185,11 +198,13 @@ class TransformerDecoder(nn.Module):
     def __init__(self, decoder_layer, num_layers, norm=None, return_intermediate=False):
         super().__init__()
         self.layers = _get_clones(decoder_layer, num_layers)
+        for i, l_ in enumerate(self.layers):
+            l_.layer_id = 64 + i
         self.num_layers = num_layers
         self.norm = norm
         self.return_intermediate = return_intermediate
 
-    def forward(self, mem, mempos, qpos, kbias, need_weights=True):
+    def forward(self, mem, mempos, qpos, kbias, need_weights=True, seed=None):
         """mem / mempos [B,L,d] compute dtype, qpos [N,d] or [B,N,d] compute dtype ->
         (hs [n,B,N,d] fp32, att [n,B,N,L] fp32 | None); n = num_layers with return_intermediate, else 1 (:116-152)."""
         B = mem.shape[0]
@@ -201,7 +216,7 @@ class TransformerDecoder(nn.Module):
         state = t32 if pre else (t32, torch.zeros((B, N, d), dtype=dt, device=mem.device), qfull)
         inter, atts = [], []
         for layer in self.layers:
-            state, att = layer(state, mem, mempos, qpos, kbias, need_weights and self.return_intermediate)
+            state, att = layer(state, mem, mempos, qpos, kbias, need_weights and self.return_intermediate, seed)
             if self.return_intermediate:
                 o32 = state if pre else state[0]
                 inter.append(ops.ln_stream(o32, *_n(self.norm), None, torch.float32) if self.norm is not None else o32)
@@ -230,6 +245,8 @@ class Transformer(nn.Module):
         self.d_model = d_model
         self.nhead = nhead
         self.compute_dtype = _DTYPES[compute_dtype]
+        self.drop_base_seed = 1     # dropout masks are a function of (drop_base_seed, training step, layer, site, element)
+        self._drop_step = 0
 
     def _reset_parameters(self):
         for p in self.parameters():
@@ -254,8 +271,12 @@ class Transformer(nn.Module):
         else:
             qpos = query_embed
         qpos = ops.cast_ag(qpos.float().contiguous(), dt)
-        mem32, mem, mempos = self.encoder(src32.contiguous(), pos.contiguous(), kbias)
-        hs, att = self.decoder(mem, mempos, qpos, kbias, need_weights)
+        seed = None
+        if self.training:
+            self._drop_step += 1
+            seed = (int(self.drop_base_seed) << 44) + (self._drop_step << 12)
+        mem32, mem, mempos = self.encoder(src32.contiguous(), pos.contiguous(), kbias, seed)
+        hs, att = self.decoder(mem, mempos, qpos, kbias, need_weights, seed)
         return hs, mem32, att
 
 

@@ -384,23 +384,46 @@ def _attn_ws(q, B, H, Lq, Lk, dh, masked):
     return torch.empty((n // 4,), dtype=torch.float32, device=q.device)
 
 
-def attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias=None, premul=0.0):
-    """q/k/v: 2-D [B*L, >=H*dh] views (column slices allowed). Returns o [B*Lq, H*dh], lse2 [B,H,Lq]."""
+def dropout(x, p, seed, out=None):
+    """x * keep(seed, element index) (0 or 1/(1-p)); out may be x (in place).  x contiguous."""
+    assert x.is_contiguous()
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.lib().svol_dropout(_ptr(x), _ptr(out), x.numel(), float(p), int(seed), _dt(x), _stream()), 'svol_dropout')
+    return out
+
+
+def dropout_add(t32, res32, p, seed):
+    """res32 + dropout(t32), fp32, written over t32."""
+    assert t32.is_contiguous() and res32.is_contiguous() and t32.dtype == torch.float32 and res32.dtype == torch.float32
+    _lib.check(_lib.lib().svol_dropout_add(_ptr(t32), _ptr(res32), _ptr(t32), t32.numel(), float(p), int(seed), _stream()),
+               'svol_dropout_add')
+    return t32
+
+
+def attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias=None, premul=0.0, drop=None):
+    """q/k/v: 2-D [B*L, >=H*dh] views (column slices allowed). Returns o [B*Lq, H*dh], lse2 [B,H,Lq].
+    drop = (p, seed): attention-probability dropout (svol_attn_fwd_dropout)."""
     o = torch.empty((B * Lq, H * dh), dtype=q.dtype, device=q.device)
     lse2 = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
     ws = _attn_ws(q, B, H, Lq, Lk, dh, kbias is not None or Lk % 128 != 0)
     if B * H * Lq * Lk >= _WGRAD_FLUSH_MIN_SCORES:
         _BIG_ATTN['left'] += 1
     tok = timer.start('attn_fwd', (B, H, Lq, Lk, dh))
-    rc = _lib.lib().svol_attn_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o),
-                                  o.stride(0), _ptr(lse2), _ptr(kbias), B, H, Lq, Lk, dh, 1.0 / math.sqrt(dh),
-                                  float(premul), _ptr(ws), ws.numel() * 4 if ws is not None else 0, _dt(q), _stream())
+    if drop is not None and drop[0] > 0.0:
+        rc = _lib.lib().svol_attn_fwd_dropout(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o),
+                                              o.stride(0), _ptr(lse2), _ptr(kbias), B, H, Lq, Lk, dh, 1.0 / math.sqrt(dh),
+                                              float(premul), _ptr(ws), ws.numel() * 4 if ws is not None else 0, float(drop[0]),
+                                              int(drop[1]), _dt(q), _stream())
+    else:
+        rc = _lib.lib().svol_attn_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o),
+                                      o.stride(0), _ptr(lse2), _ptr(kbias), B, H, Lq, Lk, dh, 1.0 / math.sqrt(dh),
+                                      float(premul), _ptr(ws), ws.numel() * 4 if ws is not None else 0, _dt(q), _stream())
     timer.stop(tok)
     _lib.check(rc, 'svol_attn_fwd')
     return o, lse2
 
 
-def attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias=None, premul=0.0):
+def attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias=None, premul=0.0, drop=None):
     """Writes dq/dk/dv (2-D views, column slices allowed)."""
     do = do if do.stride(1) == 1 else do.contiguous()
     if B * H * Lq * Lk >= _WGRAD_FLUSH_MIN_SCORES:
@@ -409,11 +432,19 @@ def attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias=None, pre
     delta = torch.empty((3, B, H, Lq), dtype=torch.float32, device=q.device)  # delta | -lse2 pairs | -delta pairs (svol_hip.h)
     ws = _attn_ws(q, B, H, Lq, Lk, dh, kbias is not None or Lk % 128 != 0)
     tok = timer.start('attn_bwd', (B, H, Lq, Lk, dh))
-    rc = _lib.lib().svol_attn_bwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o),
-                                  o.stride(0), _ptr(do), do.stride(0), _ptr(lse2), _ptr(delta), _ptr(kbias),
-                                  _ptr(dq), dq.stride(0), _ptr(dk), dk.stride(0), _ptr(dv), dv.stride(0), B, H, Lq,
-                                  Lk, dh, 1.0 / math.sqrt(dh), float(premul), _ptr(ws),
-                                  ws.numel() * 4 if ws is not None else 0, _dt(q), _stream())
+    if drop is not None and drop[0] > 0.0:
+        rc = _lib.lib().svol_attn_bwd_dropout(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o),
+                                              o.stride(0), _ptr(do), do.stride(0), _ptr(lse2), _ptr(delta), _ptr(kbias),
+                                              _ptr(dq), dq.stride(0), _ptr(dk), dk.stride(0), _ptr(dv), dv.stride(0), B, H, Lq,
+                                              Lk, dh, 1.0 / math.sqrt(dh), float(premul), _ptr(ws),
+                                              ws.numel() * 4 if ws is not None else 0, float(drop[0]), int(drop[1]), _dt(q),
+                                              _stream())
+    else:
+        rc = _lib.lib().svol_attn_bwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o),
+                                      o.stride(0), _ptr(do), do.stride(0), _ptr(lse2), _ptr(delta), _ptr(kbias),
+                                      _ptr(dq), dq.stride(0), _ptr(dk), dk.stride(0), _ptr(dv), dv.stride(0), B, H, Lq,
+                                      Lk, dh, 1.0 / math.sqrt(dh), float(premul), _ptr(ws),
+                                      ws.numel() * 4 if ws is not None else 0, _dt(q), _stream())
     timer.stop(tok)
     _lib.check(rc, 'svol_attn_bwd')
 
@@ -801,8 +832,13 @@ class MLPLNFn(torch.autograd.Function):
     (pre-norm layers, transformer.py:205-207: x is then LN(x32), not a copy of x32)."""
 
     @staticmethod
-    def forward(ctx, x32, x, W1, b1, W2, b2, gamma, beta, pos_out, act=ACT_GELU):
+    def forward(ctx, x32, x, W1, b1, W2, b2, gamma, beta, pos_out, act=ACT_GELU, drop=None):
+        """drop = (p, seed_hidden, seed_residual): training-mode dropout of the enc/dec FFN — linear2(dropout(act(linear1 x))) and
+        x + dropout2(.) (transformer.py:168,171,238-240)."""
         ctx.set_materialize_grads(False)
+        if drop is not None and drop[0] <= 0.0:
+            drop = None
+        ctx.drop = drop
         shp = x.shape
         D = shp[-1]
         dt = x.dtype
@@ -815,7 +851,12 @@ class MLPLNFn(torch.autograd.Function):
             hid = aux = gemm_nt(x2, W1c, b1, ACT_RELU)                 # relu' = [hid > 0]
         else:
             raise _lib.SvolHipError('MLPLNFn: activation must be GELU or ReLU')
-        s32 = gemm_nt(hid, W2c, b2, ACT_NONE, residual=x32_2, out_f32=True)
+        if drop is not None:
+            dropout(hid, drop[0], drop[1], out=hid)   # (ReLU: aux IS hid — kept entries stay positive, dropped ones get relu' = 0, as the mask wants)
+            s32 = dropout_add(gemm_nt(hid, W2c, b2, ACT_NONE, out_f32=True), x32_2 if x32_2.is_contiguous() else x32_2.contiguous(),
+                              drop[0], drop[2])
+        else:
+            s32 = gemm_nt(hid, W2c, b2, ACT_NONE, residual=x32_2, out_f32=True)
         ctx.W1T, ctx.W2T, ctx.shp, ctx.act, ctx.has_ln = W1T, W2T, shp, act, gamma is not None
         ctx.pos_shape = pos_out.shape if pos_out is not None else None
         nig = ctx.needs_input_grad
@@ -839,7 +880,21 @@ class MLPLNFn(torch.autograd.Function):
             dpos = _pos_grad(dypos, ctx.pos_shape, D)
         sW1, sb1, sW2, sb2, sg, sbt = ctx.sinks
         vw = lambda s_: s_.view if s_ is not None else None
-        if ctx.has_ln:
+        drop = ctx.drop
+        if drop is not None:   # the residual branch's gradient passes the residual dropout's mask before it meets any GEMM
+            if ctx.has_ln:
+                ds32, ds, dg, dbt = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True, dg_out=vw(sg),
+                                                  db_out=vw(sbt))
+            else:
+                ds32 = dy32.reshape(-1, D)
+                ds32 = ds32 if ds32.is_contiguous() else ds32.contiguous()
+                ds = torch.empty((ds32.shape[0], D), dtype=dt, device=ds32.device)   # (never ds32 itself: that is the stream's gradient)
+                dg = dbt = None
+                ds = dropout(cast(ds32, dt), drop[0], drop[2], out=ds)
+            if ctx.has_ln:
+                dropout(ds, drop[0], drop[2], out=ds)
+            db2 = colsum(ds, out=vw(sb2))
+        elif ctx.has_ln:
             ds32, ds, dg, dbt, db2 = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True,
                                                    want_colsum=True, dg_out=vw(sg), db_out=vw(sbt), cs_out=vw(sb2))
         else:
@@ -854,7 +909,12 @@ class MLPLNFn(torch.autograd.Function):
         tn = gemm_tn_sink if (sW1 is not None and sW2 is not None) else (lambda A_, B_, out: gemm_tn(A_, B_, out=out))
         tn(ds, hid, out=dW2)
         # (ds W2) * act'(aux) and its column sums, one kernel
-        dpre, db1 = gemm_nt_dact(ds, ctx.W2T, aux, ctx.act, colsum_out=vw(sb1))
+        if drop is not None:   # ... then the hidden dropout's mask, then the column sums
+            dpre, _ = gemm_nt_dact(ds, ctx.W2T, aux, ctx.act, want_colsum=False)
+            dropout(dpre, drop[0], drop[1], out=dpre)
+            db1 = colsum(dpre, out=vw(sb1))
+        else:
+            dpre, db1 = gemm_nt_dact(ds, ctx.W2T, aux, ctx.act, colsum_out=vw(sb1))
         tn(dpre, x2, out=dW1)
         dx = gemm_nt(dpre, ctx.W1T)
         if (sW1 is None) != (sW2 is None):  # only one of the two has a sink: add the other by hand
@@ -863,7 +923,7 @@ class MLPLNFn(torch.autograd.Function):
                     s_.view.add_(g_)
         n_ = lambda s_, g_: None if s_ is not None else g_
         return (ds32.view(ctx.shp), dx.view(ctx.shp), n_(sW1, dW1), n_(sb1, db1), n_(sW2, dW2), n_(sb2, db2), n_(sg, dg),
-                n_(sbt, dbt), dpos, None)
+                n_(sbt, dbt), dpos, None, None)
 
 
 # bf16 mode: the VALUE projections of every attention block multiply by split weights W_hi + W_lo (two bf16 operands = 16
@@ -884,8 +944,14 @@ class AttnLNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xq32, xq, xq_pos, xk_pos, xv, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, kbias, self_attn,
-                need_weights=False):
+                need_weights=False, drop=None):
+        """drop = (p, seed_attention, seed_residual): training-mode dropout of the enc/dec attention blocks — on the attention
+        probabilities (nn.MultiheadAttention(dropout=p)) and on the block output before the residual add (dropout1 / dropout2,
+        transformer.py:158-177,216-247).  The returned attention weights stay those of the undropped softmax."""
         ctx.set_materialize_grads(False)
+        if drop is not None and drop[0] <= 0.0:
+            drop = None
+        ctx.drop = drop
         B, Lq, d = xq.shape
         dt = xq.dtype
         Lk = Lq if self_attn else xv.shape[1]
@@ -931,9 +997,14 @@ class AttnLNFn(torch.autograd.Function):
             else:
                 gemm_nt(a_v, Wc[2 * d:], b_in[2 * d:], out=kv[:, d:])
             k, v = kv[:, :d], kv[:, d:]
-        o, lse2 = attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias, premul)
+        o, lse2 = attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias, premul, drop=(drop[0], drop[1]) if drop is not None else None)
         att = attn_weights_mean(q, k, lse2, B, H, Lq, Lk, dh, kbias, premul) if need_weights else None
-        s32 = gemm_nt(cast(o, dt) if mixed else o, Woc, b_o, residual=xq32.reshape(B * Lq, d), out_f32=True)
+        if drop is not None:
+            r32 = xq32.reshape(B * Lq, d)
+            s32 = dropout_add(gemm_nt(cast(o, dt) if mixed else o, Woc, b_o, out_f32=True), r32 if r32.is_contiguous() else r32.contiguous(),
+                              drop[0], drop[2])
+        else:
+            s32 = gemm_nt(cast(o, dt) if mixed else o, Woc, b_o, residual=xq32.reshape(B * Lq, d), out_f32=True)
         ctx.WcT, ctx.WoT, ctx.dims, ctx.self_attn, ctx.premul = WcT, WoT, (B, H, Lq, Lk, dh, d), self_attn, premul
         ctx.mixed, ctx.Wq32T = mixed, Wq32T
         ctx.pos_shape = pos_out.shape if pos_out is not None else None
@@ -969,7 +1040,22 @@ class AttnLNFn(torch.autograd.Function):
             dpos = _pos_grad(dypos, ctx.pos_shape, d)
         sk = ctx.sinks
         dg = dbt = None
-        if sk is not None:
+        drop = ctx.drop
+        if drop is not None:   # the block output's gradient passes the residual dropout's mask before out_proj's backward
+            if ctx.has_ln:
+                ds32, g, dg, dbt = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True,
+                                                 dg_out=sk[4].view if sk is not None else None,
+                                                 db_out=sk[5].view if sk is not None else None)
+            else:
+                ds32 = dy32.reshape(-1, d)
+                ds32 = ds32 if ds32.is_contiguous() else ds32.contiguous()
+                g = dropout(cast(ds32, dt), drop[0], drop[2], out=torch.empty((ds32.shape[0], d), dtype=dt, device=ds32.device))
+            if ctx.has_ln:
+                dropout(g, drop[0], drop[2], out=g)
+            dbo = colsum(g, out=sk[3].view if sk is not None else None)
+            if sk is not None:
+                dW_in, db_in, dWo = sk[0].view, sk[1].view, sk[2].view
+        elif sk is not None:
             dW_in, db_in, dWo = sk[0].view, sk[1].view, sk[2].view
             if ctx.has_ln:
                 ds32, g, dg, dbt, dbo = layernorm_bwd(dy32, dy, dypos, s32, gamma, mean, rstd, dt, want32=True,
@@ -983,10 +1069,12 @@ class AttnLNFn(torch.autograd.Function):
                                                       want_colsum=True)
             else:
                 ds32, g, dbo = _res_grad(dy32, dt, None)
+        if sk is None:
             gbuf = torch.zeros((3 * d * d + 3 * d + d * d,), dtype=torch.float32, device=g.device)  # one memset
             dW_in, db_in = gbuf[:3 * d * d].view(3 * d, d), gbuf[3 * d * d:3 * d * d + 3 * d]
             dWo = gbuf[3 * d * d + 3 * d:].view(d, d)
         mixed = ctx.mixed
+        adrop = (drop[0], drop[1]) if drop is not None else None
         tn = gemm_tn_sink if sk is not None else (lambda A_, B_, out, colsum=None: gemm_tn(A_, B_, out=out, colsum=colsum))
         tn(g, cast(o, dt) if mixed else o, out=dWo)
         do = gemm_nt(g, WoT)
@@ -996,7 +1084,7 @@ class AttnLNFn(torch.autograd.Function):
         if ctx.self_attn:
             dqkv = torch.empty((B * Lq, 3 * d), dtype=dt, device=g.device)
             dq, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
-            attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias, ctx.premul)
+            attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias, ctx.premul, drop=adrop)
             tn(dqkv[:, :2 * d], a_qp, out=dW_in[:2 * d], colsum=db_in[:2 * d])
             tn(dv, a_q, out=dW_in[2 * d:], colsum=db_in[2 * d:])
             dxq_pos = gemm_nt(dqkv[:, :2 * d], WcT[:, :2 * d])  # d(x + pos) = [dq dk] W_qk
@@ -1004,11 +1092,11 @@ class AttnLNFn(torch.autograd.Function):
             if sk is not None:
                 dW_in = db_in = dWo = dbo = dg = dbt = None
             return (ds32.view(shq), dxq.view(shq), dxq_pos.view(shq), None, None, dW_in, db_in, dWo, dbo, dg, dbt,
-                    dpos, None, None, None, None)
+                    dpos, None, None, None, None, None)
         dq = torch.empty((B * Lq, d), dtype=q.dtype, device=g.device)
         dkv = torch.empty((B * Lk, 2 * d), dtype=k.dtype, device=g.device)
         dk, dv = dkv[:, :d], dkv[:, d:]
-        attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias, ctx.premul)
+        attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias, ctx.premul, drop=adrop)
         if mixed:
             dq = cast(dq, dt)
         tn(dq, a_qp, out=dW_in[:d], colsum=db_in[:d])
@@ -1021,7 +1109,7 @@ class AttnLNFn(torch.autograd.Function):
         if sk is not None:
             dW_in = db_in = dWo = dbo = dg = dbt = None
         return (ds32.view(shq), None, dxq_pos.view(shq), dxk_pos.view(shk), dxv.view(shk), dW_in, db_in, dWo, dbo, dg,
-                dbt, dpos, None, None, None, None)
+                dbt, dpos, None, None, None, None, None)
 
 
 class LNStreamFn(torch.autograd.Function):
@@ -1075,18 +1163,18 @@ def _qscale(d, premul, device):
     return t
 
 
-def mlp_ln(x32, x, W1, b1, W2, b2, gamma, beta, pos_out=None, act=ACT_GELU):
-    return MLPLNFn.apply(x32, x, W1, b1, W2, b2, gamma, beta, pos_out, act)
+def mlp_ln(x32, x, W1, b1, W2, b2, gamma, beta, pos_out=None, act=ACT_GELU, drop=None):
+    return MLPLNFn.apply(x32, x, W1, b1, W2, b2, gamma, beta, pos_out, act, drop)
 
 
-def self_attn_ln(x32, x, x_pos, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, kbias=None):
-    return AttnLNFn.apply(x32, x, x_pos, None, None, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, kbias, True)
+def self_attn_ln(x32, x, x_pos, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, kbias=None, drop=None):
+    return AttnLNFn.apply(x32, x, x_pos, None, None, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, kbias, True, False, drop)
 
 
 def cross_attn_ln(xq32, xq, xq_pos, xk_pos, xv, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, kbias,
-                  need_weights=False):
+                  need_weights=False, drop=None):
     return AttnLNFn.apply(xq32, xq, xq_pos, xk_pos, xv, W_in, b_in, W_o, b_o, gamma, beta, pos_out, H, kbias, False,
-                          need_weights)
+                          need_weights, drop)
 
 
 def ln_stream(x32, gamma, beta, pos, dtype, want32=False):

@@ -41,6 +41,14 @@ CASES['encdec_mid_qry_pre'] = dict(
     head='variants', over=dict(mode='concat_to_qry', pre_norm=True, hidden_dim=256, nheads=8, dim_feedforward=512, enc_layers=1,
                                dec_layers=2, num_queries=100, feat_dim=64), B=2, L=2176, Ls=1, pad=0)
 CASES['encdec_sketch_detr_post'] = dict(head='sketch_detr', over=dict(mode='unused', pre_norm=False), B=2, L=6, Ls=1, pad=0)
+# TRAINING mode with dropout inside the Transformer: torch.nn.functional.dropout is replaced, for the duration
+# of the reference's forward, by a function that draws its keep mask from a seeded generator and RECORDS it — the fixture holds
+# the masks in call order, so that the oracle (and nothing else) can replay the very same masks.  input_dropout = 0: only the
+# Transformer's own dropouts (attention probabilities, dropout1/2/3, FFN dropout) are active.
+CASES['encdec_train_append_post'] = dict(head='variants', over=dict(mode='append_to_seq', pre_norm=False, dropout=0.25, input_dropout=0.0),
+                                         B=2, L=24, Ls=2, pad=5, train=True)
+CASES['encdec_train_qry_pre'] = dict(head='variants', over=dict(mode='concat_to_qry', pre_norm=True, dropout=0.25, input_dropout=0.0),
+                                     B=2, L=24, Ls=1, pad=0, train=True)
 
 
 def probe_loss(stack_logits, stack_boxes):
@@ -62,6 +70,20 @@ def run(name, c):
     sd = syn.synth_like(shapes, seed=1)
     model.load_state_dict(sd, strict=True)
     model.eval()
+    masks = []
+    if c.get('train'):
+        model.train()
+        import torch.nn.functional as F
+        gen = torch.Generator().manual_seed(1234)
+        orig_dropout = F.dropout
+
+        def recorded_dropout(x, p=0.5, training=True, inplace=False):
+            if not training or p == 0.0:
+                return x
+            keep = (torch.rand(x.shape, generator=gen) >= p)
+            masks.append(keep.reshape(-1).numpy().copy())
+            return x * keep.to(x.dtype) / (1.0 - p)
+        F.dropout = recorded_dropout
     seen = {}
 
     def _keep(_m, _i, o):  # (a hook that returns a value would REPLACE the module's output)
@@ -80,6 +102,8 @@ def run(name, c):
         logits, boxes = stack_outputs(out)
     loss = probe_loss(logits, boxes)
     loss.backward()
+    if c.get('train'):
+        F.dropout = orig_dropout
     rec = {'meta': np.asarray(json.dumps(dict(args=vars(args), head=c['head'], B=c['B'], L=c['L'], Ls=c['Ls'], pad=c['pad'],
                                               torch=torch.__version__))),
            'keys': np.asarray('\n'.join(shapes.keys())),
@@ -94,6 +118,11 @@ def run(name, c):
         a = att.detach()
         rec['att_rowsum_err'] = np.asarray(float((a.sum(-1) - 1).abs().max()))
         rec['att'] = a.numpy() if a.numel() <= 65536 else a[:, :, ::7, ::37].contiguous().numpy()
+    if c.get('train'):
+        rec['n_masks'] = np.asarray(len(masks))
+        rec['mask_sizes'] = np.asarray([m.size for m in masks], np.int64)
+        rec['mask_bits'] = np.packbits(np.concatenate(masks))
+        rec['dropout_p'] = np.asarray(args.dropout)
     for k, p in model.named_parameters():
         grad_record(rec, k, p.grad)
     path = os.path.join(HERE, f'{name}.npz')
