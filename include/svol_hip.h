@@ -113,6 +113,18 @@ int svol_gemm_nt_dact(const void* A, int64_t lda, const void* B, int64_t ldb, vo
  * matrix pipe (A^T * ones) by the workgroups that already hold the A tiles. */
 int svol_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
                  int64_t Mc, int64_t N, int64_t K, int dtype, void* stream);
+/* Up to SVOL_TN_GROUP_MAX svol_gemm_tn problems of ONE element type in one launch: the weight gradients of one backward block
+ * (dW1, dW2, dWo, dW_in of a transformer block).  `problems` is a HOST array of n records (copied into the kernel arguments);
+ * more than SVOL_TN_GROUP_MAX problems, or shapes the grouped kernels do not take, are issued one by one. */
+#define SVOL_TN_GROUP_MAX 6
+typedef struct svol_tn_problem {
+    const void* A; int64_t lda;   /* [Mc, N] */
+    const void* B; int64_t ldb;   /* [Mc, K] */
+    float* C; int64_t ldc;        /* [N, K] fp32, accumulated into */
+    float* colsum;                /* [N] fp32 or NULL, accumulated into */
+    int64_t Mc, N, K;
+} svol_tn_problem;
+int svol_gemm_tn_grouped(const svol_tn_problem* problems, int32_t n, int dtype, void* stream);
 /* out[N] (fp32) += sum_m X[m,n]   (bias gradient).  Caller zeroes `out`. */
 int svol_colsum(const void* X, int64_t ldx, float* out, int64_t M, int64_t N, int dtype, void* stream);
 /* dpre[i] = dy[i] * act'(aux[i]); aux = post-activation for RELU/SIGMOID, pre-activation for GELU. */

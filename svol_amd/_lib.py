@@ -30,6 +30,7 @@ SIGNATURES = {
     'svol_gemm_nt_dgelu': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p],
     'svol_gemm_nt_dact': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _int, _p, _i64, _i64, _i64, _int, _p],
     'svol_gemm_tn': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p],
+    'svol_gemm_tn_grouped': [_p, _i32, _int, _p],
     'svol_colsum': [_p, _i64, _p, _i64, _i64, _int, _p],
     'svol_act_bwd': [_p, _p, _p, _int, _i64, _int, _p],
     'svol_layernorm_fwd': [_p, _int, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _f32, _u64, _p, _int, _p],
@@ -78,6 +79,14 @@ SIGNATURES = {
     'svol_query_cross_bwd': [_p, _p, _p],
     'svol_query_cross_wgrad': [_p, _p, _p],
 }
+
+
+
+class TnProblem(ctypes.Structure):
+    """svol_tn_problem (include/svol_hip.h): one weight-gradient GEMM of a grouped launch."""
+    _fields_ = [('A', _p), ('lda', _i64), ('B', _p), ('ldb', _i64), ('C', _p), ('ldc', _i64), ('colsum', _p),
+                ('Mc', _i64), ('N', _i64), ('K', _i64)]
+
 
 _LIB = None
 

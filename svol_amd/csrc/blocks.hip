@@ -148,12 +148,14 @@ int svol_video_half_wgrad(const int64_t* dims, void* const* p, void* s) {
     if (!d.ok()) return SVOL_E_INVALID;
     const int64_t M = d.B * d.L, D = d.D, F = d.F;
     const int dt = d.dt;
-    RUN(svol_gemm_tn(P(DS3), D, P(HID), F, f32(P(DW_FC2)), F, nullptr, M, D, F, dt, s));
-    RUN(svol_gemm_tn(P(DPRE), F, P(Y2), D, f32(P(DW_FC1)), D, nullptr, M, F, D, dt, s));
-    RUN(svol_gemm_tn(P(G2D), D, P(O), D, f32(P(DW_O)), D, nullptr, M, D, D, dt, s));
-    RUN(svol_gemm_tn(P(DQKV), 3 * D, P(Y1POS), D, f32(P(DW_IN)), D, f32(P(DB_IN)), M, 2 * D, D, dt, s));
-    RUN(svol_gemm_tn(at(P(DQKV), 2 * D, dt), 3 * D, P(Y1), D, f32(P(DW_IN)) + 2 * D * D, D, f32(P(DB_IN)) + 2 * D, M, D, D, dt, s));
-    return SVOL_OK;
+    // the block's five weight gradients in ONE launch (svol_gemm_tn_grouped)
+    const svol_tn_problem pr[5] = {
+        {P(DS3), D, P(HID), F, f32(P(DW_FC2)), F, nullptr, M, D, F},
+        {P(DPRE), F, P(Y2), D, f32(P(DW_FC1)), D, nullptr, M, F, D},
+        {P(G2D), D, P(O), D, f32(P(DW_O)), D, nullptr, M, D, D},
+        {P(DQKV), 3 * D, P(Y1POS), D, f32(P(DW_IN)), D, f32(P(DB_IN)), M, 2 * D, D},
+        {at(P(DQKV), 2 * D, dt), 3 * D, P(Y1), D, f32(P(DW_IN)) + 2 * D * D, D, f32(P(DB_IN)) + 2 * D, M, D, D}};
+    return svol_gemm_tn_grouped(pr, 5, dt, s);
 #undef P
 }
 
@@ -205,10 +207,11 @@ int svol_query_self_wgrad(const int64_t* dims, void* const* p, void* s) {
     if (!d.ok()) return SVOL_E_INVALID;
     const int64_t R = d.B * d.N, D = d.D;
     const int qdt = d.qdt;
-    RUN(svol_gemm_tn(P(G), D, P(OA), D, f32(P(DW_O)), D, nullptr, R, D, D, qdt, s));
-    RUN(svol_gemm_tn(P(DQKV), 3 * D, P(OPOS), D, f32(P(DW_IN)), D, f32(P(DB_IN)), R, 2 * D, D, qdt, s));
-    RUN(svol_gemm_tn(at(P(DQKV), 2 * D, qdt), 3 * D, P(O), D, f32(P(DW_IN)) + 2 * D * D, D, f32(P(DB_IN)) + 2 * D, R, D, D, qdt, s));
-    return SVOL_OK;
+    const svol_tn_problem pr[3] = {
+        {P(G), D, P(OA), D, f32(P(DW_O)), D, nullptr, R, D, D},
+        {P(DQKV), 3 * D, P(OPOS), D, f32(P(DW_IN)), D, f32(P(DB_IN)), R, 2 * D, D},
+        {at(P(DQKV), 2 * D, qdt), 3 * D, P(O), D, f32(P(DW_IN)) + 2 * D * D, D, f32(P(DB_IN)) + 2 * D, R, D, D}};
+    return svol_gemm_tn_grouped(pr, 3, qdt, s);
 #undef P
 }
 
@@ -297,13 +300,16 @@ int svol_query_cross_wgrad(const int64_t* dims, void* const* p, void* s) {
     const int dt = d.dt, qdt = d.qdt;
     const bool mixed = qdt != dt;
     // the video-sized ones first (they are what the stream they share with the video half's weight gradients is sized for)
-    RUN(svol_gemm_tn(P(DKV), 2 * D, P(MPOS), D, f32(P(DW_IN)) + D * D, D, f32(P(DB_IN)) + D, M, D, D, dt, s));
-    RUN(svol_gemm_tn(at(P(DKV), D, dt), 2 * D, P(MV), D, f32(P(DW_IN)) + 2 * D * D, D, f32(P(DB_IN)) + 2 * D, M, D, D, dt, s));
-    RUN(svol_gemm_tn(P(DS6), D, P(HID), F, f32(P(DW_FC2)), F, nullptr, R, D, F, qdt, s));
-    RUN(svol_gemm_tn(P(DPRE), F, P(Y5), D, f32(P(DW_FC1)), D, nullptr, R, F, D, qdt, s));
-    RUN(svol_gemm_tn(P(G5D), D, mixed ? P(OAQ) : P(OA), D, f32(P(DW_O)), D, nullptr, R, D, D, qdt, s));
-    RUN(svol_gemm_tn(mixed ? P(DQ) : P(DQC), D, P(OPOS), D, f32(P(DW_IN)), D, f32(P(DB_IN)), R, D, D, qdt, s));
-    return SVOL_OK;
+    const svol_tn_problem pv[2] = {
+        {P(DKV), 2 * D, P(MPOS), D, f32(P(DW_IN)) + D * D, D, f32(P(DB_IN)) + D, M, D, D},
+        {at(P(DKV), D, dt), 2 * D, P(MV), D, f32(P(DW_IN)) + 2 * D * D, D, f32(P(DB_IN)) + 2 * D, M, D, D}};
+    RUN(svol_gemm_tn_grouped(pv, 2, dt, s));
+    const svol_tn_problem pq[4] = {
+        {P(DS6), D, P(HID), F, f32(P(DW_FC2)), F, nullptr, R, D, F},
+        {P(DPRE), F, P(Y5), D, f32(P(DW_FC1)), D, nullptr, R, F, D},
+        {P(G5D), D, mixed ? P(OAQ) : P(OA), D, f32(P(DW_O)), D, nullptr, R, D, D},
+        {mixed ? P(DQ) : P(DQC), D, P(OPOS), D, f32(P(DW_IN)), D, f32(P(DB_IN)), R, D, D}};
+    return svol_gemm_tn_grouped(pq, 4, qdt, s);
 #undef P
 }
 

@@ -37,6 +37,7 @@ typedef f16x2 h16x2;
 #define SVOL_H16_PSUM_MAX 6.5e4f   /* a softmax numerator that would not fit fp16 (65504) makes the row sum exceed this */
 #define svol_gemm_nt_bf16_fast svol_gemm_nt_f16_fast
 #define svol_gemm_tn_bf16_fast svol_gemm_tn_f16_fast
+#define svol_gemm_tn_bf16_grouped svol_gemm_tn_f16_grouped
 #define svol_gemm_ws_bf16 svol_gemm_ws_f16
 #define svol_gemm_n256_bf16 svol_gemm_n256_f16
 #define svol_attn_fwd_bf16_launch svol_attn_fwd_f16_launch

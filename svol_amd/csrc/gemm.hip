@@ -171,7 +171,7 @@ template <> struct TnCfg<f16_t> { static constexpr int CT = 64, STRIDE = 288, CP
 template <> struct TnCfg<float> { static constexpr int CT = 32, STRIDE = 576, CPR = 32; };
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
+__device__ __forceinline__ void gemm_tn_body(const TnArgs& p, const int bid) {
     constexpr int EPC = Tr<T>::EPC;
     constexpr int CT = TnCfg<T>::CT, S = TnCfg<T>::STRIDE, CPR = TnCfg<T>::CPR;
     __shared__ __attribute__((aligned(16))) char smem[2 * CT * S];
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
     const int wn = wave >> 1, wk = wave & 1;
     // 1-D grid, split index fastest: consecutive workgroup ids go to consecutive XCDs, so with splits % 8 == 0 all
     // output tiles of one row chunk run on the same XCD and share its L2 for the re-read A / B rows
-    const int split = blockIdx.x % p.splits, tile = blockIdx.x / p.splits;
+    const int split = bid % p.splits, tile = bid / p.splits;
     const int kt_ = tile % p.ktiles, nt_ = tile / p.ktiles;
     const int n0 = nt_ * 128, k0 = kt_ * 128;
     const int m_begin = split * p.m_chunk;
@@ -307,6 +307,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
                 if (n < p.N) atomicAdd(p.colsum + n, cs[nt][r]);
             }
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) { gemm_tn_body<T>(p, (int)blockIdx.x); }
+// several problems in one launch (svol_gemm_tn_grouped): see gemm_tn_bf16.hip
+struct TnGroupArgsG {
+    int n;
+    int begin[SVOL_TN_GROUP_MAX + 1];
+    TnArgs a[SVOL_TN_GROUP_MAX];
+};
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(TnGroupArgsG g) {
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < SVOL_TN_GROUP_MAX; ++j)
+        if (j < g.n && (int)blockIdx.x >= g.begin[j]) i = j;
+    gemm_tn_body<T>(g.a[i], (int)blockIdx.x - g.begin[i]);
 }
 
 // ---------------------------------------------------------------------------
@@ -571,10 +588,47 @@ int svol_gemm_nt_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ld
 
 int svol_gemm_tn_f16_fast(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
                           int64_t Mc, int64_t N, int64_t K, hipStream_t s);
+int svol_gemm_tn_bf16_grouped(const svol_tn_problem* pr, int n, hipStream_t s);
+int svol_gemm_tn_f16_grouped(const svol_tn_problem* pr, int n, hipStream_t s);
 int svol_gemm_nt_f16_fast(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
                           int act, void* pre, int64_t ldp, const void* res, int64_t ldr, int out_f32, const void* aux,
                           int64_t ldaux, float* colsum, int epi, const float* colscale, int64_t M, int64_t N, int64_t K,
                           int64_t kwrap, hipStream_t s);
+
+// split plan of the generic TN kernel (shared by svol_gemm_tn and svol_gemm_tn_grouped)
+static int tn_generic_plan(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum, int64_t Mc,
+                           int64_t N, int64_t K, int dtype, TnArgs& out, int64_t& wgs) {
+    const int epc = svol_is16(dtype) ? 8 : 4;
+    if (N % epc || K % epc || lda % epc || ldb % epc) return SVOL_E_UNSUPPORTED;
+    if (!aligned16(A) || !aligned16(B)) return SVOL_E_INVALID;
+    if (Mc > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return SVOL_E_UNSUPPORTED;
+    const int ct = svol_is16(dtype) ? 64 : 32;
+    const int64_t tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    // split the contraction so that ~TARGET workgroups exist, chunk a multiple of CT
+    // (measured on MI355X: the fp32 atomics of the final accumulation dominate small outputs, so few, long-running
+    //  workgroups win there: 256x256 outputs 0.065 ms at 1024 workgroups vs 0.032 ms at 256)
+    static const int force_wgs = getenv("SVOL_TN_WGS") ? atoi(getenv("SVOL_TN_WGS")) : 0;
+    const int target_wgs = force_wgs ? force_wgs : (tiles <= 8 ? 256 : 512);
+    int64_t want = (target_wgs + tiles - 1) / tiles;
+    int64_t chunk = (Mc + want - 1) / want;
+    chunk = ((chunk + ct - 1) / ct) * ct;
+    // (fp32 with few rows — the query stream's weight gradients, Mc = 800: the 4 x CT floor would leave 28 workgroups, each
+    //  walking 128 rows of fp32 MFMAs; one CT-row slab per workgroup gives 100 and the atomic volume stays small)
+    const int64_t floor_rows = (dtype == SVOL_F32 && Mc <= 4096) ? ct : 4 * ct;
+    if (chunk < floor_rows) chunk = floor_rows;
+    int64_t splits = (Mc + chunk - 1) / chunk;
+    if (splits > 8 && splits % 8) {  // keep the split count a multiple of the 8 XCDs when the rows allow it
+        const int64_t s8 = (splits + 7) / 8 * 8;
+        int64_t c8 = (Mc + s8 - 1) / s8;
+        c8 = ((c8 + ct - 1) / ct) * ct;
+        if (c8 >= floor_rows && (Mc + c8 - 1) / c8 == s8) { chunk = c8; splits = s8; }
+    }
+    const int64_t ktiles = (K + 127) / 128;
+    if (splits * tiles > (1ll << 30)) return SVOL_E_UNSUPPORTED;
+    out = TnArgs{A, B, C, colsum, lda, ldb, ldc, (int)Mc, (int)N, (int)K, (int)chunk, (int)ktiles, (int)splits};
+    wgs = splits * tiles;
+    return SVOL_OK;
+}
 
 extern "C" {
 
@@ -697,40 +751,62 @@ int svol_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* 
                                                                                               reinterpret_cast<hipStream_t>(stream));
         if (rc != SVOL_E_UNSUPPORTED) return rc;
     }
-    const int epc = svol_is16(dtype) ? 8 : 4;
-    if (N % epc || K % epc || lda % epc || ldb % epc) return SVOL_E_UNSUPPORTED;
-    if (!aligned16(A) || !aligned16(B)) return SVOL_E_INVALID;
-    if (Mc > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return SVOL_E_UNSUPPORTED;
-    const int ct = svol_is16(dtype) ? 64 : 32;
-    const int64_t tiles = ((N + 127) / 128) * ((K + 127) / 128);
-    // split the contraction so that ~TARGET workgroups exist, chunk a multiple of CT
-    // (measured on MI355X: the fp32 atomics of the final accumulation dominate small outputs, so few, long-running
-    //  workgroups win there: 256x256 outputs 0.065 ms at 1024 workgroups vs 0.032 ms at 256)
-    static const int force_wgs = getenv("SVOL_TN_WGS") ? atoi(getenv("SVOL_TN_WGS")) : 0;
-    const int target_wgs = force_wgs ? force_wgs : (tiles <= 8 ? 256 : 512);
-    int64_t want = (target_wgs + tiles - 1) / tiles;
-    int64_t chunk = (Mc + want - 1) / want;
-    chunk = ((chunk + ct - 1) / ct) * ct;
-    // (fp32 with few rows — the query stream's weight gradients, Mc = 800: the 4 x CT floor would leave 28 workgroups, each
-    //  walking 128 rows of fp32 MFMAs; one CT-row slab per workgroup gives 100 and the atomic volume stays small)
-    const int64_t floor_rows = (dtype == SVOL_F32 && Mc <= 4096) ? ct : 4 * ct;
-    if (chunk < floor_rows) chunk = floor_rows;
-    int64_t splits = (Mc + chunk - 1) / chunk;
-    if (splits > 8 && splits % 8) {  // keep the split count a multiple of the 8 XCDs when the rows allow it
-        const int64_t s8 = (splits + 7) / 8 * 8;
-        int64_t c8 = (Mc + s8 - 1) / s8;
-        c8 = ((c8 + ct - 1) / ct) * ct;
-        if (c8 >= floor_rows && (Mc + c8 - 1) / c8 == s8) { chunk = c8; splits = s8; }
-    }
-    const int64_t ktiles = (K + 127) / 128;
-    if (splits * tiles > (1ll << 30)) return SVOL_E_UNSUPPORTED;
-    TnArgs p{A, B, C, colsum, lda, ldb, ldc, (int)Mc, (int)N, (int)K, (int)chunk, (int)ktiles, (int)splits};
+    TnArgs p{};
+    int64_t wgs = 0;
+    const int prc = tn_generic_plan(A, lda, B, ldb, C, ldc, colsum, Mc, N, K, dtype, p, wgs);
+    if (prc) return prc;
+    const int64_t splits = 1, tiles = wgs;
     dim3 grid((unsigned)(splits * tiles));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SVOL_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, dim3(256), 0, s, p);
     else if (dtype == SVOL_F16) hipLaunchKernelGGL(gemm_tn_kernel<f16_t>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 0, s, p);
     SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_gemm_tn_grouped(const svol_tn_problem* pr, int32_t n, int dtype, void* stream) {
+    if (!pr || n < 0) return SVOL_E_INVALID;
+    if (!svol_is16(dtype) && dtype != SVOL_F32) return SVOL_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static const bool no_group = getenv("SVOL_TN_NO_GROUP") != nullptr;
+    for (int32_t i0 = 0; i0 < n; i0 += SVOL_TN_GROUP_MAX) {
+        const int m = (int)((n - i0 < SVOL_TN_GROUP_MAX) ? n - i0 : SVOL_TN_GROUP_MAX);
+        int rc = SVOL_E_UNSUPPORTED;
+        bool ok = !no_group && m > 1;
+        for (int i = 0; ok && i < m; ++i) ok = pr[i0 + i].A && pr[i0 + i].B && pr[i0 + i].C && pr[i0 + i].Mc > 0 && pr[i0 + i].N > 0 && pr[i0 + i].K > 0;
+        if (ok && svol_is16(dtype)) {
+            rc = (dtype == SVOL_BF16 ? svol_gemm_tn_bf16_grouped : svol_gemm_tn_f16_grouped)(pr + i0, m, s);
+        } else if (ok) {
+            TnGroupArgsG g{};
+            g.n = m;
+            int64_t tot = 0;
+            rc = SVOL_OK;
+            for (int i = 0; i < m && rc == SVOL_OK; ++i) {
+                int64_t wgs = 0;
+                const svol_tn_problem& q = pr[i0 + i];
+                rc = tn_generic_plan(q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.colsum, q.Mc, q.N, q.K, dtype, g.a[i], wgs);
+                g.begin[i] = (int)tot;
+                tot += wgs;
+            }
+            if (rc == SVOL_OK && tot <= (1ll << 30)) {
+                for (int i = m; i <= SVOL_TN_GROUP_MAX; ++i) g.begin[i] = (int)tot;
+                hipLaunchKernelGGL(gemm_tn_grouped_kernel<float>, dim3((unsigned)tot), dim3(256), 0, s, g);
+                SVOL_CHECK_LAUNCH();
+            } else {
+                rc = SVOL_E_UNSUPPORTED;
+            }
+        }
+        if (rc == SVOL_E_UNSUPPORTED) {   // one by one (odd shapes, a single problem, SVOL_TN_NO_GROUP)
+            for (int i = 0; i < m; ++i) {
+                const svol_tn_problem& q = pr[i0 + i];
+                const int r1 = svol_gemm_tn(q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.colsum, q.Mc, q.N, q.K, dtype, stream);
+                if (r1) return r1;
+            }
+        } else if (rc) {
+            return rc;
+        }
+    }
     return SVOL_OK;
 }
 

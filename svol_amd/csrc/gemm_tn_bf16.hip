@@ -41,12 +41,12 @@ __device__ __forceinline__ int phys(int row, int col) {
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_dma(TnFastArgs p) {
+__device__ __forceinline__ void tn_dma_body(const TnFastArgs& p, const int bid) {
     __shared__ __attribute__((aligned(1024))) char smem[STG * 2 * OPB];  // 64 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wk = wave & 1;
-    const int split = blockIdx.x % p.splits, tile = blockIdx.x / p.splits;
+    const int split = bid % p.splits, tile = bid / p.splits;
     const int kt_ = tile % p.ktiles, nt_ = tile / p.ktiles;
     const int n0 = nt_ * 128, k0 = kt_ * 128;
     const int m_begin = split * p.m_chunk;
@@ -183,14 +183,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_dma(TnFastArgs p) {
             }
     }
 }
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_dma(TnFastArgs p) { tn_dma_body(p, (int)blockIdx.x); }
 
-}  // namespace
+// Several weight gradients of one backward block in ONE launch (92 weight-gradient launches per step): the
+// problems ride in the kernel arguments, a workgroup finds its problem by a scan over at most SVOL_TN_GROUP_MAX prefix sums.
+struct TnGroupArgs {
+    int n;
+    int begin[SVOL_TN_GROUP_MAX + 1];
+    TnFastArgs a[SVOL_TN_GROUP_MAX];
+};
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_dma_grouped(TnGroupArgs g) {
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < SVOL_TN_GROUP_MAX; ++j)
+        if (j < g.n && (int)blockIdx.x >= g.begin[j]) i = j;
+    tn_dma_body(g.a[i], (int)blockIdx.x - g.begin[i]);
+}
 
-// launcher used by gemm.hip's svol_gemm_tn.  Returns SVOL_E_UNSUPPORTED when the shape does not qualify.
-int svol_gemm_tn_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
-                           int64_t Mc, int64_t N, int64_t K, hipStream_t s) {
-    if (N % 8 || K % 8 || lda % 8 || ldb % 8 || !aligned16(A) || !aligned16(B)) return SVOL_E_UNSUPPORTED;
-    if (Mc < 1 || Mc > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return SVOL_E_UNSUPPORTED;
+// split plan of one problem (shared by the single and the grouped launcher); false = the shape does not qualify
+bool tn_plan(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum, int64_t Mc, int64_t N,
+             int64_t K, TnFastArgs& out, int64_t& wgs) {
+    if (N % 8 || K % 8 || lda % 8 || ldb % 8 || !aligned16(A) || !aligned16(B)) return false;
+    if (Mc < 1 || Mc > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return false;
     const int64_t tiles = ((N + 127) / 128) * ((K + 127) / 128);
     // split the contraction: few, long-running workgroups for small outputs (the final fp32 atomics dominate
     // there), ~2 per CU otherwise; a multiple of the 8 XCDs so that the tiles of one row chunk share an L2
@@ -202,11 +216,42 @@ int svol_gemm_tn_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ld
     chunk = ((chunk + CT - 1) / CT) * CT;
     if (chunk < 4 * CT) chunk = 4 * CT;
     const int64_t splits = (Mc + chunk - 1) / chunk;
-    if (splits * tiles > (1ll << 30)) return SVOL_E_UNSUPPORTED;
+    if (splits * tiles > (1ll << 28)) return false;
     const int64_t ldmax = lda > ldb ? lda : ldb;
-    if (chunk * ldmax * 2 >= (1ll << 31)) return SVOL_E_UNSUPPORTED;  // 32-bit buffer offsets
-    TnFastArgs p{(const h16_t*)A, (const h16_t*)B, C, colsum, lda, ldb, ldc, (int)Mc, (int)N, (int)K, (int)chunk,
-                 (int)((K + 127) / 128), (int)splits};
-    hipLaunchKernelGGL(gemm_tn_bf16_dma, dim3((unsigned)(splits * tiles)), dim3(256), 0, s, p);
+    if (chunk * ldmax * 2 >= (1ll << 31)) return false;  // 32-bit buffer offsets
+    out = TnFastArgs{(const h16_t*)A, (const h16_t*)B, C, colsum, lda, ldb, ldc, (int)Mc, (int)N, (int)K, (int)chunk,
+                     (int)((K + 127) / 128), (int)splits};
+    wgs = splits * tiles;
+    return true;
+}
+
+}  // namespace
+
+// grouped launcher used by gemm.hip's svol_gemm_tn_grouped: all problems or none (SVOL_E_UNSUPPORTED)
+int svol_gemm_tn_bf16_grouped(const svol_tn_problem* pr, int n, hipStream_t s) {
+    if (n < 1 || n > SVOL_TN_GROUP_MAX) return SVOL_E_UNSUPPORTED;
+    TnGroupArgs g{};
+    g.n = n;
+    int64_t tot = 0;
+    for (int i = 0; i < n; ++i) {
+        int64_t wgs = 0;
+        if (!tn_plan(pr[i].A, pr[i].lda, pr[i].B, pr[i].ldb, pr[i].C, pr[i].ldc, pr[i].colsum, pr[i].Mc, pr[i].N, pr[i].K, g.a[i], wgs))
+            return SVOL_E_UNSUPPORTED;
+        g.begin[i] = (int)tot;
+        tot += wgs;
+    }
+    for (int i = n; i <= SVOL_TN_GROUP_MAX; ++i) g.begin[i] = (int)tot;
+    if (tot > (1ll << 30)) return SVOL_E_UNSUPPORTED;
+    hipLaunchKernelGGL(gemm_tn_bf16_dma_grouped, dim3((unsigned)tot), dim3(256), 0, s, g);
+    return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
+}
+
+// launcher used by gemm.hip's svol_gemm_tn.  Returns SVOL_E_UNSUPPORTED when the shape does not qualify.
+int svol_gemm_tn_bf16_fast(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum,
+                           int64_t Mc, int64_t N, int64_t K, hipStream_t s) {
+    TnFastArgs p{};
+    int64_t wgs = 0;
+    if (!tn_plan(A, lda, B, ldb, C, ldc, colsum, Mc, N, K, p, wgs)) return SVOL_E_UNSUPPORTED;
+    hipLaunchKernelGGL(gemm_tn_bf16_dma, dim3((unsigned)wgs), dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
 }

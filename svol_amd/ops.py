@@ -8,6 +8,7 @@ non-CUDA tensor or a missing library raises.
 """
 from __future__ import annotations
 
+import ctypes
 import math
 import os
 from typing import Optional
@@ -181,6 +182,22 @@ def gemm_tn(A, B, out=None, colsum=None, stream=None):
                                  Mc, N, K, _dt(A), _stream() if stream is None else stream)
     _lib.check(rc, 'svol_gemm_tn')
     return out
+
+
+def gemm_tn_grouped(problems, stream=None):
+    """several gemm_tn problems of one element type in one launch: problems = [(A, B, out, colsum | None), ...], out / colsum fp32,
+    accumulated into (svol_gemm_tn_grouped)."""
+    n = len(problems)
+    arr = (_lib.TnProblem * n)()
+    dt = None
+    for i, (A, B, out, cs) in enumerate(problems):
+        assert A.dim() == 2 and B.dim() == 2 and A.shape[0] == B.shape[0] and A.stride(1) == 1 and B.stride(1) == 1 and A.dtype == B.dtype
+        assert dt is None or dt == A.dtype
+        dt = A.dtype
+        arr[i] = _lib.TnProblem(_ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), out.stride(0), _ptr(cs), A.shape[0], A.shape[1],
+                                B.shape[1])
+    rc = _lib.lib().svol_gemm_tn_grouped(ctypes.cast(arr, ctypes.c_void_p), n, _DT[dt], _stream() if stream is None else stream)
+    _lib.check(rc, 'svol_gemm_tn_grouped')
 
 
 # ---- weight gradients off the critical path --------------------------------------------------------------------------------

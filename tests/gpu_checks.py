@@ -264,6 +264,32 @@ def check_gemm_tn():
     return res
 
 
+def check_gemm_tn_grouped():
+    """svol_gemm_tn_grouped: the weight gradients of one backward block in one launch — every problem against fp64, accumulation
+    into non-zero targets, fused column sums, ragged row counts; 5 problems (the video half), 7 (two launches), a single one
+    (falls back to the plain entry), shapes the fast kernel does not take (the group then runs one by one)."""
+    res = {}
+    for dt in DTYPES16:
+        for tag, shapes in (('video_half', [(6272, 256, 2048), (6272, 2048, 256), (6272, 256, 256), (6272, 512, 256), (6272, 256, 256)]),
+                            ('seven', [(800, 256, 256)] * 3 + [(801, 64, 256), (800, 256, 2048), (797, 2048, 256), (800, 512, 256)]),
+                            ('single', [(1000, 128, 256)]),
+                            ('odd', [(300, 24, 40), (300, 40, 24)])):
+            probs, refs = [], []
+            for i, (Mc, N, K) in enumerate(shapes):
+                A, Bm = _rnd((Mc, N), dt, 50 + i), _rnd((Mc, K), dt, 60 + i)
+                C0, cs0 = _rnd((N, K), torch.float32, 70 + i), _rnd((N,), torch.float32, 80 + i)
+                want_cs = i % 2 == 0
+                Cd, csd = C0.to(DEV), cs0.to(DEV)
+                probs.append((A.to(DEV), Bm.to(DEV), Cd, csd if want_cs else None))
+                refs.append((C0.double() + A.double().t() @ Bm.double(), cs0.double() + A.double().sum(0), want_cs, cs0))
+            ops.gemm_tn_grouped(probs)
+            for i, ((A, Bm, Cd, csd), (Cr, cr, want_cs, cs0)) in enumerate(zip(probs, refs)):
+                res[f'gemm_tn_grouped/{dt}/{tag}/{i}/C'] = (rel_err(Cd, Cr), 2e-5 if dt == torch.float32 else 1e-4)
+                if want_cs:
+                    res[f'gemm_tn_grouped/{dt}/{tag}/{i}/colsum'] = (rel_err(csd, cr), 2e-5 if dt == torch.float32 else 1e-4)
+    return res
+
+
 def check_small_ops():
     res = {}
     for dt in DTYPES16:

@@ -47,6 +47,10 @@ def test_gemm_tn(G):
     _assert(G.check_gemm_tn())
 
 
+def test_gemm_tn_grouped(G):
+    _assert(G.check_gemm_tn_grouped())
+
+
 def test_small_ops(G):
     _assert(G.check_small_ops())
 
