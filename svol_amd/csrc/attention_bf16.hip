@@ -48,6 +48,7 @@ struct Args {
     // attention-probability dropout (general kernels only; see attention.hip AttnArgs): keep mask of ((b*H + h)*Lq + q)*Lk + key
     float drop_p, drop_inv;
     uint64_t drop_seed;
+    int dq_rot;                   // != 0: the unmasked dQ kernel runs its rotated schedule (dq_phase; SVOL_ATTN_NO_DQ_ROT=1 clears it)
 };
 __device__ __forceinline__ float attn_drop(uint64_t seed, uint64_t rowbase, int key, float p, float inv) {
     return dropout_scale(seed, rowbase + (uint64_t)key, p, inv);
@@ -94,6 +95,20 @@ __device__ __forceinline__ void dma_tile(char* img, const h16_t* g, int64_t ld, 
     dma_piece(img, g, ld, row0, 2 * wave + 1, lane);
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The same transfer issued from inline asm: hipcc models the builtin as a store to LDS and drains vmcnt in front of the NEXT LDS
+// read it can see — i.e. right behind the issue, which serialises the whole load latency into every tile.  From asm the compiler
+// does not know LDS is written; the caller owns the ordering (dma_wait_all + barrier before anyone reads the image).
+__device__ __forceinline__ void dma_piece_async(char* img, const h16_t* g, int64_t ld, int row0, int piece, int lane) {
+    const int row = 16 * piece + (lane >> 2);
+    const int ch = (lane & 3) ^ ((lane >> 4) & 3);
+    const h16_t* src = g + (int64_t)(row0 + row) * ld + ch * 8;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_vptr)(img + piece * 1024));
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "m0");
+}
+__device__ __forceinline__ void dma_tile_async(char* img, const h16_t* g, int64_t ld, int row0, int wave, int lane) {
+    dma_piece_async(img, g, ld, row0, 2 * wave, lane);
+    dma_piece_async(img, g, ld, row0, 2 * wave + 1, lane);
+}
 
 __device__ __forceinline__ void load_lane_block(uint4 (&out)[2], const h16_t* g, int64_t ld, int row, bool valid, int dh,
                                                 int h) {
@@ -1034,8 +1049,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_fast(Args p) {
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt) {         // the other buffer was last read in tile t-1, behind that tile's barrier
-            dma_tile(sK + (cur ^ 1) * IMG, K, p.ldk, (t + 1) * KT, wave, lane);
-            dma_tile(sV + (cur ^ 1) * IMG, V, p.ldv, (t + 1) * KT, wave, lane);
+            dma_tile_async(sK + (cur ^ 1) * IMG, K, p.ldk, (t + 1) * KT, wave, lane);   // (waited for at the tile boundary)
+            dma_tile_async(sV + (cur ^ 1) * IMG, V, p.ldv, (t + 1) * KT, wave, lane);
         }
         const char* kimg = sK + cur * IMG;
         const char* vimg = sV + cur * IMG;
@@ -1072,6 +1087,60 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_fast(Args p) {
     h16_t* Oo = reinterpret_cast<h16_t*>(p.out_o) + (int64_t)b * p.Lq * p.ldo + hh * p.dh;
     store_acc(O, Oo, p.ldo, qrow, qvalid, p.dh, h, inv);
     if (qvalid && h == 0) p.lse2[((int64_t)b * p.H + hh) * p.Lq + qrow] = m + __builtin_amdgcn_logf(lt);
+}
+
+// ---- pieces of the ROTATED dQ loop (round 3) ----------------------------------------------------------------------------------
+// The round-2 loop issued the eight score / dP products of a 32-key step back to back (256 cycles in which the wave issues nothing
+// else) and then ran each block's exp / multiply / convert chain, which waits on exactly those results: MFMA and VALU of ONE wave
+// never overlapped, and two co-resident waves met in the same phase as often as not (co-execution 17 %, 466 cycles per block against
+// an issue floor of ~270).  Here the two query blocks of a wave run half a step apart: while block c's softmax chain issues, the
+// products of the OTHER block (for this key step or the next) are in the matrix pipe — the VALU instructions only touch results
+// that finished a phase ago.  The interleave is pinned by hand: one MFMA, then ~48 issue cycles of exp / multiply, fenced with
+// sched_barrier(0) so that hipcc's scheduler keeps the order (it would re-cluster the MFMAs).
+__device__ __forceinline__ f32x16 mma_c_first(const uint4& a0, const uint4& b0, const f32x16& c0) {
+    f32x16 acc;   // D != C: the loop-invariant row constants are never copied (see mma_first_c)
+    asm("s_nop 1\n\tv_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %1, %2, %3"
+        : "=&v"(acc)
+        : "v"(__builtin_bit_cast(h16x8, a0)), "v"(__builtin_bit_cast(h16x8, b0)), "v"(c0));
+    return acc;
+}
+__device__ __forceinline__ f32x16 mma_acc(const uint4& a1, const uint4& b1, const f32x16& acc) {
+    return SVOL_MFMA_32x32x16_H16(__builtin_bit_cast(h16x8, a1), __builtin_bit_cast(h16x8, b1), acc, 0, 0, 0);
+}
+template <int LO>
+__device__ __forceinline__ void ds_chunk(f32x16& S, const f32x16& dP) {   // dS = exp2(score - lse) * (dP - delta), 4 elements
+#pragma unroll
+    for (int i = LO; i < LO + 4; ++i) S[i] = __builtin_amdgcn_exp2f(S[i]) * dP[i];
+}
+#define SVOL_FENCE() __builtin_amdgcn_sched_barrier(0)
+// start the two products of block n (A fragments ka / va of a key step) while block c finishes: chain, conversion, dQ_c += K^T dS_c
+__device__ __forceinline__ void dq_phase(f32x16& Sn, f32x16& dPn, const uint4 (&ka)[2], const uint4 (&va)[2], const uint4 (&qbn)[2],
+                                         const uint4 (&dobn)[2], const f32x16& Cln, const f32x16& Cdn, f32x16& Sc, const f32x16& dPc,
+                                         f32x16& dQc, const uint4 (&kt)[2]) {
+    Sn = mma_c_first(ka[0], qbn[0], Cln);
+    SVOL_FENCE();
+    ds_chunk<0>(Sc, dPc);
+    SVOL_FENCE();
+    Sn = mma_acc(ka[1], qbn[1], Sn);
+    SVOL_FENCE();
+    ds_chunk<4>(Sc, dPc);
+    SVOL_FENCE();
+    dPn = mma_c_first(va[0], dobn[0], Cdn);
+    SVOL_FENCE();
+    ds_chunk<8>(Sc, dPc);
+    SVOL_FENCE();
+    dPn = mma_acc(va[1], dobn[1], dPn);
+    SVOL_FENCE();
+    ds_chunk<12>(Sc, dPc);
+    SVOL_FENCE();
+    mma_second(dQc, kt, Sc);
+}
+__device__ __forceinline__ void dq_finish(f32x16& Sc, const f32x16& dPc, f32x16& dQc, const uint4 (&kt)[2]) {
+    ds_chunk<0>(Sc, dPc);
+    ds_chunk<4>(Sc, dPc);
+    ds_chunk<8>(Sc, dPc);
+    ds_chunk<12>(Sc, dPc);
+    mma_second(dQc, kt, Sc);
 }
 
 // Two 32-query blocks per wave (256 queries per workgroup): every K / V fragment read from LDS feeds two MFMAs, and
@@ -1197,6 +1266,109 @@ __device__ __forceinline__ void attn_bwd_dq_pre_body(const Args& p) {
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_pre(Args p) { attn_bwd_dq_pre_body<false>(p); }
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_pre_masked(Args p) { attn_bwd_dq_pre_body<true>(p); }
 
+// The unmasked dQ pass on the ROTATED schedule (dq_phase above).  Same tile geometry, row constants and delta prologue as
+// attn_bwd_dq_pre_body<false>; K / V tiles come by LDS-DMA (no staging registers: the rotation keeps four accumulator blocks, the
+// row constants and both blocks' operands live — 256 VGPRs is the budget at two waves per SIMD).  A workgroup with at most 128 rows
+// left runs the same loop with its second block empty (zero operands, -inf row constant: every term is an exact zero).
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_rot(Args p) {
+    __shared__ __attribute__((aligned(1024))) char smem[4 * IMG];
+    char* sK = smem;
+    char* sV = smem + 2 * IMG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int xt, hh, b;
+    block_coords(p, xt, hh, b);
+    const h16_t* Q = reinterpret_cast<const h16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
+    const h16_t* dO = reinterpret_cast<const h16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * p.dh;
+    const h16_t* O = reinterpret_cast<const h16_t*>(p.o) + (int64_t)b * p.Lq * p.ldo + hh * p.dh;
+    const h16_t* K = reinterpret_cast<const h16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
+    const h16_t* V = reinterpret_cast<const h16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
+    dma_tile(sK, K, p.ldk, 0, wave, lane);
+    dma_tile(sV, V, p.ldv, 0, wave, lane);
+
+    int qrow[2];
+    bool qvalid[2];
+    uint4 qb[2][2], dob[2][2];
+    f32x16 Cl[2], Cd[2], dQ[2];
+    const bool single = p.Lq - xt * 256 <= 128;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        qrow[u] = single ? (u == 0 ? xt * 256 + wave * 32 + r : p.Lq) : xt * 256 + wave * 64 + u * 32 + r;
+        qvalid[u] = qrow[u] < p.Lq;
+        load_lane_block(qb[u], Q, p.ldq, qrow[u], qvalid[u], p.dh, h);
+        load_lane_block(dob[u], dO, p.lddo, qrow[u], qvalid[u], p.dh, h);
+        const int64_t sidx = ((int64_t)b * p.H + hh) * p.Lq + qrow[u];
+        Cl[u] = splat16(qvalid[u] ? -p.lse2[sidx] : -INFINITY);
+        float dl = 0.f;
+        {
+            uint4 ob[2];
+            load_lane_block(ob, O, p.ldo, qrow[u], qvalid[u], p.dh, h);
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                const h16x8 a = __builtin_bit_cast(h16x8, ob[s_]), c = __builtin_bit_cast(h16x8, dob[u][s_]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dl += (float)a[e] * (float)c[e];
+            }
+            const HalfPair sw = swap_halves(__builtin_bit_cast(unsigned, dl));
+            dl = __builtin_bit_cast(float, sw.lo) + __builtin_bit_cast(float, sw.hi);
+        }
+        if (qvalid[u] && h == 0) {
+            p.delta[sidx] = dl;
+            if (p.nl2) {
+                p.nl2[sidx] = split_bf16x2(-p.lse2[sidx]);
+                p.nd2[sidx] = split_bf16x2(-dl);
+            }
+        }
+        Cd[u] = splat16(qvalid[u] ? -dl : 0.f);
+        dQ[u] = zero16();
+    }
+    const int nt = p.Lk / KT;
+    dma_wait_all();
+    __syncthreads();
+    f32x16 S0, S1, dP0, dP1;
+    uint4 ka[2], va[2];
+    read_rows(ka, sK, r, h);
+    read_rows(va, sV, r, h);
+    S0 = mma_first_c(ka, qb[0], Cl[0]);
+    dP0 = mma_first_c(va, dob[0], Cd[0]);
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        const bool more = t + 1 < nt;
+        if (more) {   // the other image is free: its last reads came before the previous boundary's barrier
+            dma_tile_async(sK + (cur ^ 1) * IMG, K, p.ldk, (t + 1) * KT, wave, lane);
+            dma_tile_async(sV + (cur ^ 1) * IMG, V, p.ldv, (t + 1) * KT, wave, lane);
+        }
+        const char* kimg = sK + cur * IMG;
+        const char* vimg = sV + cur * IMG;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            uint4 kt[2];
+            read_tr(kt, kimg, sub, lane);
+            // block 1's products of this key step start; block 0 (products issued a phase ago) finishes
+            dq_phase(S1, dP1, ka, va, qb[1], dob[1], Cl[1], Cd[1], S0, dP0, dQ[0], kt);
+            if (sub < 3) {
+                read_rows(ka, kimg, (sub + 1) * 32 + r, h);
+                read_rows(va, vimg, (sub + 1) * 32 + r, h);
+                dq_phase(S0, dP0, ka, va, qb[0], dob[0], Cl[0], Cd[0], S1, dP1, dQ[1], kt);
+            } else {
+                dma_wait_all();      // this wave's pieces of tile t + 1 have landed; the barrier publishes everyone's
+                __syncthreads();     // (kt of this step is already in registers)
+                if (more) {
+                    read_rows(ka, sK + (cur ^ 1) * IMG, r, h);
+                    read_rows(va, sV + (cur ^ 1) * IMG, r, h);
+                    dq_phase(S0, dP0, ka, va, qb[0], dob[0], Cl[0], Cd[0], S1, dP1, dQ[1], kt);
+                } else {
+                    dq_finish(S1, dP1, dQ[1], kt);
+                }
+            }
+        }
+    }
+    h16_t* dQo = reinterpret_cast<h16_t*>(p.dq) + (int64_t)b * p.Lq * p.lddq + hh * p.dh;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) store_acc(dQ[u], dQo, p.lddq, qrow[u], qvalid[u], p.dh, h, p.scale);
+}
+
 // In this kernel the per-QUERY constants (-lse, -delta) run along the 16 accumulator registers of a lane (rows of
 // the score tile are queries), so as initial accumulators they cost four ds_read_b128 per product — half of the
 // loop's LDS traffic, and LDS was the busiest unit (rocprofv3 PMC: ~70 % of its bandwidth).  They ride the matrix
@@ -1260,6 +1432,13 @@ __device__ __forceinline__ void attn_bwd_dkdv_pre_body(const Args& p) {
             __builtin_amdgcn_global_load_lds((gbl_vptr)src, (lds_vptr)dst, 16, 0, 0);
         }
     };
+    auto dma_stats_async = [&](int buf, int row0) {   // the same from inline asm (see dma_piece_async): no compiler-inserted drain
+        if (wave < 2) {
+            const unsigned* src = (wave == 0 ? nl_h : nd_h) + row0 + (lane & 31) * 4;
+            const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_vptr)((wave == 0 ? sL : sD) + buf * KT));
+            if (lane < 32) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "m0");
+        }
+    };
     if (DMA) {
         dma_tile(sQ, Q, p.ldq, 0, wave, lane);
         dma_tile(sdO, dO, p.lddo, 0, wave, lane);
@@ -1278,9 +1457,9 @@ __device__ __forceinline__ void attn_bwd_dkdv_pre_body(const Args& p) {
         const int cur = t & 1;
         if (t + 1 < nt) {
             if (DMA) {
-                dma_tile(sQ + (cur ^ 1) * IMG, Q, p.ldq, (t + 1) * KT, wave, lane);
-                dma_tile(sdO + (cur ^ 1) * IMG, dO, p.lddo, (t + 1) * KT, wave, lane);
-                dma_stats(cur ^ 1, (t + 1) * KT);
+                dma_tile_async(sQ + (cur ^ 1) * IMG, Q, p.ldq, (t + 1) * KT, wave, lane);   // (waited for at the tile boundary)
+                dma_tile_async(sdO + (cur ^ 1) * IMG, dO, p.lddo, (t + 1) * KT, wave, lane);
+                dma_stats_async(cur ^ 1, (t + 1) * KT);
             } else {
                 load_regs(sq, Q, p.ldq, (t + 1) * KT, p.Lq, p.dh, tid);
                 load_regs(sdo, dO, p.lddo, (t + 1) * KT, p.Lq, p.dh, tid);
@@ -1474,6 +1653,8 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
             hipLaunchKernelGGL(attn_bwd_dq_bf16_pre_masked, gq2, dim3(256), 0, s, pq);
             hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre_masked, gk2, dim3(256), 0, s, pk);
         } else {
+            static const bool no_dq_rot = getenv("SVOL_ATTN_NO_DQ_ROT") != nullptr;
+            pq.dq_rot = no_dq_rot ? 0 : 1;
             // delta is a 3 x [B,H,Lq] scratch: fp32 delta | -lse2 pairs | -delta pairs (the last two for the DMA dK/dV kernel)
             static const bool no_dma = getenv("SVOL_ATTN_NO_DKDV_DMA") != nullptr;
             const bool dma = !no_dma && dh == 32 && Lq % KT == 0;
@@ -1482,7 +1663,8 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
                 pq.nl2 = pk.nl2 = reinterpret_cast<unsigned*>(delta + n);
                 pq.nd2 = pk.nd2 = reinterpret_cast<unsigned*>(delta + 2 * n);
             }
-            hipLaunchKernelGGL(attn_bwd_dq_bf16_pre, gq2, dim3(256), 0, s, pq);
+            if (pq.dq_rot && dh == 32) hipLaunchKernelGGL(attn_bwd_dq_bf16_rot, gq2, dim3(256), 0, s, pq);
+            else hipLaunchKernelGGL(attn_bwd_dq_bf16_pre, gq2, dim3(256), 0, s, pq);
             if (dma) hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre_dma, gk2, dim3(256), 0, s, pk);
             else hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre, gk2, dim3(256), 0, s, pk);
         }
