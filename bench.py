@@ -32,6 +32,36 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 FWD_BWD_GF_PER_FRAME = 34.07    # BASELINE.md §3 (algorithmic, fwd + 2x bwd, no recompute credit)
 
 
+def _host_cores():
+    """(cores this job may really use, how that was found).  The affinity mask of a pool box spans the whole host (256 logical CPUs)
+    while the job's CPU share is a cgroup quota (16 for a one-GPU box): threads beyond the quota only time-slice each other
+    (measured: 264 s per oracle step with 256 threads, 6 s with 16)."""
+    n = os.cpu_count() or 1
+    how = 'os.cpu_count'
+    try:
+        n, how = len(os.sched_getaffinity(0)), 'affinity mask'
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:   # cgroup v2
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            quota = max(1, int(float(q) / float(per) + 0.5))
+    except (OSError, ValueError):
+        try:   # cgroup v1
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                quota = max(1, int(q / per + 0.5))
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        return quota, 'cgroup cpu quota'
+    if n > 32:   # no quota visible and a mask that spans a whole host: the pool's documented share of a one-GPU job
+        return 16, f'pool share (affinity mask spans {n} CPUs, no cgroup quota visible)'
+    return max(1, n), how
+
+
 def cpu_baseline(seconds_budget=30.0):
     """Reference CPU path timed beside the GPU number: the oracle (CPU restatement proven equal to the
     reference by the golden vectors) on a BOUNDED sample of the same workload — one of the 8 videos of
@@ -40,12 +70,7 @@ def cpu_baseline(seconds_budget=30.0):
     import torch
     from oracle import svol_oracle as O
     from svol_amd import synthetic as syn
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    cores = max(1, cores)   # every core of this job's affinity mask (a one-GPU box of the pool gives 16); stated in the result
+    cores, how = _host_cores()
     torch.set_num_threads(cores)
     args = syn.cfg2_args('video_matcher')
     B, T, P = 1, 32, 196
@@ -66,7 +91,7 @@ def cpu_baseline(seconds_budget=30.0):
         if time.time() - t_start > seconds_budget and times:
             break
     t = sorted(times)[len(times) // 2]
-    return {'value': B * T / t, 'unit': 'frames/sec', 'cores': cores, 'kind': 'port',
+    return {'value': B * T / t, 'unit': 'frames/sec', 'cores': cores, 'cores_from': how, 'kind': 'port',
             'sample': f'oracle (CPU restatement, fp32, torch {torch.__version__}) on 1 of the 8 videos of configs[1]: '
                       f'B=1,T=32,P=196,d=256,6 layers,N=100, fwd+matcher+bwd, median of {len(times)} steps '
                       f'({t * 1e3:.0f} ms/step)'}
@@ -321,7 +346,7 @@ def main():
                                key=lambda f_: int(re.search(r'round(\d+)_', os.path.basename(f_)).group(1)))
                 tj = json.load(open(files[-1]))
                 meta = tj.pop('_meta', {})
-                pick = (['attn_bwd_dq_bf16_pre|', 'attn_bwd_dkdv_bf16_pre|', 'attn_bwd_dkdv_bf16_pre_dma|', 'attn_delta_bf16|'] if bwd[1] >= fwd[1]
+                pick = (['attn_bwd_dq_bf16_pre|', 'attn_bwd_dq_bf16_rot|', 'attn_bwd_dkdv_bf16_pre|', 'attn_bwd_dkdv_bf16_pre_dma|', 'attn_delta_bf16|'] if bwd[1] >= fwd[1]
                         else ['attn_fwd_bf16_pre|', 'attn_fwd_bf16_fast|'])
                 tot = sum((v['read_MB'] + v['write_MB']) * 1048576.0 for k_, v in tj.items() if any(k_.startswith(q_) for q_ in pick))
                 if tot > 0:

@@ -533,6 +533,15 @@ __global__ __launch_bounds__(256) void set_loss_kernel(const float* __restrict__
         flagged |= (status && status[p] != 0) || (box_status && box_status[p] != 0);
     }
     flagged = __syncthreads_or(flagged);
+    if (flagged) {   // ... and its unit gradients too, so that backward() / optimizer.step() cannot proceed on a non-scipy matching
+        const float qn = __builtin_nanf("");
+        for (int r = threadIdx.x; r < rows; r += 256) {
+            const int64_t row = base + r;
+            g_label[row * 2] = g_label[row * 2 + 1] = qn;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { g_bbox[row * 4 + c] = qn; g_giou[row * 4 + c] = qn; }
+        }
+    }
     if (threadIdx.x == 0 && flagged) {
         const float qnan = __builtin_nanf("");
         losses[layer * 4 + 0] = losses[layer * 4 + 1] = losses[layer * 4 + 2] = losses[layer * 4 + 3] = qnan;

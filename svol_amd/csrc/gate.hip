@@ -599,6 +599,7 @@ int svol_gate_fwd(const float* x32, const void* pos, const float* u, const float
                   void* y, void* ypos, float* a, float* mean, float* rstd, float* ws, int64_t B, int64_t L, int64_t D, int64_t H,
                   int dtype, void* stream) {
     if (!x32 || !pos || !u || !gamma || !beta || (!y && !y32) || !a || !mean || !rstd || !ws) return SVOL_E_INVALID;
+    if (!aligned16(gamma) || !aligned16(beta)) return SVOL_E_INVALID;   // (16-byte vector loads of the affine parameters)
     if (B <= 0 || L <= 0 || D <= 0 || H <= 0) return SVOL_E_INVALID;
     if (D % 4 || D > GP * 256 || H > GH || B > 65535 || L > (1 << 24)) return SVOL_E_UNSUPPORTED;
     if (!svol_is16(dtype) && dtype != SVOL_F32) return SVOL_E_INVALID;

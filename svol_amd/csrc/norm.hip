@@ -259,6 +259,7 @@ int svol_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float
                        void* ypos, const void* pos, int64_t pos_rows, float* mean, float* rstd, int64_t M, int64_t D,
                        float dropout_p, uint64_t seed, const int64_t* seed_offset_dev, int dtype, void* stream) {
     if (!x || !gamma || !beta || (!y && !y32) || !mean || !rstd || M < 0 || D <= 0) return SVOL_E_INVALID;
+    if (!aligned16(gamma) || !aligned16(beta)) return SVOL_E_INVALID;   // (16-byte vector loads of the affine parameters)
     if ((ypos != nullptr) != (pos != nullptr)) return SVOL_E_INVALID;
     if (pos && pos_rows <= 0) return SVOL_E_INVALID;
     if (D % 4 || D > LN_MAX_PASSES * 256) return SVOL_E_UNSUPPORTED;

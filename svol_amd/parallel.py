@@ -258,6 +258,7 @@ class FlatAdamW(torch.optim.Optimizer):
                  params: Optional[Iterable[torch.nn.Parameter]] = None):
         owned = [p for b in reducer.buckets for p in b['params']]
         plist = list(params) if params is not None else owned
+        self._params_given = params is not None
         known = {id(p) for p in plist}
         missing = [p for p in owned if id(p) not in known]
         if missing:
@@ -336,6 +337,12 @@ class FlatAdamW(torch.optim.Optimizer):
                 st['m'].copy_(m)
                 st['v'].copy_(v)
             return
+        if not self._params_given:
+            # torch's schema maps state to parameters BY POSITION in the optimizer's list (train.py:72: named_parameters() order);
+            # this optimizer was built in bucket (arrival) order, so the moments of the many equal-shaped d x d weights would be
+            # silently permuted
+            raise ValueError('FlatAdamW.load_state_dict: build the optimizer with params=<the parameter list in the order the checkpoint '
+                             'was written with (the reference: every trainable parameter in named_parameters() order)>')
         groups = sd['param_groups']
         plist = self.param_groups[0]['params']
         ids = [i for g in groups for i in g['params']]

@@ -95,9 +95,15 @@ def test_error_conventions_of_the_reference_are_kept():
     # (1) a prediction box with negative width in layer 0 only -> AssertionError; layer 0's losses NaN, layer 1 untouched
     bad = bx.clone()
     bad[0, 1, 3, 2] = -0.1
-    ld = crit(_outputs(lg, bad), tg)
+    lgr, badr = lg.clone().requires_grad_(True), bad.clone().requires_grad_(True)
+    ld = crit(_outputs(lgr, badr), tg)
     assert all(not bool(torch.isfinite(ld[k + '_0'])) for k in ('loss_label', 'loss_bbox', 'loss_giou'))
     assert all(bool(torch.isfinite(ld[k])) for k in ('loss_label', 'loss_bbox', 'loss_giou'))
+    # ... and the flagged layer's GRADIENTS are NaN too: backward() / optimizer.step() cannot proceed on a matching scipy
+    # would have refused; the healthy layer's gradients stay finite
+    sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict).backward()
+    assert bool(torch.isnan(lgr.grad[0]).all()) and bool(torch.isnan(badr.grad[0]).all())
+    assert bool(torch.isfinite(lgr.grad[1]).all()) and bool(torch.isfinite(badr.grad[1]).all())
     with pytest.raises(AssertionError):
         crit.last_indices()
     with pytest.raises(AssertionError):
