@@ -1061,15 +1061,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_fast(Args p) {
             read_rows(ka, kimg, sub * 32 + r, h);
             S[sub] = mma_first_c(ka, qb, Cm);  // = score - anchor
         }
-        float ls[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x2 ls[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // row sums as v_pk_add_f32 over register pairs (32 instead of 64 adds)
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 16; i += 2) {
                 S[sub][i] = __builtin_amdgcn_exp2f(S[sub][i]);
-                ls[sub] += S[sub][i];
+                S[sub][i + 1] = __builtin_amdgcn_exp2f(S[sub][i + 1]);
+                ls[sub] += f32x2{S[sub][i], S[sub][i + 1]};
             }
-        l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
+        {
+            const f32x2 t2 = (ls[0] + ls[1]) + (ls[2] + ls[3]);
+            l += t2[0] + t2[1];
+        }
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
             uint4 va[2];
@@ -1109,8 +1113,16 @@ __device__ __forceinline__ f32x16 mma_acc(const uint4& a1, const uint4& b1, cons
 }
 template <int LO>
 __device__ __forceinline__ void ds_chunk(f32x16& S, const f32x16& dP) {   // dS = exp2(score - lse) * (dP - delta), 4 elements
+    // the products as two v_pk_mul_f32 on adjacent accumulator registers (plain VALU does not co-issue with the matrix pipe — only
+    // v_exp does, profiles/round2_pmc_attention.md — so every vector instruction saved is 4 issue cycles per block)
 #pragma unroll
-    for (int i = LO; i < LO + 4; ++i) S[i] = __builtin_amdgcn_exp2f(S[i]) * dP[i];
+    for (int i = LO; i < LO + 4; i += 2) {
+        const f32x2 e = {__builtin_amdgcn_exp2f(S[i]), __builtin_amdgcn_exp2f(S[i + 1])};
+        const f32x2 d = {dP[i], dP[i + 1]};
+        const f32x2 m = e * d;
+        S[i] = m[0];
+        S[i + 1] = m[1];
+    }
 }
 #define SVOL_FENCE() __builtin_amdgcn_sched_barrier(0)
 // start the two products of block n (A fragments ka / va of a key step) while block c finishes: chain, conversion, dQ_c += K^T dS_c
@@ -1500,7 +1512,11 @@ __device__ __forceinline__ void attn_bwd_dkdv_pre_body(const Args& p) {
             read_tr(a, doimg, sub, lane);
             mma_second(dV, a, S);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) S[i] *= dP[i];
+            for (int i = 0; i < 16; i += 2) {   // v_pk_mul_f32 on adjacent accumulator registers (8 instead of 16 vector instructions)
+                const f32x2 m = f32x2{S[i], S[i + 1]} * f32x2{dP[i], dP[i + 1]};
+                S[i] = m[0];
+                S[i + 1] = m[1];
+            }
             read_tr(a, qimg, sub, lane);
             mma_second(dK, a, S);
             if (sub + 1 < 4) { S = Sn; dP = dPn; }
