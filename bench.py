@@ -107,6 +107,8 @@ def main():
                     help='static loss scale (default: 1024 with --dtype fp16 — fp16 gradients of ~1e-6 underflow otherwise; the reference '
                          'uses apex amp dynamic scaling for fp16 — else 1); folded back out inside the AdamW kernel')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--max-inflight', type=int, default=2,
+                    help='steps the host may run ahead of the GPU (svol_amd.parallel.StepFence; 0 = unbounded)')
     ap.add_argument('--graph', action='store_true',
                     help='N=1 only: replay the whole step as one captured hipGraph (removes the ~15 ms/step of host issue time, '
                          'but a captured graph serialises the query-stream / video-stream overlap: measured slower)')
@@ -234,6 +236,8 @@ def main():
     if not use_graph:
         opt.loss_scale = loss_scale
 
+    fence = parallel.StepFence(a.max_inflight) if a.max_inflight > 0 else None
+
     def step():
         reducer.zero_grad()
         if backbone is not None:
@@ -257,6 +261,14 @@ def main():
         def step():  # noqa: F811
             return gstep(inp, tg)[0]
 
+    raw_step = step
+
+    def step():  # noqa: F811
+        out_ = raw_step()
+        if fence is not None:
+            fence.tick()
+        return out_
+
     for _ in range(a.warmup):
         loss = step()
     if not use_graph:
@@ -266,10 +278,19 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     host_ms = []
+    trace = os.environ.get('SVOL_BENCH_TRACE') == '1'   # dev aid: stack of any step whose host side takes > 60 ms
+    if trace:
+        import faulthandler
     for _ in range(a.steps):
         ts = time.perf_counter()
+        if trace:
+            faulthandler.dump_traceback_later(0.06, repeat=False)
         loss = step()
+        if trace:
+            faulthandler.cancel_dump_traceback_later()
         host_ms.append((time.perf_counter() - ts) * 1e3)
+    if trace:
+        print('host_ms per step:', [round(x, 1) for x in host_ms], file=sys.stderr)
     t_issued = time.perf_counter() - t0   # the host has ISSUED every step; the GPU is still running them
     torch.cuda.synchronize()
     if world > 1:
@@ -282,7 +303,7 @@ def main():
     free_ms = []
     for _ in range(3):
         ts = time.perf_counter()
-        step()
+        raw_step()   # (unfenced: this measures issue time alone)
         free_ms.append((time.perf_counter() - ts) * 1e3)
     torch.cuda.synchronize()
     if use_graph:

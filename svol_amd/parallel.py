@@ -385,6 +385,32 @@ class FlatAdamW(torch.optim.Optimizer):
             grp['betas'] = (float(g0['betas'][0]), float(g0['betas'][1]))
 
 
+class StepFence:
+    """Bounds how far the host may run ahead of the GPU: ``tick()`` at the end of a training step records an event and waits (spinning,
+    no interrupt) for the step ``max_inflight`` steps back.  With the block programs a step takes ~6 ms of host time against ~20 ms
+    on the GPU, so an unfenced loop queues a dozen steps (>5000 packets over three streams) within a few iterations; at that depth
+    the HIP runtime's own back-pressure (kernel-argument pool / signal recycling) takes over, and that wait was measured to stall
+    host AND GPU for 0.1 - 1.7 s at a time (profiles/round3_summary.md, "host run-ahead").  Two steps in flight keep the queue full
+    without ever reaching it.  The reference's loop is fenced the same way by its per-step ``loss.item()`` logging
+    (lib/engine/train.py:233-240)."""
+
+    def __init__(self, max_inflight: int = 2):
+        from collections import deque
+        self.max_inflight = max(1, int(max_inflight))
+        self._q = deque()
+
+    def tick(self) -> None:
+        ev = torch.cuda.Event()
+        ev.record()
+        self._q.append(ev)
+        while len(self._q) > self.max_inflight:
+            self._q.popleft().synchronize()
+
+    def drain(self) -> None:
+        while self._q:
+            self._q.popleft().synchronize()
+
+
 def unused_parameters(model: torch.nn.Module):
     """Parameters that never receive a gradient (reference: grad None): the SVANet gate MHA's out_proj
     (only its attention WEIGHTS are used), the unused ``class_head``, and — svanet_variants — the input projections of

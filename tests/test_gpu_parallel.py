@@ -189,3 +189,26 @@ def test_bench_world4_gloo_rehearsal_reports_per_rank_issue_time():
     assert res['host_cores_per_rank'] >= 1
     print('world-4 gloo rehearsal: ms/step', res['ms_per_step'], 'issue per rank', res['host_issue_ms_per_rank'],
           'cores per rank', res['host_cores_per_rank'])
+
+
+@pytest.mark.gpu
+def test_step_fence_bounds_the_host_run_ahead():
+    """parallel.StepFence: after tick() at most ``max_inflight`` steps are unfinished on the device (profiles/round3_summary.md, "host
+    run-ahead": the unfenced loop stalled 1 s in hipMalloc).  A spin kernel of ~20 ms per step stands in for the training step."""
+    import time
+    from svol_amd import parallel
+    x = torch.randn(8192, 8192, device='cuda')
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); (x @ x); torch.cuda.synchronize(); one = time.perf_counter() - t0
+    fence = parallel.StepFence(2)
+    evs = []
+    for i in range(8):
+        for _ in range(3):
+            x @ x
+        e = torch.cuda.Event(); e.record(); evs.append(e)
+        fence.tick()
+        # everything older than the two newest steps has finished when tick() returns
+        assert all(ev.query() for ev in evs[:-2]), i
+    assert len(fence._q) == 2
+    fence.drain()
+    assert not fence._q and all(ev.query() for ev in evs) and one > 0
