@@ -721,15 +721,22 @@ __device__ __forceinline__ void block_coords(const Args& p, int& xt, int& hh, in
     if (p.head_xcd) {
         const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
         int hl;
+        const int two = p.head_xcd == 2 ? 2 : 1;   // 2: the heads of a pair alternate tile by tile (see below)
         if (p.tail_last) {  // the short last tiles (dQ pass: half a workgroup of rows) fill the launch's last, partial round
             const int nfull = p.nxt - 1, hpx = (p.B * p.H) >> 3;
-            if (slot < hpx * nfull) { hl = slot / nfull; xt = slot - hl * nfull; }
-            else { hl = slot - hpx * nfull; xt = nfull; }
+            if (slot < hpx * nfull) {
+                const int g = slot / (two * nfull), r = slot - g * two * nfull;
+                hl = g * two + (two == 2 ? (r & 1) : 0);
+                xt = two == 2 ? (r >> 1) : r;
+            } else { hl = slot - hpx * nfull; xt = nfull; }
         } else {
-            hl = slot / p.nxt;
-            xt = slot - hl * p.nxt;
+            const int g = slot / (two * p.nxt), r = slot - g * two * p.nxt;
+            hl = g * two + (two == 2 ? (r & 1) : 0);
+            xt = two == 2 ? (r >> 1) : r;
         }
-        const int head = hl * 8 + xcd;
+        // head_xcd == 2: the two heads that share every 128-byte line of the [.., H, 32]-interleaved operands (64 bytes each) are
+        // walked by the SAME XCD, the same x tile of both in consecutive workgroups: a line is fetched once, into one L2
+        const int head = p.head_xcd == 2 ? (((hl >> 1) * 8 + xcd) * 2 + (hl & 1)) : hl * 8 + xcd;
         hh = head % p.H;
         b = head / p.H;
     } else {
@@ -1600,8 +1607,9 @@ int svol_attn_fwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
     else bind_ws(p, ws);
     dim3 grid((unsigned)(((Lq + 127) / 128) * p.ksplit), (unsigned)H, (unsigned)B);
     static const bool no_head_xcd = getenv("SVOL_ATTN_NO_HEAD_XCD") != nullptr;
+    static const bool head_pair = getenv("SVOL_ATTN_NO_HEAD_PAIR") == nullptr;
     if (pre && !no_head_xcd && (B * H) % 8 == 0) {  // heads dealt to the XCDs (block_coords)
-        p.head_xcd = 1;
+        p.head_xcd = (head_pair && (B * H) % 16 == 0 && H % 2 == 0 && dh == 32) ? 2 : 1;
         p.nxt = (Lq + 127) / 128;
         grid = dim3((unsigned)(B * H * p.nxt));
     }
@@ -1656,7 +1664,8 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
         dim3 gq2((unsigned)((Lq + 255) / 256), (unsigned)H, (unsigned)B);
         dim3 gk2 = gk;
         if (!no_head_xcd && (B * H) % 8 == 0) {  // heads dealt to the XCDs (block_coords)
-            pq.head_xcd = pk.head_xcd = 1;
+            static const bool head_pair = getenv("SVOL_ATTN_NO_HEAD_PAIR") == nullptr;
+            pq.head_xcd = pk.head_xcd = (head_pair && (B * H) % 16 == 0 && H % 2 == 0 && dh == 32) ? 2 : 1;
             pq.nxt = (Lq + 255) / 256;
             pk.nxt = (Lk + 127) / 128;
             pq.tail_last = (Lq % 256 >= 1 && Lq % 256 <= 128 && pq.nxt > 1) ? 1 : 0;

@@ -196,6 +196,7 @@ def test_step_fence_bounds_the_host_run_ahead():
     """parallel.StepFence: after tick() at most ``max_inflight`` steps are unfinished on the device (profiles/round3_summary.md, "host
     run-ahead": the unfenced loop stalled 1 s in hipMalloc).  A spin kernel of ~20 ms per step stands in for the training step."""
     import time
+    import torch
     from svol_amd import parallel
     x = torch.randn(8192, 8192, device='cuda')
     torch.cuda.synchronize()
