@@ -374,6 +374,10 @@ int svol_attn_small_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, 
 #define SVOL_BLK_QUERY_CROSS 2
 /* comma-separated slot names of a block, in index order (the host builds its name -> index map from this) */
 const char* svol_block_slot_names(int block);
+/* Measurement aid.  With SVOL_BLOCK_TRACE=1 in the environment every block program records a HIP event behind each entry point it
+ * calls; this synchronises the device, writes "program | call site  calls  avg_us  total_ms" lines for everything recorded since the
+ * last dump into buf (NUL-terminated, truncated to cap) and forgets them.  Without the variable: writes "" and returns. */
+int svol_block_trace_dump(char* buf, int64_t cap);
 
 /* video half (:122-143): gate -> LN1 ; q|k, v projections, self-attention, out-proj + residual -> LN2 ; fc1+GELU, fc2 + residual
  * -> LN3 (+pos).  M = B*L rows.

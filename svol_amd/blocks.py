@@ -436,7 +436,7 @@ class VideoHalfFn(torch.autograd.Function):
         _lib.check(L_.svol_video_half_bwd(dims, tbl.arr, 1, s), 'svol_video_half_bwd')
         if ctx.big:
             ops._BIG_ATTN['left'] -= 1
-            ops.flush_wgrad()   # queued weight-gradient GEMMs run beside the attention backward (issue-bound; they are HBM / atomic bound)
+            ops.flush_wgrad(gate=True)   # queued weight-gradient GEMMs run beside the attention backward (issue-bound; they are HBM / atomic bound)
         ev = _maybe_events('attn_bwd', (B, H, L, L, D // H))
         if ev:
             tbl.set('EV_A0', ev[0].cuda_event)
@@ -674,3 +674,10 @@ def query_cross(layer, out, mv, mpos, kbias, qpos, dt, qdt):
     pl = plan(layer, QC, dt, qdt)
     o32, o, opos = out
     return QueryCrossFn.apply(pl, o32, o, opos, mv, mpos, kbias, qpos, *pl.inputs(o32, opos, mv, mpos))
+
+
+def trace_dump() -> str:
+    """In-step durations per call site of the block programs (``SVOL_BLOCK_TRACE=1``; include/svol_hip.h svol_block_trace_dump)."""
+    buf = ctypes.create_string_buffer(1 << 20)
+    _lib.check(_lib.lib().svol_block_trace_dump(buf, len(buf)), 'svol_block_trace_dump')
+    return buf.value.decode()

@@ -6,10 +6,48 @@
 // what moves into C is the sequencing and the pointer arithmetic on caller-owned buffers (slot tables), ~4 us per launch instead of
 // ~30.  No allocation, no synchronisation, no global state: every function is a straight line of launches.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
 
 #include "common.h"
 
 namespace {
+
+// ---- SVOL_BLOCK_TRACE=1: in-step duration of every launch group of a block program, WITHOUT a profiler attached (rocprofv3 makes
+// the host the bottleneck of this step, which moves the streams against each other).  An event after every entry point a program
+// calls; svol_block_trace_dump() turns consecutive pairs into per-call-site sums.  Off (the default): one predictable branch per call.
+const bool kTrace = getenv("SVOL_BLOCK_TRACE") != nullptr;
+struct TraceRec { const char* prog; const char* site; hipEvent_t e0, e1; };
+std::mutex g_trace_mu;
+std::vector<TraceRec> g_trace_log;
+struct Trace {
+    const char* prog;
+    hipStream_t s;
+    hipEvent_t last = nullptr;
+    Trace* prev;
+    static thread_local Trace* cur;
+    Trace(const char* prog_, void* s_) : prog(prog_), s(static_cast<hipStream_t>(s_)), prev(cur) {
+        cur = this;
+        if (kTrace && hipEventCreate(&last) == hipSuccess) (void)hipEventRecord(last, s);
+    }
+    ~Trace() { cur = prev; }
+    void mark(const char* site) {
+        if (!kTrace || !last) return;
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        (void)hipEventRecord(e, s);
+        std::lock_guard<std::mutex> lk(g_trace_mu);
+        g_trace_log.push_back({prog, site, last, e});
+        last = e;
+    }
+};
+thread_local Trace* Trace::cur = nullptr;
 
 struct Dims {
     int64_t B, L, N, D, H, F, ws_bytes;
@@ -45,10 +83,11 @@ inline int nt_res(const void* A, int64_t lda, const void* W, int64_t ldw, void* 
                         1, M, N, K, dtype, s);
 }
 
-#define RUN(expr)                \
-    do {                         \
-        const int rc_ = (expr);  \
-        if (rc_) return rc_;     \
+#define RUN(expr)                                 \
+    do {                                          \
+        const int rc_ = (expr);                   \
+        if (rc_) return rc_;                      \
+        if (kTrace && Trace::cur) Trace::cur->mark(#expr); \
     } while (0)
 
 #define SLOT_NAME(n) #n ","
@@ -64,6 +103,63 @@ inline void record(void* ev, void* stream) {
 
 extern "C" {
 
+int svol_block_trace_dump(char* buf, int64_t cap) {
+    if (!buf || cap <= 0) return SVOL_E_INVALID;
+    buf[0] = 0;
+    if (!kTrace) return SVOL_OK;
+    if (hipDeviceSynchronize() != hipSuccess) return SVOL_E_LAUNCH;
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    static const bool timeline = getenv("SVOL_BLOCK_TRACE") && atoi(getenv("SVOL_BLOCK_TRACE")) == 2;
+    if (timeline && !g_trace_log.empty()) {   // every record with its start / end relative to the first one (all streams, one clock)
+        std::string out;
+        char line[256];
+        const hipEvent_t ref = g_trace_log.front().e0;
+        for (const TraceRec& r : g_trace_log) {
+            float t0 = 0.f, t1 = 0.f;
+            if (hipEventElapsedTime(&t0, ref, r.e0) != hipSuccess || hipEventElapsedTime(&t1, ref, r.e1) != hipSuccess) continue;
+            std::string site(r.site);
+            const size_t c = site.find(',');
+            if (c != std::string::npos) site.resize(c);
+            snprintf(line, sizeof line, "%9.3f %9.3f  %-20s %s\n", t0, t1, r.prog, site.c_str());
+            out += line;
+        }
+        std::map<hipEvent_t, int> seen_;
+        for (const TraceRec& r : g_trace_log) { seen_[r.e0] = 1; seen_[r.e1] = 1; }
+        for (auto& kv : seen_) (void)hipEventDestroy(kv.first);
+        g_trace_log.clear();
+        strncpy(buf, out.c_str(), (size_t)cap - 1);
+        buf[cap - 1] = 0;
+        return SVOL_OK;
+    }
+    std::map<std::string, std::pair<double, int>> acc;
+    std::vector<std::string> order;
+    std::map<hipEvent_t, int> seen;
+    for (const TraceRec& r : g_trace_log) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+        std::string site(r.site);
+        const size_t c = site.find(',');
+        if (c != std::string::npos) site.resize(c);
+        const std::string key = std::string(r.prog) + " | " + site;
+        if (!acc.count(key)) order.push_back(key);
+        acc[key].first += ms;
+        acc[key].second += 1;
+    }
+    for (const TraceRec& r : g_trace_log) { seen[r.e0] = 1; seen[r.e1] = 1; }
+    for (auto& kv : seen) (void)hipEventDestroy(kv.first);
+    g_trace_log.clear();
+    std::string out;
+    char line[256];
+    for (const std::string& k : order) {
+        snprintf(line, sizeof line, "%-110s calls %6d  avg_us %9.1f  total_ms %9.3f\n", k.c_str(), acc[k].second,
+                 acc[k].first / acc[k].second * 1e3, acc[k].first);
+        out += line;
+    }
+    strncpy(buf, out.c_str(), (size_t)cap - 1);
+    buf[cap - 1] = 0;
+    return SVOL_OK;
+}
+
 const char* svol_block_slot_names(int block) {
     switch (block) {
         case SVOL_BLK_VIDEO_HALF: return kVhNames;
@@ -78,6 +174,7 @@ const char* svol_block_slot_names(int block) {
 // ---------------------------------------------------------------------------------------------------------------------
 int svol_video_half_fwd(const int64_t* dims, void* const* p, void* s) {
     if (!dims || !p) return SVOL_E_INVALID;
+    Trace tr_("video_half_fwd", s);
     const Dims d(dims);
     if (!d.ok() || d.L <= 0 || d.F <= 0) return SVOL_E_INVALID;
     const int64_t M = d.B * d.L, D = d.D, F = d.F, dh = D / d.H;
@@ -111,6 +208,7 @@ int svol_video_half_fwd(const int64_t* dims, void* const* p, void* s) {
 
 int svol_video_half_bwd(const int64_t* dims, void* const* p, int phase, void* s) {
     if (!dims || !p || phase < 0 || phase > 2) return SVOL_E_INVALID;
+    Trace tr_(phase == 2 ? "video_half_bwd.2" : "video_half_bwd.1", s);
     const Dims d(dims);
     if (!d.ok() || d.L <= 0 || d.F <= 0) return SVOL_E_INVALID;
     const int64_t M = d.B * d.L, D = d.D, F = d.F, dh = D / d.H;
@@ -144,6 +242,7 @@ int svol_video_half_bwd(const int64_t* dims, void* const* p, int phase, void* s)
 
 int svol_video_half_wgrad(const int64_t* dims, void* const* p, void* s) {
     if (!dims || !p) return SVOL_E_INVALID;
+    Trace tr_("video_half_wgrad", s);
     const Dims d(dims);
     if (!d.ok()) return SVOL_E_INVALID;
     const int64_t M = d.B * d.L, D = d.D, F = d.F;
@@ -155,7 +254,8 @@ int svol_video_half_wgrad(const int64_t* dims, void* const* p, void* s) {
         {P(G2D), D, P(O), D, f32(P(DW_O)), D, nullptr, M, D, D},
         {P(DQKV), 3 * D, P(Y1POS), D, f32(P(DW_IN)), D, f32(P(DB_IN)), M, 2 * D, D},
         {at(P(DQKV), 2 * D, dt), 3 * D, P(Y1), D, f32(P(DW_IN)) + 2 * D * D, D, f32(P(DB_IN)) + 2 * D, M, D, D}};
-    return svol_gemm_tn_grouped(pr, 5, dt, s);
+    RUN(svol_gemm_tn_grouped(pr, 5, dt, s));
+    return SVOL_OK;
 #undef P
 }
 
@@ -164,6 +264,7 @@ int svol_video_half_wgrad(const int64_t* dims, void* const* p, void* s) {
 // ---------------------------------------------------------------------------------------------------------------------
 int svol_query_self_fwd(const int64_t* dims, void* const* p, void* s) {
     if (!dims || !p) return SVOL_E_INVALID;
+    Trace tr_("query_self_fwd", s);
     const Dims d(dims);
     if (!d.ok() || d.N <= 0) return SVOL_E_INVALID;
     const int64_t R = d.B * d.N, D = d.D, dh = D / d.H;
@@ -184,6 +285,7 @@ int svol_query_self_fwd(const int64_t* dims, void* const* p, void* s) {
 
 int svol_query_self_bwd(const int64_t* dims, void* const* p, void* s) {
     if (!dims || !p) return SVOL_E_INVALID;
+    Trace tr_("query_self_bwd", s);
     const Dims d(dims);
     if (!d.ok() || d.N <= 0) return SVOL_E_INVALID;
     const int64_t R = d.B * d.N, D = d.D, dh = D / d.H;
@@ -203,6 +305,7 @@ int svol_query_self_bwd(const int64_t* dims, void* const* p, void* s) {
 
 int svol_query_self_wgrad(const int64_t* dims, void* const* p, void* s) {
     if (!dims || !p) return SVOL_E_INVALID;
+    Trace tr_("query_self_wgrad", s);
     const Dims d(dims);
     if (!d.ok()) return SVOL_E_INVALID;
     const int64_t R = d.B * d.N, D = d.D;
@@ -211,7 +314,8 @@ int svol_query_self_wgrad(const int64_t* dims, void* const* p, void* s) {
         {P(G), D, P(OA), D, f32(P(DW_O)), D, nullptr, R, D, D},
         {P(DQKV), 3 * D, P(OPOS), D, f32(P(DW_IN)), D, f32(P(DB_IN)), R, 2 * D, D},
         {at(P(DQKV), 2 * D, qdt), 3 * D, P(O), D, f32(P(DW_IN)) + 2 * D * D, D, f32(P(DB_IN)) + 2 * D, R, D, D}};
-    return svol_gemm_tn_grouped(pr, 3, qdt, s);
+    RUN(svol_gemm_tn_grouped(pr, 3, qdt, s));
+    return SVOL_OK;
 #undef P
 }
 
@@ -220,6 +324,7 @@ int svol_query_self_wgrad(const int64_t* dims, void* const* p, void* s) {
 // ---------------------------------------------------------------------------------------------------------------------
 int svol_query_cross_fwd(const int64_t* dims, void* const* p, void* s) {
     if (!dims || !p) return SVOL_E_INVALID;
+    Trace tr_("query_cross_fwd", s);
     const Dims d(dims);
     if (!d.ok() || d.N <= 0 || d.L <= 0 || d.F <= 0) return SVOL_E_INVALID;
     const int64_t R = d.B * d.N, M = d.B * d.L, D = d.D, F = d.F, dh = D / d.H;
@@ -257,6 +362,7 @@ int svol_query_cross_fwd(const int64_t* dims, void* const* p, void* s) {
 
 int svol_query_cross_bwd(const int64_t* dims, void* const* p, void* s) {
     if (!dims || !p) return SVOL_E_INVALID;
+    Trace tr_("query_cross_bwd", s);
     const Dims d(dims);
     if (!d.ok() || d.N <= 0 || d.L <= 0 || d.F <= 0) return SVOL_E_INVALID;
     const int64_t R = d.B * d.N, M = d.B * d.L, D = d.D, F = d.F, dh = D / d.H;
@@ -294,6 +400,7 @@ int svol_query_cross_bwd(const int64_t* dims, void* const* p, void* s) {
 
 int svol_query_cross_wgrad(const int64_t* dims, void* const* p, void* s) {
     if (!dims || !p) return SVOL_E_INVALID;
+    Trace tr_("query_cross_wgrad", s);
     const Dims d(dims);
     if (!d.ok()) return SVOL_E_INVALID;
     const int64_t R = d.B * d.N, M = d.B * d.L, D = d.D, F = d.F;
@@ -309,7 +416,8 @@ int svol_query_cross_wgrad(const int64_t* dims, void* const* p, void* s) {
         {P(DPRE), F, P(Y5), D, f32(P(DW_FC1)), D, nullptr, R, F, D},
         {P(G5D), D, mixed ? P(OAQ) : P(OA), D, f32(P(DW_O)), D, nullptr, R, D, D},
         {mixed ? P(DQ) : P(DQC), D, P(OPOS), D, f32(P(DW_IN)), D, f32(P(DB_IN)), R, D, D}};
-    return svol_gemm_tn_grouped(pq, 4, qdt, s);
+    RUN(svol_gemm_tn_grouped(pq, 4, qdt, s));
+    return SVOL_OK;
 #undef P
 }
 

@@ -236,13 +236,25 @@ def _wgrad_stream(dev):
     return ws
 
 
-def flush_wgrad():
+WGRAD_GATE = os.environ.get('SVOL_NO_WGRAD_GATE') is None
+
+
+def flush_wgrad(gate=False):
     """issue every queued weight-gradient launch (callables that put it on the weight-gradient stream behind the event recorded when
-    it was queued)."""
+    it was queued).  ``gate=True`` (the caller is about to launch a large attention backward on the current stream): the
+    weight-gradient stream additionally waits for THIS point of the current stream.  Deferring the launches on the host alone orders
+    nothing on the device once the host runs ahead of it (block programs: a step is issued in ~6 ms): the queued GEMMs then start the
+    moment their operands exist, i.e. beside the next layer's LayerNorm / dgelu kernels, which are HBM-bound like they are
+    (tools/block_trace.py timeline: LN3' 182 us against 47 alone), instead of beside the issue-bound attention backward."""
     if not _WGRAD_PENDING:
         return
     items = list(_WGRAD_PENDING)
     _WGRAD_PENDING.clear()
+    if gate and WGRAD_GATE and not torch.cuda.is_current_stream_capturing():
+        cur = _current_stream_obj()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        _wgrad_stream(cur.device).wait_event(ev)
     for it in items:
         it()
 
@@ -445,7 +457,7 @@ def attn_bwd(q, k, v, o, do, lse2, B, H, Lq, Lk, dh, dq, dk, dv, kbias=None, pre
     do = do if do.stride(1) == 1 else do.contiguous()
     if B * H * Lq * Lk >= _WGRAD_FLUSH_MIN_SCORES:
         _BIG_ATTN['left'] -= 1
-        flush_wgrad()   # the queued weight-gradient GEMMs run beside this launch (flushing behind it instead: same step time)
+        flush_wgrad(gate=True)   # the queued weight-gradient GEMMs run beside this launch
     delta = torch.empty((3, B, H, Lq), dtype=torch.float32, device=q.device)  # delta | -lse2 pairs | -delta pairs (svol_hip.h)
     ws = _attn_ws(q, B, H, Lq, Lk, dh, kbias is not None or Lk % 128 != 0)
     tok = timer.start('attn_bwd', (B, H, Lq, Lk, dh))

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""In-step duration of every launch group of the block programs at the bench workload, no profiler attached:
+    SVOL_BLOCK_TRACE=1 python tools/block_trace.py [steps]
+(svol_block_trace_dump, include/svol_hip.h).  The events cost ~2 us each on the stream; the step runs ~1 % slower with them."""
+import os
+import sys
+import time
+
+os.environ.setdefault('SVOL_BLOCK_TRACE', '1')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from svol_amd import blocks, parallel  # noqa: E402
+from svol_amd import synthetic as syn  # noqa: E402
+from svol_amd.modeling.loss import build_loss  # noqa: E402
+from svol_amd.modeling.svanet import build_svanet  # noqa: E402
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    dev = torch.device('cuda', 0)
+    args = syn.cfg2_args('video_matcher')
+    args.compute_dtype = os.environ.get('SVOL_TRACE_DTYPE', 'bf16')
+    B, T, P = 8, 32, 196
+    torch.manual_seed(1)
+    model = build_svanet(args).to(dev).train()
+    crit = build_loss(args).to(dev).train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    reducer = parallel.BucketedGradAllReduce(parallel.arrival_order(model), skip=parallel.unused_parameters(model), ordered=True)
+    opt = parallel.FlatAdamW(reducer, lr=1e-4, weight_decay=1e-4, params=params)
+    inp = {k: v.to(dev) for k, v in syn.synth_inputs(args, B, T, P, seed=1).items()}
+    tg = syn.synth_targets(B, T, seed=1)
+    fence = parallel.StepFence(2)
+
+    def step():
+        reducer.zero_grad()
+        crit.prepack(tg, args.num_layers, B, args.num_queries, dev)
+        out = model(inp['src_sketch'], inp['src_sketch_mask'], inp['src_video'], inp['src_video_mask'])
+        crit(out, tg)
+        crit.weighted_total().backward()
+        reducer.finish(mean=False)
+        opt.step()
+        fence.tick()
+
+    for _ in range(4):
+        step()
+    blocks.trace_dump()   # forget the warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    txt = blocks.trace_dump()
+    if os.environ['SVOL_BLOCK_TRACE'] == '2':   # timeline of the traced steps: start / end (ms) of every call site, all streams
+        print(f'# {steps} steps, {ms:.2f} ms/step; start end (ms from the first record) program call-site')
+        print(txt)
+        return
+    tot = 0.0
+    print(f'# {steps} steps, {ms:.2f} ms/step with the trace events; per step:')
+    for line in txt.splitlines():
+        head, rest = line.rsplit('calls', 1)
+        f = rest.split()
+        calls, avg, total = int(f[0]), float(f[2]), float(f[4])
+        tot += total / steps
+        print(f'{head.strip():100s} x{calls / steps:5.1f}  avg {avg:8.1f} us   {total / steps:7.3f} ms/step')
+    print(f'# sum over the traced call sites (all streams): {tot:.2f} ms/step')
+
+
+if __name__ == '__main__':
+    main()
