@@ -43,6 +43,10 @@ extern "C" {
 #define SVOL_ACT_RELU 1
 #define SVOL_ACT_GELU 2    /* exact erf GELU: cross_modal_transformer.py:189-190 */
 #define SVOL_ACT_SIGMOID 3 /* svanet.py:127 */
+#define SVOL_ACT_GELU_D 5  /* GELU whose saved tensor is the DERIVATIVE: svol_gemm_nt writes gelu'(pre-activation) into `pre`
+                            * instead of the pre-activation (same Phi / exp as the activation itself: two more VALU ops), and
+                            * svol_gemm_nt_dact / svol_act_bwd multiply by `aux` as it is — the MLP backward's epilogue loses its
+                            * erf + exp per element (the K = 256 kernels are VALU-issue bound: profiles/round2_ws_gemm_lab.md) */
 #define SVOL_ACT_RELU_RES 4 /* relu(A*B^T + bias + residual): the ReLU AFTER the identity add of a ResNet BasicBlock (svol_gemm_nt only) */
 
 int svol_abi_version(void);
@@ -102,8 +106,8 @@ int svol_gemm_nt_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, v
                        const void* pre, int64_t ldp, float* colsum, int64_t M, int64_t N, int64_t K, int dtype,
                        void* stream);
 /* The same step for either MLP activation: C = (A * B^T) .* act'(aux), act = SVOL_ACT_GELU (aux = the saved
- * PRE-activation) or SVOL_ACT_RELU (aux = the saved POST-activation, relu' = [aux > 0]: the F.relu FFN of the
- * enc/dec Transformer, transformer.py:191,245). */
+ * PRE-activation), SVOL_ACT_GELU_D (aux = the derivative itself, saved by svol_gemm_nt under the same code) or SVOL_ACT_RELU
+ * (aux = the saved POST-activation, relu' = [aux > 0]: the F.relu FFN of the enc/dec Transformer, transformer.py:191,245). */
 int svol_gemm_nt_dact(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                       const void* aux, int64_t ldaux, int act, float* colsum, int64_t M, int64_t N, int64_t K,
                       int dtype, void* stream);
@@ -386,7 +390,7 @@ int svol_block_trace_dump(char* buf, int64_t cap);
  *  w  : W_IN dt [3D,D] · WV_HILO bf16 [D,2D] or NULL · W_O dt [D,D] · W_FC1 dt [F,D] · W_FC2 dt [D,F] and the transposes
  *       W_IN_T [D,3D] · W_O_T · W_FC1_T [D,F] · W_FC2_T [F,D]
  *  sav: Y1, Y1POS dt [M,D] · A, MEAN1, RSTD1 f32 [M] · GATE_WS f32 [B*H*(L+2)] · QKV dt [M,3D] · O dt [M,D] · LSE f32 [B,H,L] ·
- *       S2 f32 [M,D] · Y2 dt [M,D] · MEAN2, RSTD2 · PRE, HID dt [M,F] · S3 f32 [M,D] · MEAN3, RSTD3
+ *       S2 f32 [M,D] · Y2 dt [M,D] · MEAN2, RSTD2 · PRE (= gelu'(fc1 output), SVOL_ACT_GELU_D), HID dt [M,F] · S3 f32 [M,D] · MEAN3, RSTD3
  *  out: M32 f32, M dt, MPOS dt [M,D]          scr: Y1_32, Y2_32 f32 [M,D] · ATTN_WS
  *  bwd in : DM32 f32, DM dt, DMPOS dt (each may be NULL, not all)
  *  bwd tmp: DS32_3 f32, DS3 dt [M,D] · DPRE dt [M,F] · DY2 dt · DS32_2 f32 · G2D dt · DO dt [M,D] · DQKV dt [M,3D] ·
@@ -449,6 +453,9 @@ enum { SVOL_QC_SLOTS(SVOL_SLOT_ENUM_QC) SVOL_QC_COUNT };
 int svol_video_half_fwd(const int64_t* dims, void* const* slots, void* stream);
 int svol_video_half_bwd(const int64_t* dims, void* const* slots, int phase, void* stream);
 int svol_video_half_wgrad(const int64_t* dims, void* const* slots, void* stream);
+/* the same in two launches: part 1 = fc2 / fc1 / out-proj (operands exist after svol_video_half_bwd phase 1), part 2 = in_proj
+ * (after phase 2); part 0 = all five */
+int svol_video_half_wgrad_part(const int64_t* dims, void* const* slots, int part, void* stream);
 int svol_query_self_fwd(const int64_t* dims, void* const* slots, void* stream);
 int svol_query_self_bwd(const int64_t* dims, void* const* slots, void* stream);
 int svol_query_self_wgrad(const int64_t* dims, void* const* slots, void* stream);

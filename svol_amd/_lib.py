@@ -73,6 +73,7 @@ SIGNATURES = {
     'svol_video_half_fwd': [_p, _p, _p],
     'svol_video_half_bwd': [_p, _p, _int, _p],
     'svol_video_half_wgrad': [_p, _p, _p],
+    'svol_video_half_wgrad_part': [_p, _p, _int, _p],
     'svol_query_self_fwd': [_p, _p, _p],
     'svol_query_self_bwd': [_p, _p, _p],
     'svol_query_self_wgrad': [_p, _p, _p],

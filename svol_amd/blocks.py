@@ -23,6 +23,7 @@ import torch
 
 from . import _lib, ops
 
+WGRAD_SPLIT = os.environ.get('SVOL_WGRAD_SPLIT') is not None   # measured: +0.16 ms/step (more work beside the attention backward than the shorter tail saves)
 ENABLED = os.environ.get('SVOL_NO_BLOCKS') is None
 VH, QS, QC = 0, 1, 2
 _F32, _BF16 = 0, 1
@@ -298,12 +299,15 @@ def plan(layer, block, dt, qdt):
 # ----------------------------------------------------------------------------------------------------------------------
 # weight-gradient deferral (policy of ops.gemm_tn_sink, one queue item per block)
 # ----------------------------------------------------------------------------------------------------------------------
-def _issue_wgrad(fn_name, dims, tbl, keep, dev):
+def _issue_wgrad(fn_name, dims, tbl, keep, dev, part=None):
     """the block's weight-gradient GEMMs: on the weight-gradient stream behind an event when every target is a sink, else in line."""
     fn = getattr(_lib.lib(), fn_name)
 
     def run(stream_handle):
-        _lib.check(fn(dims, tbl.arr, stream_handle), fn_name)
+        if part is None:
+            _lib.check(fn(dims, tbl.arr, stream_handle), fn_name)
+        else:
+            _lib.check(fn(dims, tbl.arr, part, stream_handle), fn_name)
 
     if not ops.WGRAD_ASYNC or (not ops.WGRAD_IN_CAPTURE and torch.cuda.is_current_stream_capturing()):
         run(ops._stream())
@@ -434,8 +438,12 @@ class VideoHalfFn(torch.autograd.Function):
         L_ = _lib.lib()
         s = ops._stream()
         _lib.check(L_.svol_video_half_bwd(dims, tbl.arr, 1, s), 'svol_video_half_bwd')
+        keep = [t_ for t_ in (ctx.arena, tmp, dm32, dm, dmpos) if t_ is not None]
+        split = bufs is None and ctx.big and WGRAD_SPLIT
         if ctx.big:
             ops._BIG_ATTN['left'] -= 1
+            if split:   # this layer's MLP / out-proj weight gradients exist already: they go beside ITS attention backward
+                _issue_wgrad('svol_video_half_wgrad_part', dims, tbl, keep, dev, part=1)
             ops.flush_wgrad(gate=True)   # queued weight-gradient GEMMs run beside the attention backward (issue-bound; they are HBM / atomic bound)
         ev = _maybe_events('attn_bwd', (B, H, L, L, D // H))
         if ev:
@@ -444,9 +452,10 @@ class VideoHalfFn(torch.autograd.Function):
         _lib.check(L_.svol_video_half_bwd(dims, tbl.arr, 2, s), 'svol_video_half_bwd')
         tbl.set('EV_A0', None)
         tbl.set('EV_A1', None)
-        keep = (ctx.arena, tmp, dm32, dm, dmpos)
-        if bufs is None:
-            _issue_wgrad('svol_video_half_wgrad', dims, tbl, [t_ for t_ in keep if t_ is not None], dev)
+        if split:
+            _issue_wgrad('svol_video_half_wgrad_part', dims, tbl, keep, dev, part=2)
+        elif bufs is None:
+            _issue_wgrad('svol_video_half_wgrad', dims, tbl, keep, dev)
         else:
             _lib.check(L_.svol_video_half_wgrad(dims, tbl.arr, s), 'svol_video_half_wgrad')
         pl.done(n_par > 0)

@@ -95,6 +95,9 @@ const char* const kVhNames = SVOL_VH_SLOTS(SLOT_NAME);
 const char* const kQsNames = SVOL_QS_SLOTS(SLOT_NAME);
 const char* const kQcNames = SVOL_QC_SLOTS(SLOT_NAME);
 
+// the video half's MLP saves gelu' instead of the pre-activation (SVOL_VH_GELU_PRE=1: round 2's form, for A/B runs)
+const int kVhGelu = getenv("SVOL_VH_GELU_PRE") ? SVOL_ACT_GELU : SVOL_ACT_GELU_D;
+
 inline void record(void* ev, void* stream) {
     if (ev) (void)hipEventRecord(static_cast<hipEvent_t>(ev), static_cast<hipStream_t>(stream));
 }
@@ -198,7 +201,8 @@ int svol_video_half_fwd(const int64_t* dims, void* const* p, void* s) {
     RUN(svol_layernorm_fwd(P(S2), xf, f32(P(G2)), f32(P(BT2)), f32(P(Y2_32)), P(Y2), nullptr, nullptr, 0, f32(P(MEAN2)), f32(P(RSTD2)), M,
                            D, 0.f, 0, nullptr, dt, s));
     // MLP1 + residual -> LN3 (+pos) (:142-143)
-    RUN(svol_gemm_nt(P(Y2), D, nullptr, 0, P(W_FC1), D, P(HID), F, f32(P(B_FC1)), nullptr, SVOL_ACT_GELU, P(PRE), F, nullptr, 0, 0, M, F,
+    // (PRE holds gelu'(pre-activation): SVOL_ACT_GELU_D — the backward's epilogue is then a multiply)
+    RUN(svol_gemm_nt(P(Y2), D, nullptr, 0, P(W_FC1), D, P(HID), F, f32(P(B_FC1)), nullptr, kVhGelu, P(PRE), F, nullptr, 0, 0, M, F,
                      D, dt, s));
     RUN(nt_res(P(HID), F, P(W_FC2), F, P(S3), P(B_FC2), P(Y2_32), M, D, F, dt, s));
     RUN(svol_layernorm_fwd(P(S3), xf, f32(P(G3)), f32(P(BT3)), f32(P(M32)), P(M), P(MPOS), P(POS), M, f32(P(MEAN3)), f32(P(RSTD3)), M, D,
@@ -217,7 +221,7 @@ int svol_video_half_bwd(const int64_t* dims, void* const* p, int phase, void* s)
         // LN3' -> (ds32, ds), b_fc2' ; (ds W2) * gelu'(pre), b_fc1' ; dpre W1 -> dy2
         RUN(svol_layernorm_bwd(f32(P(DM32)), P(DM), P(DMPOS), P(S3), xf, f32(P(G3)), f32(P(MEAN3)), f32(P(RSTD3)), f32(P(DS32_3)), P(DS3),
                                f32(P(DG3)), f32(P(DBT3)), f32(P(DB_FC2)), M, D, 0.f, 0, nullptr, dt, s));
-        RUN(svol_gemm_nt_dact(P(DS3), D, P(W_FC2_T), D, P(DPRE), F, P(PRE), F, SVOL_ACT_GELU, f32(P(DB_FC1)), M, F, D, dt, s));
+        RUN(svol_gemm_nt_dact(P(DS3), D, P(W_FC2_T), D, P(DPRE), F, P(PRE), F, kVhGelu, f32(P(DB_FC1)), M, F, D, dt, s));
         RUN(nt(P(DPRE), F, P(W_FC1_T), F, P(DY2), D, nullptr, nullptr, M, D, F, dt, s));
         // LN2' -> (ds32_2, g), b_o' ; do = g Wo
         RUN(svol_layernorm_bwd(f32(P(DS32_3)), P(DY2), nullptr, P(S2), xf, f32(P(G2)), f32(P(MEAN2)), f32(P(RSTD2)), f32(P(DS32_2)), P(G2D),
@@ -240,24 +244,29 @@ int svol_video_half_bwd(const int64_t* dims, void* const* p, int phase, void* s)
     return SVOL_OK;
 }
 
-int svol_video_half_wgrad(const int64_t* dims, void* const* p, void* s) {
-    if (!dims || !p) return SVOL_E_INVALID;
-    Trace tr_("video_half_wgrad", s);
+int svol_video_half_wgrad_part(const int64_t* dims, void* const* p, int part, void* s) {
+    if (!dims || !p || part < 0 || part > 2) return SVOL_E_INVALID;
+    Trace tr_(part == 1 ? "video_half_wgrad.1" : part == 2 ? "video_half_wgrad.2" : "video_half_wgrad", s);
     const Dims d(dims);
     if (!d.ok()) return SVOL_E_INVALID;
     const int64_t M = d.B * d.L, D = d.D, F = d.F;
     const int dt = d.dt;
-    // the block's five weight gradients in ONE launch (svol_gemm_tn_grouped)
+    // the block's five weight gradients in ONE launch (svol_gemm_tn_grouped) — or in two: the MLP / out-proj ones exist after
+    // phase 1 of the backward (part 1: they can run beside THIS layer's attention backward), the in_proj ones after phase 2 (part 2)
     const svol_tn_problem pr[5] = {
         {P(DS3), D, P(HID), F, f32(P(DW_FC2)), F, nullptr, M, D, F},
         {P(DPRE), F, P(Y2), D, f32(P(DW_FC1)), D, nullptr, M, F, D},
         {P(G2D), D, P(O), D, f32(P(DW_O)), D, nullptr, M, D, D},
         {P(DQKV), 3 * D, P(Y1POS), D, f32(P(DW_IN)), D, f32(P(DB_IN)), M, 2 * D, D},
         {at(P(DQKV), 2 * D, dt), 3 * D, P(Y1), D, f32(P(DW_IN)) + 2 * D * D, D, f32(P(DB_IN)) + 2 * D, M, D, D}};
-    RUN(svol_gemm_tn_grouped(pr, 5, dt, s));
+    if (part == 1) RUN(svol_gemm_tn_grouped(pr, 3, dt, s));
+    else if (part == 2) RUN(svol_gemm_tn_grouped(pr + 3, 2, dt, s));
+    else RUN(svol_gemm_tn_grouped(pr, 5, dt, s));
     return SVOL_OK;
-#undef P
 }
+
+int svol_video_half_wgrad(const int64_t* dims, void* const* p, void* s) { return svol_video_half_wgrad_part(dims, p, 0, s); }
+#undef P
 
 // ---------------------------------------------------------------------------------------------------------------------
 // query self-attention

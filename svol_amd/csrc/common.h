@@ -224,8 +224,11 @@ __device__ __forceinline__ float dgelu_fast(float x) {
 // derivative of the MLP activation for the fused backward epilogue: aux is the PRE-activation for GELU and the
 // POST-activation for ReLU (relu'(pre) = [hid > 0])
 __device__ __forceinline__ float dact_fast(float aux, int act) {
-    return act == SVOL_ACT_RELU ? (aux > 0.f ? 1.f : 0.f) : dgelu_fast(aux);
+    return act == SVOL_ACT_RELU ? (aux > 0.f ? 1.f : 0.f) : (act == SVOL_ACT_GELU_D ? aux : dgelu_fast(aux));
 }
+__device__ __forceinline__ bool act_is_gelu(int act) { return act == SVOL_ACT_GELU || act == SVOL_ACT_GELU_D; }
+// what svol_gemm_nt saves next to a GELU output: the pre-activation, or (SVOL_ACT_GELU_D) its derivative there
+__device__ __forceinline__ float pre_save_fast(float v, int act) { return act == SVOL_ACT_GELU_D ? dgelu_fast(v) : v; }
 
 // exact (erf) GELU and derivative
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

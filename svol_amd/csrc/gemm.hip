@@ -134,9 +134,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs p) {
                 const int m = bm + wm * WT + mt * 16 + fq * 4 + r;
                 if (m >= p.M) continue;
                 float v = (acc[mt][nt][r] + bv) * cs;
-                if (pre) pre[(int64_t)m * p.ldp + n] = from_f32<T>(v);
+                if (pre) pre[(int64_t)m * p.ldp + n] = from_f32<T>(p.act == SVOL_ACT_GELU_D ? dgelu_f(v) : v);
                 if (p.act == SVOL_ACT_RELU) v = fmaxf(v, 0.f);
-                else if (p.act == SVOL_ACT_GELU) v = gelu_f(v);
+                else if (act_is_gelu(p.act)) v = gelu_f(v);
                 else if (p.act == SVOL_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
                 if (res) v += to_f32(res[(int64_t)m * p.ldr + n]);
                 if (p.act == SVOL_ACT_RELU_RES) v = fmaxf(v, 0.f);
@@ -443,6 +443,7 @@ __global__ void act_bwd_kernel(const T* dy, const T* aux, T* dpre, int act, int6
         float d;
         if (act == SVOL_ACT_RELU) d = a > 0.f ? g : 0.f;
         else if (act == SVOL_ACT_GELU) d = g * dgelu_f(a);
+        else if (act == SVOL_ACT_GELU_D) d = g * a;
         else if (act == SVOL_ACT_SIGMOID) d = g * a * (1.f - a);
         else d = g;
         dpre[i] = from_f32<T>(d);
@@ -522,11 +523,18 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_skinny(SkArgs p) {
                 if (p.bias) v[e] += p.bias[n0 + e];
                 if (p.colscale) v[e] *= p.colscale[n0 + e];
             }
-            if (p.pre) *reinterpret_cast<f32x4*>(p.pre + (int64_t)m * p.ldp + n0) = v;
+            if (p.pre) {
+                f32x4 sv = v;
+                if (p.act == SVOL_ACT_GELU_D) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sv[e] = dgelu_f(v[e]);
+                }
+                *reinterpret_cast<f32x4*>(p.pre + (int64_t)m * p.ldp + n0) = sv;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (p.act == SVOL_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
-                else if (p.act == SVOL_ACT_GELU) v[e] = gelu_f(v[e]);
+                else if (act_is_gelu(p.act)) v[e] = gelu_f(v[e]);
                 else if (p.act == SVOL_ACT_SIGMOID) v[e] = 1.f / (1.f + __expf(-v[e]));
             }
             if (p.res) {
@@ -543,7 +551,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_skinny(SkArgs p) {
         if (mv) {
             const f32x4 x = *reinterpret_cast<const f32x4*>(p.aux + (int64_t)m * p.ldaux + n0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= p.act == SVOL_ACT_RELU ? (x[e] > 0.f ? 1.f : 0.f) : dgelu_f(x[e]);
+            for (int e = 0; e < 4; ++e) v[e] *= p.act == SVOL_ACT_RELU ? (x[e] > 0.f ? 1.f : 0.f) : (p.act == SVOL_ACT_GELU_D ? x[e] : dgelu_f(x[e]));
         } else {
             v = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -649,6 +657,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* A2, int64_t n_sp
                         const void* residual, int64_t ldr, int out_f32, int64_t M, int64_t N, int64_t K, int64_t kwrap, int dtype,
                         void* stream) {
     if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return SVOL_E_INVALID;
+    if (act == SVOL_ACT_GELU_D && !pre_act_out) return SVOL_E_INVALID;   // the derivative is what this variant exists to save
     if (M == 0 || N == 0) return SVOL_OK;
     const int epc = svol_is16(dtype) ? 8 : 4;
     if (!svol_is16(dtype) && dtype != SVOL_F32) return SVOL_E_INVALID;
@@ -709,7 +718,7 @@ int svol_gemm_nt_split(const void* A, int64_t lda, const void* W_hilo, int64_t l
 int svol_gemm_nt_dact(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* aux,
                       int64_t ldaux, int act, float* colsum, int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
     if (!A || !B || !C || !aux || M < 0 || N < 0 || K <= 0) return SVOL_E_INVALID;
-    if (act != SVOL_ACT_GELU && act != SVOL_ACT_RELU) return SVOL_E_INVALID;
+    if (act != SVOL_ACT_GELU && act != SVOL_ACT_RELU && act != SVOL_ACT_GELU_D) return SVOL_E_INVALID;
     if (M == 0 || N == 0) return SVOL_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (svol_is16(dtype)) {

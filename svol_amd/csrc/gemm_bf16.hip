@@ -201,15 +201,20 @@ __device__ __forceinline__ void gemm_nt_bf16_body(const FastArgs& p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = (v[e] + bias4[e]) * scale4[e];
                     if (p.pre) {
-                        if (colv) Out4<h16_t>::store(p.pre + (int64_t)m * p.ldp + ncol, v);
+                        f32x4 sv = v;
+                        if (p.act == SVOL_ACT_GELU_D) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) sv[e] = dgelu_fast(v[e]);
+                        }
+                        if (colv) Out4<h16_t>::store(p.pre + (int64_t)m * p.ldp + ncol, sv);
                         else
                             for (int e = 0; e < 4; ++e)
-                                if (ncol + e < p.N) p.pre[(int64_t)m * p.ldp + ncol + e] = (h16_t)v[e];
+                                if (ncol + e < p.N) p.pre[(int64_t)m * p.ldp + ncol + e] = (h16_t)sv[e];
                     }
                     if (p.act == SVOL_ACT_RELU) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    } else if (p.act == SVOL_ACT_GELU) {
+                    } else if (act_is_gelu(p.act)) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
                     } else if (p.act == SVOL_ACT_SIGMOID) {
@@ -358,13 +363,16 @@ __device__ __forceinline__ void gemm_nt_bf16_skinny_body(const FastArgs& p) {
                 if (p.colscale) v[e] *= p.colscale[n0 + e];
             }
             if (p.pre) {
-                Out4<h16_t>::store(p.pre + (int64_t)m * p.ldp + n0, f32x4{v[0], v[1], v[2], v[3]});
-                Out4<h16_t>::store(p.pre + (int64_t)m * p.ldp + n0 + 4, f32x4{v[4], v[5], v[6], v[7]});
+                float sv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sv[e] = pre_save_fast(v[e], p.act);
+                Out4<h16_t>::store(p.pre + (int64_t)m * p.ldp + n0, f32x4{sv[0], sv[1], sv[2], sv[3]});
+                Out4<h16_t>::store(p.pre + (int64_t)m * p.ldp + n0 + 4, f32x4{sv[4], sv[5], sv[6], sv[7]});
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (p.act == SVOL_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
-                else if (p.act == SVOL_ACT_GELU) v[e] = gelu_fast(v[e]);
+                else if (act_is_gelu(p.act)) v[e] = gelu_fast(v[e]);
                 else if (p.act == SVOL_ACT_SIGMOID) v[e] = 1.f / (1.f + __expf(-v[e]));
             }
             if (p.res) {

@@ -180,7 +180,7 @@ __device__ __forceinline__ void gemm_n256_body(const N256Args& p) {
                 *reinterpret_cast<f32x4*>(C) = f32x4{v[0], v[1], v[2], v[3]};
                 *reinterpret_cast<f32x4*>(C + 4) = f32x4{v[4], v[5], v[6], v[7]};
             } else {
-                if (p.act == SVOL_ACT_GELU) {
+                if (act_is_gelu(p.act)) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
                 }
@@ -210,7 +210,7 @@ int svol_gemm_n256_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, 
     if (off || N % BN || K % BK || K < 512 || M < 4096) return SVOL_E_UNSUPPORTED;
     if (epi != 0 || pre || colscale) return SVOL_E_UNSUPPORTED;
     if (kwrap != K && (kwrap % BK || 2 * kwrap != K)) return SVOL_E_UNSUPPORTED;
-    if (act != SVOL_ACT_NONE && ((act != SVOL_ACT_GELU && act != SVOL_ACT_RELU) || out_f32)) return SVOL_E_UNSUPPORTED;
+    if (act != SVOL_ACT_NONE && ((act != SVOL_ACT_GELU && act != SVOL_ACT_RELU) || out_f32)) return SVOL_E_UNSUPPORTED;   // (GELU_D: needs `pre`, not here)
     if (res && !out_f32) return SVOL_E_UNSUPPORTED;
     auto al16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
     if (lda % 8 || ldw % 8 || !al16(A) || !al16(W) || !al16(C)) return SVOL_E_UNSUPPORTED;

@@ -217,12 +217,12 @@ __device__ __forceinline__ void gemm_ws_body(const WsArgs& p) {
                     for (int hf = 0; hf < 2; ++hf) {
                         h16x8 o;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (h16_t)v[hf][e];
+                        for (int e = 0; e < 8; ++e) o[e] = (h16_t)pre_save_fast(v[hf][e], p.act);
                         *reinterpret_cast<h16x8*>(p.pre + (int64_t)m * p.ldp + c0 + hf * 32 + fq * 8) = o;
                     }
                 }
                 h16_t* C = reinterpret_cast<h16_t*>(p.C);
-                if (p.act == SVOL_ACT_GELU) {
+                if (act_is_gelu(p.act)) {
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -482,7 +482,7 @@ __device__ __forceinline__ void gemm_wsp_body(const WsArgs& p) {
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[hf][e] = (h16_t)v[hf][e];
+                    for (int e = 0; e < 8; ++e) o[hf][e] = (h16_t)pre_save_fast(v[hf][e], ACT);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[0]), rP, voffP, j * pstep, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[1]), rP, voffP + 64, j * pstep, 0);
             }
@@ -492,7 +492,7 @@ __device__ __forceinline__ void gemm_wsp_body(const WsArgs& p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float y = v[hf][e];
-                    if constexpr (ACT == SVOL_ACT_GELU) y = gelu_fast(y);
+                    if constexpr (ACT == SVOL_ACT_GELU || ACT == SVOL_ACT_GELU_D) y = gelu_fast(y);
                     if constexpr (ACT == SVOL_ACT_RELU) y = fmaxf(y, 0.f);
                     o[hf][e] = (h16_t)y;
                 }
@@ -580,8 +580,10 @@ WSP_KERNEL(gemm_wsp_bf16_none, 0, SVOL_ACT_NONE, false, false, 2)
 WSP_KERNEL(gemm_wsp_bf16_none_scale, 0, SVOL_ACT_NONE, false, true, 2)
 WSP_KERNEL(gemm_wsp_bf16_gelu, 0, SVOL_ACT_GELU, false, false, 7)
 WSP_KERNEL(gemm_wsp_bf16_gelu_pre, 0, SVOL_ACT_GELU, true, false, 8)
+WSP_KERNEL(gemm_wsp_bf16_gelu_dpre, 0, SVOL_ACT_GELU_D, true, false, 9)
 WSP_KERNEL(gemm_wsp_bf16_relu, 0, SVOL_ACT_RELU, false, false, 2)
 WSP_KERNEL(gemm_wsp_bf16_dgelu, 2, SVOL_ACT_GELU, false, false, 9)
+WSP_KERNEL(gemm_wsp_bf16_dmul, 2, SVOL_ACT_GELU_D, false, false, 3)
 WSP_KERNEL(gemm_wsp_bf16_drelu, 2, SVOL_ACT_RELU, false, false, 3)
 #undef WSP_KERNEL
 
@@ -601,7 +603,8 @@ int svol_gemm_ws_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, vo
         if (!res || act != SVOL_ACT_NONE || pre || colscale) return SVOL_E_UNSUPPORTED;
         mode = 1;
     } else {
-        if (res || (act != SVOL_ACT_NONE && act != SVOL_ACT_GELU && act != SVOL_ACT_RELU)) return SVOL_E_UNSUPPORTED;
+        if (res || (act != SVOL_ACT_NONE && act != SVOL_ACT_GELU && act != SVOL_ACT_RELU && act != SVOL_ACT_GELU_D)) return SVOL_E_UNSUPPORTED;
+        if (act == SVOL_ACT_GELU_D && !pre) return SVOL_E_INVALID;
         mode = 0;
     }
     auto al16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
@@ -639,9 +642,10 @@ int svol_gemm_ws_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, vo
     if (!no_pipe && mode == 0) {
         if (act == SVOL_ACT_NONE && !pre) kp = colscale ? gemm_wsp_bf16_none_scale : gemm_wsp_bf16_none;
         else if (act == SVOL_ACT_GELU && !colscale) kp = pre ? gemm_wsp_bf16_gelu_pre : gemm_wsp_bf16_gelu;
+        else if (act == SVOL_ACT_GELU_D && !colscale) kp = gemm_wsp_bf16_gelu_dpre;
         else if (act == SVOL_ACT_RELU && !pre && !colscale) kp = gemm_wsp_bf16_relu;
     } else if (!no_pipe && mode == 2) {
-        kp = act == SVOL_ACT_RELU ? gemm_wsp_bf16_drelu : gemm_wsp_bf16_dgelu;
+        kp = act == SVOL_ACT_RELU ? gemm_wsp_bf16_drelu : (act == SVOL_ACT_GELU_D ? gemm_wsp_bf16_dmul : gemm_wsp_bf16_dgelu);
     }
     if (kp) hipLaunchKernelGGL(kp, grid, dim3(256), 0, s, p);
     else if (mode == 0) hipLaunchKernelGGL(gemm_ws_bf16_m0, grid, dim3(256), 0, s, p);

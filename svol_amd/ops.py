@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_RELU_RES = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_RELU_RES, ACT_GELU_D = 0, 1, 2, 3, 4, 5
 _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}   # SVOL_F32 / SVOL_BF16 / SVOL_F16
 
 

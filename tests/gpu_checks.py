@@ -187,6 +187,33 @@ def check_gemm_dgelu():
     return res
 
 
+def check_gemm_gelu_d():
+    """SVOL_ACT_GELU_D: the forward GEMM saves gelu'(pre-activation) next to gelu(pre-activation), the backward step multiplies by
+    the saved tensor as it is.  Against fp64 for every kernel family that can carry a `pre` output (weight-stationary K = 256, tile
+    kernels, skinny, fp32), and the chained fwd -> bwd against the SVOL_ACT_GELU pair on the same operands."""
+    res = {}
+    for dt in DTYPES16:
+        shapes = [(300, 256, 64), (1000, 2048, 256), (77, 96, 32), (4133, 512, 256), (5001, 320, 256), (800, 2048, 256)]
+        for (M, N, K) in shapes:
+            A, W, bias = _rnd((M, K), dt, 60), _rnd((N, K), dt, 61, 1.0 / math.sqrt(K)), _rnd((N,), torch.float32, 62)
+            G_, W2 = _rnd((M, 64), dt, 63), _rnd((N, 64), dt, 64, 1.0 / 8)
+            hid, dsave = ops.gemm_nt(A.to(DEV), W.to(DEV), bias.to(DEV), ops.ACT_GELU_D, want_pre=True)
+            hid0, pre0 = ops.gemm_nt(A.to(DEV), W.to(DEV), bias.to(DEV), ops.ACT_GELU, want_pre=True)
+            z = (A.double() @ W.double().t() + bias.double()).requires_grad_(True)
+            h64 = O.gelu_erf(z)
+            h64.sum().backward()
+            res[f'gelu_d/{dt}/{M}x{N}x{K}/hid'] = (rel_err(hid, h64.detach()), TOL[dt])
+            res[f'gelu_d/{dt}/{M}x{N}x{K}/hid_same_as_gelu'] = (rel_err(hid, hid0.double()), TOL[dt] / 4)   # (an ulp: different kernels, different fma contraction)
+            res[f'gelu_d/{dt}/{M}x{N}x{K}/saved_derivative'] = (rel_err(dsave, z.grad), TOL[dt])
+            out, cs = ops.gemm_nt_dact(G_.to(DEV), W2.to(DEV), dsave, ops.ACT_GELU_D)
+            out0, cs0 = ops.gemm_nt_dact(G_.to(DEV), W2.to(DEV), pre0, ops.ACT_GELU)
+            ref = (G_.double() @ W2.double().t()) * z.grad
+            res[f'gelu_d/{dt}/{M}x{N}x{K}/dpre'] = (rel_err(out, ref), 2 * TOL[dt])
+            res[f'gelu_d/{dt}/{M}x{N}x{K}/dpre_vs_gelu_pair'] = (rel_err(out, out0.double()), 2 * TOL[dt])
+            res[f'gelu_d/{dt}/{M}x{N}x{K}/colsum'] = (rel_err(cs, ref.sum(0)), 1e-4 if dt == torch.float32 else 1e-2)
+    return res
+
+
 def check_gemm_drelu():
     """(A W^T) * [hid > 0] + column sums: the ReLU FFN backward step of the enc/dec Transformer; the ReLU forward at K = 256
     through the weight-stationary kernel (M >= 4096)."""

@@ -33,6 +33,7 @@ def test_gemm_nt_split_weights(G):
 
 def test_gemm_nt_dgelu_fused(G):
     _assert(G.check_gemm_dgelu())
+    _assert(G.check_gemm_gelu_d())
 
 
 def test_gemm_nt_drelu_fused(G):
