@@ -316,6 +316,38 @@ def main():
             eager_step()
         torch.cuda.synchronize()
         ops.timer.disable()
+    # the same two attention launches ALONE (nothing else on the device), right after the timed region: inside the step the backward
+    # launch shares the CUs with the step's weight-gradient GEMMs, which are gated to run beside it
+    alone = None
+    if rank == 0 and a.dtype != 'fp32':
+        try:
+            L_ = T * P + (1 if a.workload == 'encdec' else 0)
+            Hh, Dm = args.nheads, args.hidden_dim
+            dh_ = Dm // Hh
+            tdt = {'bf16': torch.bfloat16, 'fp16': torch.float16}[a.dtype]
+            qkv = (torch.randn(B * L_, 3 * Dm, device=dev) * 0.5).to(tdt)
+            q_, k_, v_ = qkv[:, :Dm], qkv[:, Dm:2 * Dm], qkv[:, 2 * Dm:]
+            pm = 1.4426950408889634 / dh_ ** 0.5
+            o_, lse_ = ops.attn_fwd(q_, k_, v_, B, Hh, L_, L_, dh_, None, pm)
+            do_ = (torch.randn(B * L_, Dm, device=dev) * 0.5).to(tdt)
+            dqkv = torch.empty_like(qkv)
+
+            def _time(fn, n=10):
+                fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / n
+            alone = {'attn_fwd_ms': _time(lambda: ops.attn_fwd(q_, k_, v_, B, Hh, L_, L_, dh_, None, pm)),
+                     'attn_bwd_ms': _time(lambda: ops.attn_bwd(q_, k_, v_, o_, do_, lse_, B, Hh, L_, L_, dh_, dqkv[:, :Dm], dqkv[:, Dm:2 * Dm],
+                                                               dqkv[:, 2 * Dm:], None, pm))}
+            del qkv, o_, lse_, do_, dqkv
+        except Exception as e:  # a measurement aid must not take the bench line down
+            alone = {'error': repr(e)}
     issue_per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -396,6 +428,18 @@ def main():
                 'whole_step_tflops': fps * gf_frame / 1e3 / world,
                 'whole_step_frac_of_peak': fps * gf_frame / 1e3 / world / PEAK_BF16_MFMA_TFLOPS,
                 'issue_bound_frac': (floor_bwd_ms / bwd[1]) if bwd[1] >= fwd[1] else (floor_fwd_ms / fwd[1]), 'issue_bound': issue}
+        if alone and 'attn_bwd_ms' in alone:
+            # (the in-step figures above are the contract's; these say what the co-scheduled weight-gradient GEMMs cost the launch)
+            roof['same_launches_alone'] = {
+                'attn_fwd_ms': alone['attn_fwd_ms'], 'attn_bwd_ms': alone['attn_bwd_ms'],
+                'frac': (2.0 * attn_fwd_flop / (alone['attn_bwd_ms'] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS) if bwd[1] >= fwd[1]
+                else (attn_fwd_flop / (alone['attn_fwd_ms'] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS),
+                'issue_bound_frac': (floor_bwd_ms / alone['attn_bwd_ms']) if bwd[1] >= fwd[1] else (floor_fwd_ms / alone['attn_fwd_ms']),
+                'note': 'measured right after the timed region with nothing else on the device; in the step the weight-gradient GEMMs '
+                        'are gated to run beside the attention backward (SVOL_NO_WGRAD_GATE=1 moves them beside the LayerNorm / dgelu '
+                        'kernels instead: launch_ms ~1.27, step +0.13 ms)'}
+        elif alone:
+            roof['same_launches_alone'] = alone
 
     if rank == 0:
         res = {
