@@ -616,7 +616,11 @@ static int tn_generic_plan(const void* A, int64_t lda, const void* B, int64_t ld
     // (measured on MI355X: the fp32 atomics of the final accumulation dominate small outputs, so few, long-running
     //  workgroups win there: 256x256 outputs 0.065 ms at 1024 workgroups vs 0.032 ms at 256)
     static const int force_wgs = getenv("SVOL_TN_WGS") ? atoi(getenv("SVOL_TN_WGS")) : 0;
-    const int target_wgs = force_wgs ? force_wgs : (tiles <= 8 ? 256 : 512);
+    // fp32 with few rows (the query stream's weight gradients, Mc = 800): every split adds a full tile of fp32 atomics — 13 splits of the
+    // [256, 2048] MLP gradients were 6.8 M atomics per problem, which is what their 87 us were (atomic rate ~128 per clock, tools/micro/
+    // atomic_rate) — so few splits: ~128 workgroups per problem
+    static const int small_wgs = getenv("SVOL_TN_SMALL_WGS") ? atoi(getenv("SVOL_TN_SMALL_WGS")) : 128;
+    const int target_wgs = force_wgs ? force_wgs : ((dtype == SVOL_F32 && Mc <= 4096) ? small_wgs : (tiles <= 8 ? 256 : 512));
     int64_t want = (target_wgs + tiles - 1) / tiles;
     int64_t chunk = (Mc + want - 1) / want;
     chunk = ((chunk + ct - 1) / ct) * ct;
