@@ -54,6 +54,18 @@ def main():
     if os.environ['SVOL_BLOCK_TRACE'] == '2':   # timeline of the traced steps: start / end (ms) of every call site, all streams
         print(f'# {steps} steps, {ms:.2f} ms/step; start end (ms from the first record) program call-site')
         print(txt)
+        rows = []
+        for line in txt.splitlines():
+            f = line.split()
+            if len(f) >= 4:
+                rows.append((float(f[0]), float(f[1]), f[2], ' '.join(f[3:])))
+        vh = sorted(r for r in rows if r[2].startswith('video_half_fwd') or r[2].startswith('video_half_bwd'))
+        if vh:
+            span, busy = vh[-1][1] - vh[0][0], sum(r[1] - r[0] for r in vh)
+            gaps = sorted(((vh[i + 1][0] - vh[i][1], vh[i][1], vh[i][3], vh[i + 1][3]) for i in range(len(vh) - 1)), reverse=True)
+            print(f'# video-stream block programs: span {span:.3f} ms, busy {busy:.3f} ms, idle {span - busy:.3f} ms in {len(gaps)} gaps; largest:')
+            for g in gaps[:5]:
+                print(f'#   {g[0]:.3f} ms at {g[1]:.3f}: after {g[2][:44]} before {g[3][:44]}')
         return
     tot = 0.0
     print(f'# {steps} steps, {ms:.2f} ms/step with the trace events; per step:')
