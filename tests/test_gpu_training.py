@@ -137,3 +137,45 @@ def test_training_step_does_not_depend_on_stream_timing(dtype):
         assert l1 == l0, (which, 'mid', l0, l1)
         err = float((g1 - g0).norm()) / gn
         assert err <= tol, (which, 'mid', err)
+
+
+@pytest.mark.gpu
+def test_block_trace_reports_every_launch_group_of_a_step():
+    """SVOL_BLOCK_TRACE (svol_block_trace_dump, tools/block_trace.py): the un-profiled per-call-site durations DESIGN.md section 5 quotes.
+    The variable is read when the library loads, so the traced step runs in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import torch
+from svol_amd import blocks, parallel, synthetic as syn
+from svol_amd.modeling.loss import build_loss
+from svol_amd.modeling.svanet import build_svanet
+args = syn.cfg2_args('video_matcher'); args.compute_dtype = 'bf16'
+B, T, P = 2, 8, 49
+torch.manual_seed(0)
+model = build_svanet(args).cuda().train(); crit = build_loss(args).cuda().train()
+red = parallel.BucketedGradAllReduce(parallel.arrival_order(model), skip=parallel.unused_parameters(model), ordered=True)
+inp = {k: v.cuda() for k, v in syn.synth_inputs(args, B, T, P, seed=1).items()}
+tg = syn.synth_targets(B, T, seed=1)
+for _ in range(2):
+    red.zero_grad()
+    out = model(inp['src_sketch'], inp['src_sketch_mask'], inp['src_video'], inp['src_video_mask'])
+    crit(out, tg); crit.weighted_total().backward(); red.finish()
+print(blocks.trace_dump())
+'''
+    env = dict(os.environ, SVOL_BLOCK_TRACE='1', PYTHONPATH=root)
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ' | ' in ln and 'avg_us' in ln]
+    progs = {ln.split(' | ')[0].strip() for ln in lines}
+    assert {'video_half_fwd', 'video_half_bwd.1', 'video_half_bwd.2', 'query_self_fwd', 'query_cross_fwd', 'query_cross_bwd'} <= progs, progs
+    attn = [ln for ln in lines if ln.startswith('video_half_bwd.2') and 'svol_attn_bwd' in ln]
+    from svol_amd import synthetic as syn
+    assert attn and int(attn[0].split('calls')[1].split()[0]) == 2 * syn.cfg2_args('video_matcher').num_layers   # two steps x six layers
+    # and without the variable the dump is empty
+    env.pop('SVOL_BLOCK_TRACE')
+    r2 = subprocess.run([sys.executable, '-c', 'from svol_amd import blocks; print(repr(blocks.trace_dump()))'], env=env, capture_output=True,
+                        text=True, timeout=300, cwd=root)
+    assert r2.returncode == 0 and r2.stdout.strip() == "''", (r2.stdout, r2.stderr[-500:])
