@@ -1545,6 +1545,356 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_pre(Args p) { attn_
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_pre_dma(Args p) { attn_bwd_dkdv_pre_body<false, true>(p); }
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16_pre_masked(Args p) { attn_bwd_dkdv_pre_body<true>(p); }
 
+// ===========================================================================================
+// SINGLE-PASS backward (round 4): the two-pass kernels above recompute S = Q K^T and dP = dO V^T in both passes and exponentiate
+// twice — 16 MFMAs and two exp passes per 32 x 32 block where one pass needs 10 and one — and both sit within 15-25 % of their own
+// instruction-issue floor.  Here a workgroup is KEY-stationary: 4 waves x 128 keys = 512 keys of one (batch, head); a wave keeps
+// dK^T / dV^T of its four 32-key blocks in 128 accumulator registers and K / V as MFMA B operands in registers, and the workgroup
+// streams the head's queries in 32-row steps (Q / dO tiles + the per-query constants -lse, -delta by LDS-DMA, 128 rows at a time):
+//   S = Q K^T - lse, dP = dO V^T - delta (row constants = initial accumulators, read once per step for all four key blocks),
+//   P = exp2(S), dV^T += dO^T P, dS = P * dP, dK^T += Q^T dS                (key on the lane: P / dS feed the next MFMA as they stand)
+//   dQ[q][d] += dS[q][key] K[key][d]: the one product that contracts over the LANE index of dS — the wave writes its packed dS block
+//   to its own LDS image [key][q] and reads it back transposed (ds_read_b64_tr_b16); K as that product's B operand is loop invariant.
+// dQ is summed over the workgroup's 512 keys on chip (each wave's 32 x 32 fp32 partial through LDS, one row group per wave) and leaves
+// as fp32 atomics with d on the lane — two 128-byte row segments per wave instruction, the full-rate shape — into a zeroed fp32 image
+// that attn_dq_round_bf16 rounds afterwards: L / 512 adds per element (0.63 GB per launch at B 8, H 8, L 6272 against the 2.5 GB of
+// 128-key ownership that ruled a single pass out in round 3).  The atomics of step i are issued in step i + 1, behind the barrier that
+// publishes the partials, and are never waited for inside the loop (counted vmcnt).
+constexpr int SP_KB = 4;                    // 32-key blocks per wave
+constexpr int SP_WKEYS = 32 * SP_KB;        // keys per wave
+constexpr int SP_KEYS = 4 * SP_WKEYS;       // keys per workgroup
+constexpr int SP_PART = 4 * 4 * 64 * 16;    // one partial buffer: [wave][row group][lane] x 16 bytes
+constexpr int SP_LDS = 4 * IMG + 4 * IMG + 2 * SP_PART + 4 * KT * 4;
+
+// byte offset of the 8-byte unit (chunk g = q / 8, half = (q / 4) & 1) of row `key` in a [32 keys][32 q] 16-bit image with 64-byte
+// rows: 16-byte chunks and 8-byte halves XOR-ed with key bits so that the 16 lanes of a ds_write_b64 group (16 keys, one unit each)
+// land on 32 different banks; the transposed read takes four whole rows per 32-lane half and is conflict free either way
+__device__ __forceinline__ int ds_off(int key, int g, int half) {
+    return key * 64 + ((g ^ ((key >> 2) & 3)) << 4) + ((half ^ ((key >> 1) & 1)) << 3);
+}
+// operand whose contraction index runs over the rows of 32-row sub-tile `sub` of a [128][32] image in NATURAL order (k-step s, lane
+// half h, element j <-> row 16 s + 8 h + j), lane & 31 = column: the loop-invariant B operand K[key][d] of the dQ product
+__device__ __forceinline__ void read_tr_nat(uint4 (&a)[2], const char* img, int sub, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, hh = g >> 1;
+    const int ch = 2 * (g & 1) + (p >> 1), inner = 8 * (p & 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int r1 = 32 * sub + 16 * s + 8 * hh + q;
+        const h16x4 lo = SVOL_DS_READ_TR16_H16((lds_bf16x4_ptr)(img + img_off(r1, ch) + inner));
+        const h16x4 hi = SVOL_DS_READ_TR16_H16((lds_bf16x4_ptr)(img + img_off(r1 + 4, ch) + inner));
+        a[s] = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+}
+// A operand dS[q][key] of the dQ product from the wave's [32 keys][32 q] image (ds_off), same natural key order
+__device__ __forceinline__ void read_ds_tr(uint4 (&a)[2], const char* img, int lane) {
+    const int gg = lane >> 4, i = lane & 15, qq = i >> 2, p = i & 3, hh = gg >> 1;
+    const int g = 2 * (gg & 1) + (p >> 1), half = p & 1;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int key = 16 * s + 8 * hh + qq;
+        const h16x4 lo = SVOL_DS_READ_TR16_H16((lds_bf16x4_ptr)(img + ds_off(key, g, half)));
+        const h16x4 hi = SVOL_DS_READ_TR16_H16((lds_bf16x4_ptr)(img + ds_off(key + 4, g, half)));
+        a[s] = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+}
+// the 16 accumulator registers of a lane as the two B-operand fragments of the next product (v_cvt_pk per register pair)
+__device__ __forceinline__ void pack16(uint4 (&o)[2], const f32x16& x) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        h16x8 b;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const h16x2 pr = cvt_pk_h16(x[8 * s + j], x[8 * s + j + 1]);
+            b[j] = pr[0];
+            b[j + 1] = pr[1];
+        }
+        o[s] = __builtin_bit_cast(uint4, b);
+    }
+}
+__device__ __forceinline__ void mma_packed(f32x16& acc, const uint4 (&a)[2], const uint4 (&b)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        acc = SVOL_MFMA_32x32x16_H16(__builtin_bit_cast(h16x8, a[s]), __builtin_bit_cast(h16x8, b[s]), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void sp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// before the single pass: delta = rowsum(dO * O); the row constants as plain fp32 vectors nl = -lse2, nd = -delta ([B,H,Lq], the
+// loop DMAs 64 of them per wave instruction); the fp32 dQ image zeroed.  One thread per (row, head), 32 rows x H heads per block;
+// the [B,H,Lq] side is read / written through LDS so that both sides of the transposition are coalesced.
+__global__ __launch_bounds__(256) void attn_bwd_sp_prep_bf16(Args p) {
+    __shared__ float s_lse[8][33], s_dl[8][33];
+    const int tid = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;          // global row (b * Lq + q); Lq % 32 == 0
+    const int b = (int)(row0 / p.Lq), q0 = (int)(row0 % p.Lq);
+    {
+        const int hh = tid >> 5, rl = tid & 31;
+        if (hh < p.H) s_lse[hh][rl] = p.lse2[((int64_t)b * p.H + hh) * p.Lq + q0 + rl];
+    }
+    const int rl = tid >> 3, hh = tid & 7;
+    float dl = 0.f;
+    if (hh < p.H) {
+        const int64_t row = row0 + rl;
+        const h16_t* o = reinterpret_cast<const h16_t*>(p.o) + row * p.ldo + hh * 32;
+        const h16_t* d = reinterpret_cast<const h16_t*>(p.d_o) + row * p.lddo + hh * 32;
+#pragma unroll
+        for (int i = 0; i < 32; i += 8) {
+            const h16x8 a = *reinterpret_cast<const h16x8*>(o + i), c = *reinterpret_cast<const h16x8*>(d + i);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += (float)a[e] * (float)c[e];
+        }
+        float* z = p.ws_dq + row * (p.H * 32) + hh * 32;
+#pragma unroll
+        for (int i = 0; i < 32; i += 4) *reinterpret_cast<f32x4*>(z + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+        s_dl[hh][rl] = dl;
+    }
+    __syncthreads();
+    {
+        const int h2 = tid >> 5, r2 = tid & 31;
+        if (h2 < p.H) {
+            const int64_t si = ((int64_t)b * p.H + h2) * p.Lq + q0 + r2;
+            reinterpret_cast<float*>(p.nl2)[si] = -s_lse[h2][r2];
+            reinterpret_cast<float*>(p.nd2)[si] = -s_dl[h2][r2];
+            p.delta[si] = s_dl[h2][r2];
+        }
+    }
+}
+// after it: dq (16-bit) = scale * fp32 image
+__global__ __launch_bounds__(256) void attn_dq_round_bf16(Args p) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;   // 8 consecutive columns of one row
+    const int64_t W = (int64_t)p.H * 32, total = (int64_t)p.B * p.Lq * W;
+    if (i >= total) return;
+    const int64_t row = i / W, c = i % W;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p.ws_dq + i), b = *reinterpret_cast<const f32x4*>(p.ws_dq + i + 4);
+    h16x8 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = (h16_t)(a[e] * p.scale); v[4 + e] = (h16_t)(b[e] * p.scale); }
+    *reinterpret_cast<h16x8*>(reinterpret_cast<h16_t*>(p.dq) + row * p.lddq + c) = v;
+}
+
+// Every MFMA of the single-pass kernel is inline asm: at one wave per SIMD (512 registers) hipcc selects the AGPR-destination form
+// for the builtin, so score / dP tiles that the VALU exponentiates would pay a v_accvgpr_read per element.  Register classes by
+// constraint: results the VALU touches "v", the dK / dV accumulators and the loop-invariant K / V fragments "a".
+// HAZARDS are ours inside and behind an asm statement (hipcc pads nothing): s_nop 1 in front = VALU-written operand -> MFMA read;
+// an MFMA result must not be read by a non-MFMA instruction for 12 wait states — the loop below keeps every such consumer dozens of
+// instructions behind its producer, and tests/test_isa_hazards.py checks the distance in the emitted code.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ u32x4 to_acc(u32x4 r) {
+    asm volatile("; operand -> AGPR" : "+a"(r));
+    return r;
+}
+__device__ __forceinline__ u32x4 as_u32x4(const uint4& v) { return u32x4{v.x, v.y, v.z, v.w}; }
+// D = A B + C, two k-steps, B fragments in AGPRs, D and C different VGPR ranges
+__device__ __forceinline__ f32x16 sp_mma_c(const uint4 (&a)[2], const u32x4 (&b)[2], const f32x16& c0) {
+    f32x16 acc;
+    asm("s_nop 1\n\tv_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %1, %2, %5\n\tv_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %3, %4, %0"
+        : "=&v"(acc)
+        : "v"(as_u32x4(a[0])), "a"(b[0]), "v"(as_u32x4(a[1])), "a"(b[1]), "v"(c0));
+    return acc;
+}
+// acc (AGPRs) += A B, two k-steps, both operands in VGPRs (B fresh from v_cvt_pk)
+__device__ __forceinline__ void sp_mma_acc(f32x16& acc, const uint4 (&a)[2], const uint4 (&b)[2]) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %1, %2, %0\n\tv_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %3, %4, %0"
+                 : "+a"(acc)
+                 : "v"(as_u32x4(a[0])), "v"(as_u32x4(b[0])), "v"(as_u32x4(a[1])), "v"(as_u32x4(b[1])));
+}
+// dQ partial (VGPRs): FIRST = A B (C is the inline constant 0), then += A B; B (K fragments) in AGPRs
+template <bool FIRST>
+__device__ __forceinline__ void sp_mma_dq(f32x16& acc, const uint4 (&a)[2], const u32x4 (&b)[2]) {
+    if (FIRST)
+        asm volatile("v_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %1, %2, 0\n\tv_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %3, %4, %0"
+                     : "=&v"(acc)
+                     : "v"(as_u32x4(a[0])), "a"(b[0]), "v"(as_u32x4(a[1])), "a"(b[1]));
+    else
+        asm volatile("v_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %1, %2, %0\n\tv_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %3, %4, %0"
+                     : "+v"(acc)
+                     : "v"(as_u32x4(a[0])), "a"(b[0]), "v"(as_u32x4(a[1])), "a"(b[1]));
+}
+
+template <bool LIVE>
+__device__ __forceinline__ void attn_bwd_sp_body(const Args& p, char* smem, int xt, int hh, int b) {
+    // every LDS-DMA destination (row constants, Q / dO tiles, the prologue's K / V staging) sits in the first 64 KiB: the existing
+    // kernels never put an M0 base above 0xFFFF, and nothing here depends on how many bits of M0 the transfer honours
+    float* sL = reinterpret_cast<float*>(smem);   // [2][KT] -lse2
+    float* sD = sL + 2 * KT;                      // [2][KT] -delta
+    char* sQ = smem + 4 * KT * 4;          // [2][IMG]   Q tiles (128 queries)
+    char* sdO = sQ + 2 * IMG;              // [2][IMG]   dO tiles
+    char* sTall = sQ + 4 * IMG;            // [4 waves][4 blocks][32 keys][32 q] dS images
+    char* sPart = sQ + 8 * IMG;            // [2][SP_PART] dQ partials
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const h16_t* Q = reinterpret_cast<const h16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * 32;
+    const h16_t* dO = reinterpret_cast<const h16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * 32;
+    const h16_t* K = reinterpret_cast<const h16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * 32;
+    const h16_t* V = reinterpret_cast<const h16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * 32;
+    const float* nl_g = reinterpret_cast<const float*>(p.nl2) + ((int64_t)b * p.H + hh) * p.Lq;
+    const float* nd_g = reinterpret_cast<const float*>(p.nd2) + ((int64_t)b * p.H + hh) * p.Lq;
+    const int dqw = p.H * 32;
+    float* dq32 = p.ws_dq + (int64_t)b * p.Lq * dqw + hh * 32;
+    const int key0 = xt * SP_KEYS + wave * SP_WKEYS;
+    char* sT = sTall + wave * IMG;
+
+    u32x4 kbk[SP_KB][2], vbk[SP_KB][2], kd[SP_KB][2];
+    f32x16 dK[SP_KB], dV[SP_KB];
+    if (LIVE) {   // this wave's K tile, then its V tile, through ITS quarter of the (still unused) Q / dO buffers
+        char* sS = sQ + wave * IMG;
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) dma_piece(sS, K, p.ldk, key0, pc, lane);
+        dma_wait_all();
+#pragma unroll
+        for (int kb = 0; kb < SP_KB; ++kb) {
+            uint4 t0[2], t1[2];
+            read_rows(t0, sS, kb * 32 + r, h);
+            read_tr_nat(t1, sS, kb, lane);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { kbk[kb][s] = to_acc(as_u32x4(t0[s])); kd[kb][s] = to_acc(as_u32x4(t1[s])); }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) dma_piece(sS, V, p.ldv, key0, pc, lane);
+        dma_wait_all();
+#pragma unroll
+        for (int kb = 0; kb < SP_KB; ++kb) {
+            uint4 t0[2];
+            read_rows(t0, sS, kb * 32 + r, h);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) vbk[kb][s] = to_acc(as_u32x4(t0[s]));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int kb = 0; kb < SP_KB; ++kb) {
+            dK[kb] = zero16();
+            dV[kb] = zero16();
+            asm volatile("; accumulators -> AGPR" : "+a"(dK[kb]), "+a"(dV[kb]));
+        }
+    }
+    // both partial slots start as zeros: a wave without keys never writes its own, and step 0 "reduces" an empty buffer (every
+    // step then issues the same four atomics, which keeps the counted waits below uniform)
+#pragma unroll
+    for (int buf = 0; buf < 2; ++buf)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(sPart + buf * SP_PART + ((wave * 4 + g) * 64 + lane) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-query constants of a 128-query tile: wave 0 / 1 -> -lse of queries 0..63 / 64..127, wave 2 / 3 -> -delta
+    auto dma_stats = [&](int buf, int row0) {
+        const float* src = (wave < 2 ? nl_g : nd_g) + row0 + (wave & 1) * 64 + (lane & 15) * 4;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_vptr)((wave < 2 ? sL : sD) + buf * KT + (wave & 1) * 64));
+        if (lane < 16) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "m0");
+    };
+    const int nt = p.Lq / KT, nsteps = p.Lq / 32;   // launcher: Lq % 128 == 0
+    sp_barrier();                          // every wave is done with its staging quarter
+    dma_tile_async(sQ, Q, p.ldq, 0, wave, lane);
+    dma_tile_async(sdO, dO, p.lddo, 0, wave, lane);
+    dma_stats(0, 0);
+    dma_wait_all();
+    sp_barrier();
+
+    // the sum over the four waves of one row group (rows 8 wave + 4 h + e of the step's 32 queries) of the partials in `buf`,
+    // added to the fp32 image: lanes 0..31 / 32..63 = the 128 contiguous bytes of two rows
+    const int dq_lane = (8 * wave + 4 * h) * dqw + r;
+    auto reduce_step = [&](int buf, int qbase) {
+        const char* pb = sPart + buf * SP_PART + (wave * 64 + lane) * 16;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(pb);
+#pragma unroll
+        for (int w2 = 1; w2 < 4; ++w2) acc += *reinterpret_cast<const f32x4*>(pb + w2 * 4 * 64 * 16);
+        float* dst = dq32 + (int64_t)qbase * dqw + dq_lane;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e * dqw, acc[e]);
+    };
+
+    for (int st = 0; st < nsteps; ++st) {
+        const int sub = st & 3, t = st >> 2, cur = t & 1;
+        if (sub == 0 && t + 1 < nt) {      // the other tile buffers were last read in step st - 1, behind that step's barrier
+            dma_tile_async(sQ + (cur ^ 1) * IMG, Q, p.ldq, (t + 1) * KT, wave, lane);
+            dma_tile_async(sdO + (cur ^ 1) * IMG, dO, p.lddo, (t + 1) * KT, wave, lane);
+            dma_stats(cur ^ 1, (t + 1) * KT);
+            asm volatile("" ::: "memory");   // the atomics below stay BEHIND these five transfers (the counted vmcnt at the tile's end relies on it)
+        }
+        if (LIVE) {
+            const char* qimg = sQ + cur * IMG;
+            const char* doimg = sdO + cur * IMG;
+            uint4 qa[2], doa[2], qt[2], dot[2];
+            read_rows(qa, qimg, sub * 32 + r, h);
+            read_rows(doa, doimg, sub * 32 + r, h);
+            const f32x16 Cl = rows16(sL + cur * KT, sub, h), Cd = rows16(sD + cur * KT, sub, h);
+            read_tr(qt, qimg, sub, lane);
+            read_tr(dot, doimg, sub, lane);
+            f32x16 dQp;
+            f32x16 S = sp_mma_c(qa, kbk[0], Cl), dP = sp_mma_c(doa, vbk[0], Cd);
+#pragma unroll
+            for (int kb = 0; kb < SP_KB; ++kb) {
+                f32x16 Sn, dPn;
+                if (kb + 1 < SP_KB) {      // the next block's products go out ahead of this block's vector work
+                    Sn = sp_mma_c(qa, kbk[kb + 1], Cl);
+                    dPn = sp_mma_c(doa, vbk[kb + 1], Cd);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // S / dP of THIS block are read below: at least four MFMAs behind their own
+#pragma unroll
+                for (int i = 0; i < 16; ++i) S[i] = __builtin_amdgcn_exp2f(S[i]);
+                uint4 pk[2];
+                pack16(pk, S);
+                sp_mma_acc(dV[kb], dot, pk);          // dV^T += dO^T P
+#pragma unroll
+                for (int i = 0; i < 16; ++i) S[i] *= dP[i];
+                pack16(pk, S);
+                sp_mma_acc(dK[kb], qt, pk);           // dK^T += Q^T dS
+                char* img = sT + kb * 2048;
+                *reinterpret_cast<uint2*>(img + ds_off(r, 0, h)) = make_uint2(pk[0].x, pk[0].y);
+                *reinterpret_cast<uint2*>(img + ds_off(r, 1, h)) = make_uint2(pk[0].z, pk[0].w);
+                *reinterpret_cast<uint2*>(img + ds_off(r, 2, h)) = make_uint2(pk[1].x, pk[1].y);
+                *reinterpret_cast<uint2*>(img + ds_off(r, 3, h)) = make_uint2(pk[1].z, pk[1].w);
+                if (kb > 0) {                          // dQ += dS K of the PREVIOUS block: its image has long been written
+                    uint4 a[2];
+                    read_ds_tr(a, sT + (kb - 1) * 2048, lane);
+                    if (kb == 1) sp_mma_dq<true>(dQp, a, kd[0]);
+                    else sp_mma_dq<false>(dQp, a, kd[kb - 1]);
+                }
+                if (kb + 1 < SP_KB) { S = Sn; dP = dPn; }
+            }
+            {
+                uint4 a[2];
+                read_ds_tr(a, sT + (SP_KB - 1) * 2048, lane);
+                sp_mma_dq<false>(dQp, a, kd[SP_KB - 1]);
+            }
+            // the previous step's partials (published by the last barrier) leave as atomics while the last products finish: the
+            // partial below is read from MFMA results by ds_write (MFMA -> non-MFMA read: tests/test_isa_hazards.py)
+            __builtin_amdgcn_sched_barrier(0);
+            reduce_step((st - 1) & 1, st > 0 ? (st - 1) * 32 : 0);
+            __builtin_amdgcn_sched_barrier(0);
+            char* pw = sPart + (st & 1) * SP_PART + (wave * 4 * 64 + lane) * 16;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4*>(pw + g * 64 * 16) = f32x4{dQp[4 * g], dQp[4 * g + 1], dQp[4 * g + 2], dQp[4 * g + 3]};
+        } else {
+            reduce_step((st - 1) & 1, st > 0 ? (st - 1) * 32 : 0);
+        }
+        // tile t + 1 (5 LDS-DMA instructions, issued at the top of this tile) is older than this tile's 16 atomics
+        if (sub == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        sp_barrier();
+    }
+    reduce_step((nsteps - 1) & 1, (nsteps - 1) * 32);
+    if (LIVE) {
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the last asm MFMAs' results are read by compiler-generated code below
+        h16_t* dKo = reinterpret_cast<h16_t*>(p.dk) + (int64_t)b * p.Lk * p.lddk + hh * 32;
+        h16_t* dVo = reinterpret_cast<h16_t*>(p.dv) + (int64_t)b * p.Lk * p.lddv + hh * 32;
+#pragma unroll
+        for (int kb = 0; kb < SP_KB; ++kb) {
+            store_acc(dK[kb], dKo, p.lddk, key0 + kb * 32 + r, true, 32, h, p.scale / p.premul);
+            store_acc(dV[kb], dVo, p.lddv, key0 + kb * 32 + r, true, 32, h, 1.f);
+        }
+    }
+}
+__global__ __launch_bounds__(256, 1) void attn_bwd_sp_bf16(Args p) {
+    __shared__ __attribute__((aligned(1024))) char smem[SP_LDS];
+    int xt, hh, b;
+    block_coords(p, xt, hh, b);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // wave-uniform (Lk % 128 == 0): the last workgroup of a head may own fewer than 512 keys; its key-less waves only help with
+    // staging, the reduction and the barriers (same number of barriers and vector-memory instructions on both paths)
+    if (xt * SP_KEYS + wave * SP_WKEYS < p.Lk) attn_bwd_sp_body<true>(p, smem, xt, hh, b);
+    else attn_bwd_sp_body<false>(p, smem, xt, hh, b);
+}
+
 }  // namespace
 
 // entry points used by attention.hip's C-ABI functions
@@ -1565,6 +1915,13 @@ static int plan_ksplit(int B, int H, int Lq, int Lk, int dh, int64_t ws_floats, 
     *tiles_per_split = tps;
     return ks;
 }
+// shapes the single-pass backward (attn_bwd_sp_bf16) serves: full 128-row tiles both ways, heads dealt to the XCDs, enough keys for
+// the 512-key workgroups to fill the chip (SVOL_ATTN_SP_MIN_LK lowers the bar: tests drive small shapes through it)
+static bool sp_shape_ok(int B, int H, int Lq, int Lk, int dh) {
+    static const bool no_sp = getenv("SVOL_ATTN_NO_SP") != nullptr;
+    static const int min_lk = getenv("SVOL_ATTN_SP_MIN_LK") ? atoi(getenv("SVOL_ATTN_SP_MIN_LK")) : 2 * SP_KEYS;
+    return !no_sp && dh == 32 && H <= 8 && (B * H) % 8 == 0 && Lq % KT == 0 && Lk % KT == 0 && Lk >= min_lk;
+}
 int64_t svol_attn_ws_floats_bf16(int B, int H, int Lq, int Lk, int dh) {
     int tps;
     const int ks = plan_ksplit(B, H, Lq, Lk, dh, INT64_MAX, &tps);
@@ -1572,7 +1929,9 @@ int64_t svol_attn_ws_floats_bf16(int B, int H, int Lq, int Lk, int dh) {
         // key-tile classes of the masked fast kernels (one int per (batch, key tile)), or the redo flags of the unmasked fast
         // forward (one int per workgroup: (batch, head, 128-query tile)) — whichever is larger
         const int64_t cls = (int64_t)B * ((Lk + KT - 1) / KT), redo = (int64_t)B * H * ((Lq + 127) / 128);
-        return cls > redo ? cls : redo;
+        const int64_t sp = sp_shape_ok(B, H, Lq, Lk, dh) ? (int64_t)B * Lq * H * dh : 0;   // fp32 dQ image of the single-pass backward
+        const int64_t m = cls > redo ? cls : redo;
+        return m > sp ? m : sp;
     }
     return (int64_t)ks * B * Lq * H * dh + (int64_t)ks * B * H * Lq * 2 + (int64_t)B * Lq * H * dh;
 }
@@ -1678,6 +2037,20 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
             hipLaunchKernelGGL(attn_bwd_dq_bf16_pre_masked, gq2, dim3(256), 0, s, pq);
             hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre_masked, gk2, dim3(256), 0, s, pk);
         } else {
+            if (pq.head_xcd && sp_shape_ok(B, H, Lq, Lk, dh) && ws && ws_bytes >= (int64_t)B * Lq * H * dh * 4) {
+                // single pass: row constants + zeroed fp32 dQ image, the key-stationary kernel, rounding of dQ
+                Args ps = pq;
+                const int64_t n = (int64_t)B * H * Lq;
+                ps.ws_dq = ws;
+                ps.nl2 = reinterpret_cast<unsigned*>(delta + n);     // here: plain fp32 -lse2
+                ps.nd2 = reinterpret_cast<unsigned*>(delta + 2 * n);  //       plain fp32 -delta
+                ps.nxt = (Lk + SP_KEYS - 1) / SP_KEYS;
+                ps.tail_last = (Lk % SP_KEYS != 0 && ps.nxt > 1) ? 1 : 0;
+                hipLaunchKernelGGL(attn_bwd_sp_prep_bf16, dim3((unsigned)((int64_t)B * Lq / 32)), dim3(256), 0, s, ps);
+                hipLaunchKernelGGL(attn_bwd_sp_bf16, dim3((unsigned)(B * H * ps.nxt)), dim3(256), 0, s, ps);
+                hipLaunchKernelGGL(attn_dq_round_bf16, dim3((unsigned)(((int64_t)B * Lq * H * 32 / 8 + 255) / 256)), dim3(256), 0, s, ps);
+                return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
+            }
             static const bool no_dq_rot = getenv("SVOL_ATTN_NO_DQ_ROT") != nullptr;
             pq.dq_rot = no_dq_rot ? 0 : 1;
             // delta is a 3 x [B,H,Lq] scratch: fp32 delta | -lse2 pairs | -delta pairs (the last two for the DMA dK/dV kernel)

@@ -1,0 +1,122 @@
+"""Static check of the hand-placed MFMA hazards of the single-pass attention backward (svol_amd/csrc/attention_bf16.hip,
+attn_bwd_sp_bf16).  Every MFMA of that kernel is inline asm, and hipcc pads nothing behind an asm statement: an MFMA result that a
+NON-MFMA instruction reads (v_exp on the score tile, v_mul on dP, ds_write of the dQ partial, v_accvgpr_read of dK / dV) needs
+NumPasses + 4 wait states on gfx950 (LLVM GCNHazardRecognizer: 12 for an 8-pass, 20 for a 16-pass XDL op).  The kernel keeps every such
+consumer dozens of instructions behind its producer by construction; this test compiles the file to assembly (no GPU needed, ~10 s) and
+measures the distance in the code hipcc really emitted, so a compiler or source change that moves a consumer up fails here, not as a
+rare wrong gradient."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(REPO, 'svol_amd', 'csrc', 'attention_bf16.hip')
+# Model: an XDL op of P passes needs P + 4 wait states before a non-MFMA reader (gfx950).  One instruction = one wait state, s_nop N =
+# N + 1, and an intervening MFMA = P: the matrix pipe is in order and fully paced (one 32x32x16 16-bit MFMA per 32 cycles = 8 passes
+# per SIMD, MI355X_MICROARCH.md), so when a later MFMA issues, every earlier one has finished its passes.  The 32x32x16 16-bit forms
+# are documented as 8-pass; the check must hold under P = 16 as well.
+PASSES = (8, 16)
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', shutil.which('hipcc')):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+def _regs(tok):
+    """'v[64:79]' / 'v12' / 'a[0:15]' -> (file, set of indices); anything else -> None"""
+    m = re.fullmatch(r'([va])\[(\d+):(\d+)\]', tok)
+    if m:
+        return m.group(1), set(range(int(m.group(2)), int(m.group(3)) + 1))
+    m = re.fullmatch(r'([va])(\d+)', tok)
+    if m:
+        return m.group(1), {int(m.group(2))}
+    return None
+
+
+def _parse(line):
+    line = line.split(';')[0].strip()
+    if not line or line.endswith(':') or line.startswith('.'):
+        return None
+    parts = line.split(None, 1)
+    ops = [t.strip() for t in parts[1].split(',')] if len(parts) > 1 else []
+    return parts[0], [t.split()[0] if t else t for t in ops]
+
+
+def _kernel_lines(asm, name):
+    i = asm.index(name + ':')
+    j = asm.index('.end_amdhsa_kernel', i)
+    return asm[i:j].split('\n')
+
+
+def _wait_states(op, ops, passes):
+    if op == 's_nop':
+        return int(ops[0], 0) + 1
+    if op.startswith('v_mfma'):
+        return passes
+    return 1
+
+
+def _check(lines, passes):
+    NEED = passes + 4
+    insts = [(n, _parse(l)) for n, l in enumerate(lines)]
+    insts = [(n, p) for n, p in insts if p]
+    worst = None
+    n_mfma = 0
+    for k, (n, (op, ops)) in enumerate(insts):
+        if not op.startswith('v_mfma'):
+            continue
+        n_mfma += 1
+        dst = _regs(ops[0])
+        assert dst, (op, ops)
+        states = 0
+        for n2, (op2, ops2) in insts[k + 1:]:
+            if op2.startswith('s_cbranch') or op2 in ('s_branch', 's_endpgm', 's_barrier'):
+                break          # a barrier costs far more than the hazard window; branches end the linear walk (loop bodies are long)
+            touched = [_regs(t) for t in ops2]
+            hit = any(t and t[0] == dst[0] and (t[1] & dst[1]) for t in touched)
+            if hit:
+                chain = op2.startswith('v_mfma') and len(ops2) >= 4 and _regs(ops2[3]) == dst and _regs(ops2[0]) == dst \
+                    and not any(_regs(t) and _regs(t)[0] == dst[0] and (_regs(t)[1] & dst[1]) for t in ops2[1:3])
+                if not chain:
+                    if worst is None or states < worst[0]:
+                        worst = (states, lines[n].strip(), lines[n2].strip())
+                    assert states >= NEED, f'{lines[n2].strip()!r} reads the result of {lines[n].strip()!r} after {states} wait states'
+                break          # (an accumulate chain restarts the walk from its own MFMA)
+            states += _wait_states(op2, ops2, passes)
+            if states > 4 * NEED:
+                break
+    return n_mfma, worst
+
+
+@pytest.mark.parametrize('flag', [[], ['-DSVOL_H16_FP16']], ids=['bf16', 'fp16'])
+def test_single_pass_backward_mfma_results_are_not_read_early(tmp_path, flag):
+    hipcc = _hipcc()
+    if hipcc is None:
+        pytest.skip('hipcc not found')
+    from svol_amd import build
+    out = str(tmp_path / 'attention.s')
+    cmd = [hipcc] + build.COMMON + build.PER_FILE.get('attention_bf16.hip', []) + flag + ['--cuda-device-only', '-S', SRC, '-o', out]
+    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+    asm = open(out).read()
+    name = [m for m in re.findall(r'^(_Z\w*attn_bwd_sp_bf16\w*):', asm, flags=re.M)]
+    assert name, 'attn_bwd_sp_bf16 not found in the assembly'
+    lines = _kernel_lines(asm, name[0])
+    for passes in PASSES:
+        n_mfma, worst = _check(lines, passes)
+        assert n_mfma >= 40                  # the loop body alone holds 40
+        assert worst is not None and worst[0] >= passes + 4
+    body = '\n'.join(lines)
+    # the whole point of the asm forms: no accumulator <-> vector register copies inside the loop, nothing spilled
+    meta = asm[asm.index('amdhsa.kernels'):]
+    k = meta[meta.index(name[0]):]
+    assert int(re.search(r'\.private_segment_fixed_size:\s*(\d+)', k).group(1)) == 0
+    assert int(re.search(r'\.vgpr_spill_count:\s*(\d+)', k).group(1)) == 0
+    assert body.count('v_accvgpr_read') <= 160 and body.count('v_accvgpr_write') <= 160   # prologue / epilogue only (128 accumulators)
+    assert 'cmpswap' not in body             # dQ leaves as global_atomic_add_f32, not a compare-and-swap loop
+    assert body.count('global_atomic_add_f32') >= 4
