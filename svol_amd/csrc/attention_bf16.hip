@@ -1564,7 +1564,7 @@ constexpr int SP_KB = 4;                    // 32-key blocks per wave
 constexpr int SP_WKEYS = 32 * SP_KB;        // keys per wave
 constexpr int SP_KEYS = 4 * SP_WKEYS;       // keys per workgroup
 constexpr int SP_PART = 4 * 4 * 64 * 16;    // one partial buffer: [wave][row group][lane] x 16 bytes
-constexpr int SP_LDS = 4 * IMG + 4 * IMG + 2 * SP_PART + 4 * KT * 4;
+constexpr int SP_LDS = 4 * IMG + 4 * IMG + 2 * SP_PART + 4 * KT * 4 + 512;
 
 // byte offset of the 8-byte unit (chunk g = q / 8, half = (q / 4) & 1) of row `key` in a [32 keys][32 q] 16-bit image with 64-byte
 // rows: 16-byte chunks and 8-byte halves XOR-ed with key bits so that the 16 lanes of a ds_write_b64 group (16 keys, one unit each)
@@ -1658,11 +1658,31 @@ __global__ __launch_bounds__(256) void attn_bwd_sp_prep_bf16(Args p) {
         }
     }
 }
-// after it: dq (16-bit) = scale * fp32 image
+// after it: dq (16-bit) = scale * fp32 image; dk / dv of a head's tail keys (Lk % 512 of them) = the sum of the four query-quarter
+// partials the tail workgroups left behind the image (blocks past the image's)
 __global__ __launch_bounds__(256) void attn_dq_round_bf16(Args p) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;   // 8 consecutive columns of one row
     const int64_t W = (int64_t)p.H * 32, total = (int64_t)p.B * p.Lq * W;
-    if (i >= total) return;
+    if (i >= total) {
+        const int tk = p.Lk % (4 * 128);
+        const int64_t j = i - ((total + 2047) / 2048) * 2048;               // 8 consecutive d of one (head, dk | dv, key)
+        if (tk == 0 || j < 0 || j >= (int64_t)p.B * p.H * 2 * tk * 32) return;
+        const int64_t per = (int64_t)2 * tk * 32;
+        const int bh = (int)(j / per), rem = (int)(j % per), kv = rem / (tk * 32), key = (rem / 32) % tk, d0 = rem % 32;
+        const float* src = p.ws_dq + total + (int64_t)bh * 4 * per + rem;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = a;
+#pragma unroll
+        for (int part = 0; part < 4; ++part) { a += *reinterpret_cast<const f32x4*>(src + part * per); c += *reinterpret_cast<const f32x4*>(src + part * per + 4); }
+        const float mul = kv == 0 ? p.scale / p.premul : 1.f;
+        h16x8 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = (h16_t)(a[e] * mul); v[4 + e] = (h16_t)(c[e] * mul); }
+        const int b_ = bh / p.H, hh_ = bh % p.H;
+        const int64_t row = (int64_t)b_ * p.Lk + (p.Lk - tk) + key;
+        h16_t* o = kv == 0 ? reinterpret_cast<h16_t*>(p.dk) + row * p.lddk : reinterpret_cast<h16_t*>(p.dv) + row * p.lddv;
+        *reinterpret_cast<h16x8*>(o + hh_ * 32 + d0) = v;
+        return;
+    }
     const int64_t row = i / W, c = i % W;
     const f32x4 a = *reinterpret_cast<const f32x4*>(p.ws_dq + i), b = *reinterpret_cast<const f32x4*>(p.ws_dq + i + 4);
     h16x8 v;
@@ -1674,74 +1694,99 @@ __global__ __launch_bounds__(256) void attn_dq_round_bf16(Args p) {
 // Every MFMA of the single-pass kernel is inline asm: at one wave per SIMD (512 registers) hipcc selects the AGPR-destination form
 // for the builtin, so score / dP tiles that the VALU exponentiates would pay a v_accvgpr_read per element.  Register classes by
 // constraint: results the VALU touches "v", the dK / dV accumulators and the loop-invariant K / V fragments "a".
-// HAZARDS are ours inside and behind an asm statement (hipcc pads nothing): s_nop 1 in front = VALU-written operand -> MFMA read;
-// an MFMA result must not be read by a non-MFMA instruction for 12 wait states — the loop below keeps every such consumer dozens of
-// instructions behind its producer, and tests/test_isa_hazards.py checks the distance in the emitted code.
+// One MFMA per statement, and the statements are placed BY HAND between chunks of vector work (sched_barrier(0) on both sides): a
+// single wave issues in order, so a cluster of MFMAs stalls on the matrix pipe (32 cycles each) while the vector work behind it
+// waits, and a cluster of vector work leaves the pipe idle — the first version of this kernel, scheduled by hipcc, ran the two as a
+// plain sum (840 cycles per 32 x 32 block).  Per block: 10 MFMAs (80 issue cycles) + ~296 cycles of exp / multiply / convert / LDS
+// issue, i.e. one MFMA every ~37 cycles with ~30 cycles of fillers behind it.
+// HAZARDS are ours inside and behind an asm statement (hipcc pads nothing): a VALU-written operand needs 2 wait states before the
+// MFMA that reads it (every such MFMA below sits >= 2 instructions behind the conversion that feeds it); an MFMA result must not be
+// read by a non-MFMA instruction for passes + 4 wait states — every such consumer is at least four MFMAs behind its producer.
+// tests/test_isa_hazards.py checks both distances in the emitted code.
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 __device__ __forceinline__ u32x4 to_acc(u32x4 r) {
     asm volatile("; operand -> AGPR" : "+a"(r));
     return r;
 }
 __device__ __forceinline__ u32x4 as_u32x4(const uint4& v) { return u32x4{v.x, v.y, v.z, v.w}; }
-// D = A B + C, two k-steps, B fragments in AGPRs, D and C different VGPR ranges
-__device__ __forceinline__ f32x16 sp_mma_c(const uint4 (&a)[2], const u32x4 (&b)[2], const f32x16& c0) {
-    f32x16 acc;
-    asm("s_nop 1\n\tv_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %1, %2, %5\n\tv_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %3, %4, %0"
-        : "=&v"(acc)
-        : "v"(as_u32x4(a[0])), "a"(b[0]), "v"(as_u32x4(a[1])), "a"(b[1]), "v"(c0));
-    return acc;
+#define SP_FENCE() __builtin_amdgcn_sched_barrier(0)
+// D (VGPRs) = A B + C, B in AGPRs, D and C different ranges
+__device__ __forceinline__ void sp_mfma_c(f32x16& d, const uint4& a, const u32x4& b, const f32x16& c) {
+    asm volatile("v_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %1, %2, %3" : "=&v"(d) : "v"(as_u32x4(a)), "a"(b), "v"(c));
 }
-// acc (AGPRs) += A B, two k-steps, both operands in VGPRs (B fresh from v_cvt_pk)
-__device__ __forceinline__ void sp_mma_acc(f32x16& acc, const uint4 (&a)[2], const uint4 (&b)[2]) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %1, %2, %0\n\tv_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %3, %4, %0"
-                 : "+a"(acc)
-                 : "v"(as_u32x4(a[0])), "v"(as_u32x4(b[0])), "v"(as_u32x4(a[1])), "v"(as_u32x4(b[1])));
+// D (VGPRs) = A B (C = the inline constant 0), B in AGPRs
+__device__ __forceinline__ void sp_mfma_z(f32x16& d, const uint4& a, const u32x4& b) {
+    asm volatile("v_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %1, %2, 0" : "=&v"(d) : "v"(as_u32x4(a)), "a"(b));
 }
-// dQ partial (VGPRs): FIRST = A B (C is the inline constant 0), then += A B; B (K fragments) in AGPRs
-template <bool FIRST>
-__device__ __forceinline__ void sp_mma_dq(f32x16& acc, const uint4 (&a)[2], const u32x4 (&b)[2]) {
-    if (FIRST)
-        asm volatile("v_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %1, %2, 0\n\tv_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %3, %4, %0"
-                     : "=&v"(acc)
-                     : "v"(as_u32x4(a[0])), "a"(b[0]), "v"(as_u32x4(a[1])), "a"(b[1]));
-    else
-        asm volatile("v_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %1, %2, %0\n\tv_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %3, %4, %0"
-                     : "+v"(acc)
-                     : "v"(as_u32x4(a[0])), "a"(b[0]), "v"(as_u32x4(a[1])), "a"(b[1]));
+// D (VGPRs) += A B, B in AGPRs
+__device__ __forceinline__ void sp_mfma_v(f32x16& d, const uint4& a, const u32x4& b) {
+    asm volatile("v_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %1, %2, %0" : "+v"(d) : "v"(as_u32x4(a)), "a"(b));
 }
+// acc (AGPRs) += A B, both operands in VGPRs
+__device__ __forceinline__ void sp_mfma_a(f32x16& acc, const uint4& a, const u32x4& b) {
+    asm volatile("v_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %1, %2, %0" : "+a"(acc) : "v"(as_u32x4(a)), "v"(b));
+}
+__device__ __forceinline__ unsigned cvt_pk_u32(float a, float b) { return __builtin_bit_cast(unsigned, cvt_pk_h16(a, b)); }
 
-template <bool LIVE>
-__device__ __forceinline__ void attn_bwd_sp_body(const Args& p, char* smem, int xt, int hh, int b) {
+// A operands (rows of Q and dO) and row constants (-lse, -delta as initial accumulators) of one 32-query step
+struct SpStep {
+    uint4 qa[2], doa[2];
+    f32x16 Cl, Cd;
+};
+constexpr int SP_OFF_Q = 4 * KT * 4 + 512;        // LDS map: [2][KT] -lse2 | [2][KT] -delta | [KT] -inf | Q tiles | dO tiles | dS | partials
+constexpr int SP_OFF_T = SP_OFF_Q + 4 * IMG;
+constexpr int SP_OFF_P = SP_OFF_Q + 8 * IMG;
+
+// NKB = 32-key blocks per wave: 4 in every full workgroup (512 keys); the last workgroup of a head whose key count is not a multiple
+// of 512 spreads its 128 / 256 / 384 keys over all four waves (NKB = 1 / 2 / 3) instead of leaving waves without work.
+//
+// The kernel is ONE uniform stream of blocks j = step * NKB + kb (32 queries x 32 keys each).  Block j
+//   * issues the score / dP products of block j + 1 (slots 1-4; across a step boundary they use the next step's operands, which were
+//     fetched from LDS as soon as the last products of the current step had been issued),
+//   * exponentiates, multiplies and converts its own tiles between the MFMAs and feeds dV / dK (slots 5, 7, 9, 10), writes its packed
+//     dS to the wave's LDS image and reads it back transposed,
+//   * runs the dQ product of block j - 2 (slots 6, 8): a transposed read is consumed a whole block after it was issued.
+// The dQ partial of a step is therefore complete in block 1 of the NEXT step (block 0 two steps later when NKB = 1): it is written to LDS
+// there, published by that step's barrier and added to the fp32 image (atomics) one step later.  DW + 1 extra DRAIN steps flush the
+// pipeline: their row constant is -inf, so P = dS = 0 and the accumulators do not move — no epilogue code, no special cases.
+// ABL: timing-only ablations for tools/micro/attn_lab_sp (results invalid): 1 no vector fillers, 2 no MFMAs, 4 no step barrier,
+// 8 no dS round trip through LDS, 16 no tile DMA / waits.  The product instantiates ABL = 0 only.
+//
+// hh, b: head, batch.  kbase: first key of the workgroup.  [t_begin, t_end): the 128-query tiles it sweeps — all of them for a full
+// workgroup; the tail workgroup of a head (fewer than 512 keys, NKB < 4) exists FOUR times, each sweeping a quarter of the tiles and
+// leaving its dK / dV as an fp32 partial in `tail_out` (attn_dq_round_bf16 adds the four): a tail of 128 keys then costs a sixth of a
+// full workgroup's time instead of 0.6 of it (measured), which is what the partial fourth round of workgroups cost the launch.
+template <int NKB, int ABL = 0>
+__device__ __forceinline__ void attn_bwd_sp_body(const Args& p, char* smem, int hh, int b, int kbase, int t_begin, int t_end, float* tail_out) {
     // every LDS-DMA destination (row constants, Q / dO tiles, the prologue's K / V staging) sits in the first 64 KiB: the existing
     // kernels never put an M0 base above 0xFFFF, and nothing here depends on how many bits of M0 the transfer honours
     float* sL = reinterpret_cast<float*>(smem);   // [2][KT] -lse2
     float* sD = sL + 2 * KT;                      // [2][KT] -delta
-    char* sQ = smem + 4 * KT * 4;          // [2][IMG]   Q tiles (128 queries)
-    char* sdO = sQ + 2 * IMG;              // [2][IMG]   dO tiles
-    char* sTall = sQ + 4 * IMG;            // [4 waves][4 blocks][32 keys][32 q] dS images
-    char* sPart = sQ + 8 * IMG;            // [2][SP_PART] dQ partials
+    float* sNeg = sL + 4 * KT;                    // [KT]    -inf (drain steps)
+    char* sQ = smem + SP_OFF_Q;            // [2][IMG]   Q tiles (128 queries); dO tiles 2 * IMG behind
+    char* sPart = smem + SP_OFF_P;         // [2][SP_PART] dQ partials
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    constexpr int dqw = 8 * 32;            // launcher: H == 8 (row pitch of the fp32 dQ image: immediates instead of address arithmetic)
     const h16_t* Q = reinterpret_cast<const h16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * 32;
     const h16_t* dO = reinterpret_cast<const h16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * 32;
     const h16_t* K = reinterpret_cast<const h16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * 32;
     const h16_t* V = reinterpret_cast<const h16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * 32;
     const float* nl_g = reinterpret_cast<const float*>(p.nl2) + ((int64_t)b * p.H + hh) * p.Lq;
     const float* nd_g = reinterpret_cast<const float*>(p.nd2) + ((int64_t)b * p.H + hh) * p.Lq;
-    const int dqw = p.H * 32;
-    float* dq32 = p.ws_dq + (int64_t)b * p.Lq * dqw + hh * 32;
-    const int key0 = xt * SP_KEYS + wave * SP_WKEYS;
-    char* sT = sTall + wave * IMG;
+    const int key0 = kbase + wave * 32 * NKB;
+    char* sT = smem + SP_OFF_T + wave * IMG;   // this wave's dS images: [NKB][32 keys][32 q]
+    const int ntl = t_end - t_begin;       // tiles of this workgroup (>= 1)
 
-    u32x4 kbk[SP_KB][2], vbk[SP_KB][2], kd[SP_KB][2];
-    f32x16 dK[SP_KB], dV[SP_KB];
-    if (LIVE) {   // this wave's K tile, then its V tile, through ITS quarter of the (still unused) Q / dO buffers
+    u32x4 kbk[NKB][2], vbk[NKB][2], kd[NKB][2];
+    f32x16 dK[NKB], dV[NKB];
+    {   // this wave's K rows, then its V rows, through ITS quarter of the (still unused) Q / dO buffers
         char* sS = sQ + wave * IMG;
 #pragma unroll
-        for (int pc = 0; pc < 8; ++pc) dma_piece(sS, K, p.ldk, key0, pc, lane);
+        for (int pc = 0; pc < 2 * NKB; ++pc) dma_piece(sS, K, p.ldk, key0, pc, lane);
         dma_wait_all();
 #pragma unroll
-        for (int kb = 0; kb < SP_KB; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
             uint4 t0[2], t1[2];
             read_rows(t0, sS, kb * 32 + r, h);
             read_tr_nat(t1, sS, kb, lane);
@@ -1750,10 +1795,10 @@ __device__ __forceinline__ void attn_bwd_sp_body(const Args& p, char* smem, int 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int pc = 0; pc < 8; ++pc) dma_piece(sS, V, p.ldv, key0, pc, lane);
+        for (int pc = 0; pc < 2 * NKB; ++pc) dma_piece(sS, V, p.ldv, key0, pc, lane);
         dma_wait_all();
 #pragma unroll
-        for (int kb = 0; kb < SP_KB; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
             uint4 t0[2];
             read_rows(t0, sS, kb * 32 + r, h);
 #pragma unroll
@@ -1761,139 +1806,315 @@ __device__ __forceinline__ void attn_bwd_sp_body(const Args& p, char* smem, int 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int kb = 0; kb < SP_KB; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
             dK[kb] = zero16();
             dV[kb] = zero16();
             asm volatile("; accumulators -> AGPR" : "+a"(dK[kb]), "+a"(dV[kb]));
         }
     }
-    // both partial slots start as zeros: a wave without keys never writes its own, and step 0 "reduces" an empty buffer (every
-    // step then issues the same four atomics, which keeps the counted waits below uniform)
+    // both partial slots start as zeros (the first steps "reduce" empty buffers: every step issues the same four atomics, which
+    // keeps the counted waits uniform); the -inf row constants of the drain steps
 #pragma unroll
     for (int buf = 0; buf < 2; ++buf)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<f32x4*>(sPart + buf * SP_PART + ((wave * 4 + g) * 64 + lane) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < KT) sNeg[tid] = -INFINITY;
 
-    // per-query constants of a 128-query tile: wave 0 / 1 -> -lse of queries 0..63 / 64..127, wave 2 / 3 -> -delta
-    auto dma_stats = [&](int buf, int row0) {
-        const float* src = (wave < 2 ? nl_g : nd_g) + row0 + (wave & 1) * 64 + (lane & 15) * 4;
-        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_vptr)((wave < 2 ? sL : sD) + buf * KT + (wave & 1) * 64));
-        if (lane < 16) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "m0");
+    // ---- addresses: everything lane dependent is computed ONCE; a step adds scalars ----
+    // LDS-DMA sources of this wave's two 16-row pieces of a tile (dma_piece's address arithmetic), tile t_begin
+    const int prow = t_begin * KT + 32 * wave + (lane >> 2), pch = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
+    const h16_t* gq = Q + (int64_t)prow * p.ldq + pch;
+    const h16_t* gdo = dO + (int64_t)prow * p.lddo + pch;
+    const float* gst = (wave < 2 ? nl_g : nd_g) + t_begin * KT + (wave & 1) * 64 + (lane & 15) * 4;
+    const unsigned lds_q = (unsigned)(size_t)(lds_vptr)sQ + wave * 2048, lds_st = (unsigned)(size_t)(lds_vptr)((wave < 2 ? sL : sD) + (wave & 1) * 64);
+    auto dma_tile_at = [&](int tl, int buf) {   // local tile tl -> buffer buf: 5 vector-memory instructions per wave
+        const h16_t* a = gq + (int64_t)tl * KT * p.ldq;
+        const h16_t* c = gdo + (int64_t)tl * KT * p.lddo;
+        const unsigned dq_ = __builtin_amdgcn_readfirstlane(lds_q + buf * IMG), dd_ = dq_ + 2 * IMG;
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dq_), "v"(a) : "m0");
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dq_ + 1024), "v"(a + 16 * p.ldq) : "m0");
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dd_), "v"(c) : "m0");
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dd_ + 1024), "v"(c + 16 * p.lddo) : "m0");
+        const unsigned ds_ = __builtin_amdgcn_readfirstlane(lds_st + buf * KT * 4);
+        const float* e = gst + tl * KT;
+        if (lane < 16) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(ds_), "v"(e) : "m0");
     };
-    const int nt = p.Lq / KT, nsteps = p.Lq / 32;   // launcher: Lq % 128 == 0
-    sp_barrier();                          // every wave is done with its staging quarter
-    dma_tile_async(sQ, Q, p.ldq, 0, wave, lane);
-    dma_tile_async(sdO, dO, p.lddo, 0, wave, lane);
-    dma_stats(0, 0);
+    // byte offsets inside a tile image, without the 32-row sub-tile (+ sub * 2048): img_off(32 sub + x, ch) = 2048 sub + img_off(x, ch)
+    // for every x < 32 — the swizzle only looks at bits 2-3 of the row
+    const unsigned o_rows0 = img_off(r, h), o_rows1 = img_off(r, 2 + h);                     // read_rows, k-step 0 / 1
+    unsigned o_trl, o_trh;                                                                     // read_tr: lo / hi row groups (k-step 1: + 1024)
+    {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, h2 = g >> 1;
+        const int ch = 2 * (g & 1) + (pp >> 1), inner = 8 * (pp & 1);
+        o_trl = img_off(4 * h2 + q, ch) + inner;
+        o_trh = img_off(4 * h2 + q + 8, ch) + inner;
+    }
+    const unsigned o_st = 16 * h;                                                              // rows16: + 128 sub + 32 g
+    auto tr_pair = [&](uint4 (&a)[2], const char* img) {   // = read_tr(a, tile image, sub, lane) with img = tile image + 2048 sub
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const h16x4 lo = SVOL_DS_READ_TR16_H16((lds_bf16x4_ptr)(img + o_trl + 1024 * s));
+            const h16x4 hi = SVOL_DS_READ_TR16_H16((lds_bf16x4_ptr)(img + o_trh + 1024 * s));
+            a[s] = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    };
+    // operands of step (local tile tl, sub-tile sub); tiles past the end are DRAIN tiles: any resident rows, -inf as the score constant
+    auto load_step = [&](SpStep& f, int tl, int sub, bool drain) {
+        const int cur = (drain ? ntl - 1 : tl) & 1;
+        const char* qi = sQ + cur * IMG + sub * 2048;
+        f.qa[0] = *reinterpret_cast<const uint4*>(qi + o_rows0);
+        f.qa[1] = *reinterpret_cast<const uint4*>(qi + o_rows1);
+        f.doa[0] = *reinterpret_cast<const uint4*>(qi + 2 * IMG + o_rows0);
+        f.doa[1] = *reinterpret_cast<const uint4*>(qi + 2 * IMG + o_rows1);
+        const char* cl = drain ? reinterpret_cast<const char*>(sNeg) : reinterpret_cast<const char*>(sL) + cur * KT * 4 + sub * 128;
+        const char* cd = reinterpret_cast<const char*>(sD) + cur * KT * 4 + sub * 128;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(cl + o_st + 32 * g), c = *reinterpret_cast<const f32x4*>(cd + o_st + 32 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { f.Cl[4 * g + e] = a[e]; f.Cd[4 * g + e] = c[e]; }
+        }
+    };
+    // the wave's dS image: where this lane writes its four 8-byte units, and where it reads them back transposed
+    unsigned o_w[4], o_rl, o_rh;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) o_w[g] = ds_off(r, g, h);
+    {
+        const int gg = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3, h2 = gg >> 1;
+        o_rl = ds_off(8 * h2 + qq, 2 * (gg & 1) + (pp >> 1), pp & 1);          // k-step 1: + 1024 (keys + 16: same swizzle bits)
+        o_rh = ds_off(8 * h2 + qq + 4, 2 * (gg & 1) + (pp >> 1), pp & 1);
+    }
+    // the sum over the four waves of one row group (rows 8 wave + 4 h + e of a step's 32 queries) of the partials in `buf`, added
+    // to the fp32 image: lanes 0..31 / 32..63 = the 128 contiguous bytes of two rows
+    float* dq_base = p.ws_dq + ((int64_t)b * p.Lq + (int64_t)t_begin * KT) * dqw + hh * 32;   // (uniform)
+    const int dq_lane = (8 * wave + 4 * h) * dqw + r;
+    const char* pr_base = sPart + (wave * 64 + lane) * 16;
+    auto reduce_load = [&](f32x4 (&v)[4], int buf) {
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) v[w2] = *reinterpret_cast<const f32x4*>(pr_base + buf * SP_PART + w2 * 4 * 64 * 16);
+    };
+    auto reduce_add = [&](const f32x4 (&v)[4], int qstep) {   // qstep: local step whose partial this is (< 0: an empty buffer)
+        const f32x4 acc = (v[0] + v[1]) + (v[2] + v[3]);
+        float* dst = dq_base + (int64_t)(qstep > 0 ? qstep : 0) * 32 * dqw + dq_lane;
+#ifdef SP_ABLATE   // lab only (tools/micro/attn_lab_sp -DSP_ABLATE=1): plain stores in place of the atomics — same instruction and vmcnt counts
+#pragma unroll
+        for (int e = 0; e < 4; ++e) __builtin_nontemporal_store(acc[e], dst + e * dqw);
+#else
+#pragma unroll
+        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e * dqw, acc[e]);
+#endif
+    };
+
+    sp_barrier();                          // every wave is done with its staging quarter; zeros / -inf are in place
+    dma_tile_at(0, 0);
+    if (ntl > 1) dma_tile_at(1, 1);        // (with one wave per SIMD nothing hides a late tile: two tiles ahead from the start)
     dma_wait_all();
     sp_barrier();
 
-    // the sum over the four waves of one row group (rows 8 wave + 4 h + e of the step's 32 queries) of the partials in `buf`,
-    // added to the fp32 image: lanes 0..31 / 32..63 = the 128 contiguous bytes of two rows
-    const int dq_lane = (8 * wave + 4 * h) * dqw + r;
-    auto reduce_step = [&](int buf, int qbase) {
-        const char* pb = sPart + buf * SP_PART + (wave * 64 + lane) * 16;
-        f32x4 acc = *reinterpret_cast<const f32x4*>(pb);
+    constexpr int DW = NKB == 1 ? 2 : 1;   // a step's dQ partial is written DW steps later
+    constexpr int KBW = NKB == 1 ? 0 : 1;  //   ... at the end of this block
+    constexpr int AHEAD = NKB == 1 ? 2 : 1;   // how many steps ahead the operand fetch runs
+    SpStep f;                  // operands of the step whose products are issued next
+    f32x16 S, dP;              // score - lse / dP - delta of the block that is processed next
+    load_step(f, 0, 0, false);
+    sp_mfma_c(S, f.qa[0], kbk[0][0], f.Cl);
+    sp_mfma_v(S, f.qa[1], kbk[0][1]);
+    sp_mfma_c(dP, f.doa[0], vbk[0][0], f.Cd);
+    sp_mfma_v(dP, f.doa[1], vbk[0][1]);
+    SP_FENCE();
+    if (NKB == 1) load_step(f, 0, 1, false);   // (NKB == 1: a block's "next block" is always the next step's)
+    uint4 dsa0[2], dsa1[2];                // dS^T fragments of the two previous blocks (older first)
 #pragma unroll
-        for (int w2 = 1; w2 < 4; ++w2) acc += *reinterpret_cast<const f32x4*>(pb + w2 * 4 * 64 * 16);
-        float* dst = dq32 + (int64_t)qbase * dqw + dq_lane;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e * dqw, acc[e]);
-    };
+    for (int s = 0; s < 2; ++s) dsa0[s] = dsa1[s] = make_uint4(0, 0, 0, 0);
+    f32x16 dQp = zero16();
 
-    for (int st = 0; st < nsteps; ++st) {
-        const int sub = st & 3, t = st >> 2, cur = t & 1;
-        if (sub == 0 && t + 1 < nt) {      // the other tile buffers were last read in step st - 1, behind that step's barrier
-            dma_tile_async(sQ + (cur ^ 1) * IMG, Q, p.ldq, (t + 1) * KT, wave, lane);
-            dma_tile_async(sdO + (cur ^ 1) * IMG, dO, p.lddo, (t + 1) * KT, wave, lane);
-            dma_stats(cur ^ 1, (t + 1) * KT);
-            asm volatile("" ::: "memory");   // the atomics below stay BEHIND these five transfers (the counted vmcnt at the tile's end relies on it)
+    // one iteration = one 128-query tile = four steps with a compile-time sub-tile; iteration ntl is the DRAIN tile (4 >= DW + 1 steps)
+    for (int tl = 0; tl <= ntl; ++tl) {
+        const bool drain = tl == ntl;
+        const char* qtile = sQ + ((drain ? ntl - 1 : tl) & 1) * IMG;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+        const int st = 4 * tl + sub;
+        if (!(ABL & 16) && sub == 0 && tl >= 1 && tl + 1 < ntl) {   // the other tile buffers were last read in the step before, behind its barrier
+            dma_tile_at(tl + 1, (tl + 1) & 1);
+            asm volatile("" ::: "memory");   // the atomics below stay BEHIND these five transfers (the counted vmcnt below relies on it)
         }
-        if (LIVE) {
-            const char* qimg = sQ + cur * IMG;
-            const char* doimg = sdO + cur * IMG;
-            uint4 qa[2], doa[2], qt[2], dot[2];
-            read_rows(qa, qimg, sub * 32 + r, h);
-            read_rows(doa, doimg, sub * 32 + r, h);
-            const f32x16 Cl = rows16(sL + cur * KT, sub, h), Cd = rows16(sD + cur * KT, sub, h);
-            read_tr(qt, qimg, sub, lane);
-            read_tr(dot, doimg, sub, lane);
-            f32x16 dQp;
-            f32x16 S = sp_mma_c(qa, kbk[0], Cl), dP = sp_mma_c(doa, vbk[0], Cd);
+        const int subn = (sub + AHEAD) & 3, tn = tl + (sub + AHEAD >= 4 ? 1 : 0);   // the step whose operands this step fetches
+        uint4 qt[2], dot[2];               // transposed A operands of this step's dV / dK products
+        tr_pair(qt, qtile + sub * 2048);
+        tr_pair(dot, qtile + 2 * IMG + sub * 2048);
+        f32x4 red[4];
+        reduce_load(red, (sub - DW - 1) & 1);   // the partial published by the last barrier
 #pragma unroll
-            for (int kb = 0; kb < SP_KB; ++kb) {
-                f32x16 Sn, dPn;
-                if (kb + 1 < SP_KB) {      // the next block's products go out ahead of this block's vector work
-                    Sn = sp_mma_c(qa, kbk[kb + 1], Cl);
-                    dPn = sp_mma_c(doa, vbk[kb + 1], Cd);
-                }
-                __builtin_amdgcn_sched_barrier(0);   // S / dP of THIS block are read below: at least four MFMAs behind their own
+        for (int kb = 0; kb < NKB; ++kb) {
+            const int kn = kb + 1 < NKB ? kb + 1 : 0;    // key block of the NEXT block in the stream
+            const int ks = (kb + 2 * NKB - 2) % NKB;     // key block whose dQ product runs here (the block two back in the stream)
+            f32x16 Sn, dPn;
+            u32x4 pw0, pw1, dw0, dw1;      // P / dS of this block, packed: the B operands of the dV / dK products
+            char* img = sT + kb * 2048;
+            // Pure vector instructions carry no ordering against an asm statement or a sched_barrier in instruction selection — hipcc
+            // moved conversions right in front of the MFMA that reads them (VALU write -> MFMA read hazard: NaNs in dK / dV) and
+            // emptied the filler slots; pinning them with empty asm statements costs an s_nop behind every statement.  So the fillers
+            // are asm volatile too: volatile statements keep their order, the instruction stream of a block IS the source below.
+            // (Hazards then ours: v_exp result -> VALU read 1 wait state, VALU write -> MFMA operand 2: see the slot comments.)
+#define SP_SLOT(stmt) do { SP_FENCE(); if (!(ABL & 2)) { stmt; } SP_FENCE(); } while (0)
+#define SP_E(i) do { if (!(ABL & 1)) asm volatile("v_exp_f32 %0, %0" : "+v"(S[i])); } while (0)
+#define SP_CP(j) if (!(ABL & 1)) asm volatile("v_cvt_pk_" SVOL_H16_ASM "_f32 %0, %1, %2" : "=v"(((j) < 4 ? pw0 : pw1)[(j) & 3]) : "v"(S[2 * (j)]), "v"(S[2 * (j) + 1]))
+#define SP_M2(i) do { if (ABL & 1) break; f32x2 d_ = {dP[i], dP[(i) + 1]}; const f32x2 s_ = {S[i], S[(i) + 1]}; asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(d_) : "v"(s_)); dP[i] = d_[0]; dP[(i) + 1] = d_[1]; } while (0)
+#define SP_CD(j) if (!(ABL & 1)) asm volatile("v_cvt_pk_" SVOL_H16_ASM "_f32 %0, %1, %2" : "=v"(((j) < 4 ? dw0 : dw1)[(j) & 3]) : "v"(dP[2 * (j)]), "v"(dP[2 * (j) + 1]))
+#define SP_W(g) if (!(ABL & 8)) *reinterpret_cast<uint2*>(img + o_w[g]) = (g) < 2 ? make_uint2(dw0[2 * ((g) & 1)], dw0[2 * ((g) & 1) + 1]) \
+                                                                  : make_uint2(dw1[2 * ((g) & 1)], dw1[2 * ((g) & 1) + 1])
+            // slot 1
+            SP_SLOT(sp_mfma_c(Sn, f.qa[0], kbk[kn][0], f.Cl));
+            SP_E(0); SP_E(1); SP_E(2); SP_E(3);
+            // slot 2
+            SP_SLOT(sp_mfma_v(Sn, f.qa[1], kbk[kn][1]));
+            SP_CP(0); SP_CP(1); SP_E(4); SP_E(5); SP_M2(0);
+            // slot 3
+            SP_SLOT(sp_mfma_c(dPn, f.doa[0], vbk[kn][0], f.Cd));
+            SP_E(6); SP_E(7); SP_CP(2); SP_CP(3);
+            // slot 4
+            SP_SLOT(sp_mfma_v(dPn, f.doa[1], vbk[kn][1]));
+            SP_M2(2); SP_E(8); SP_E(9); SP_CD(0); SP_CD(1); SP_M2(4);
+            // the products that read this step's operands are all issued: fetch the operands of the step after it
+            if (NKB == 1 || kb == NKB - 2) load_step(f, tn, subn, tn >= ntl);
+            if (kb == NKB - 1) reduce_add(red, st - DW - 1);   // (atomics of the partial published by the last barrier)
+            // slot 5: dV^T += dO^T P, first k-step (P registers 0..7)
+            SP_SLOT(sp_mfma_a(dV[kb], dot[0], pw0));
+            SP_E(10); SP_E(11); SP_CP(4); SP_M2(6);
+            // slot 6: dQ += dS K of the block two back, first k-step
+            SP_SLOT(if (ks == 0) sp_mfma_z(dQp, dsa0[0], kd[0][0]); else sp_mfma_v(dQp, dsa0[0], kd[ks][0]));
+            SP_CD(2); SP_CD(3); SP_E(12); SP_CP(5); SP_M2(8);
+            // slot 7: dK^T += Q^T dS, first k-step (dS registers 0..7; the last conversion is two instructions back)
+            SP_SLOT(sp_mfma_a(dK[kb], qt[0], dw0));
+            SP_E(13); SP_E(14); SP_E(15); SP_CP(6);
+            // slot 8
+            SP_SLOT(sp_mfma_v(dQp, dsa0[1], kd[ks][1]));
+            SP_CP(7); SP_M2(10); SP_M2(12); SP_M2(14); SP_CD(4); SP_CD(5);
+            // slot 9: dV, second k-step
+            SP_SLOT(sp_mfma_a(dV[kb], dot[1], pw1));
+            SP_CD(6); SP_CD(7);
+            // (the partial stays LIVE up to here on every path: where the write below is skipped — hipcc peels the first steps — a dead
+            // MFMA result would have its registers reused while the MFMA is still in flight: a write-after-write hazard nobody pads)
+            if (kb == KBW) asm volatile("" ::"v"(dQp));
+            if (kb == KBW && st >= DW) {   // the dQ partial of step st - DW is complete (slot 8 was its last product, 7+ instructions back)
+                char* pwr = sPart + ((sub - DW) & 1) * SP_PART + (wave * 4 * 64 + lane) * 16;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) S[i] = __builtin_amdgcn_exp2f(S[i]);
-                uint4 pk[2];
-                pack16(pk, S);
-                sp_mma_acc(dV[kb], dot, pk);          // dV^T += dO^T P
-#pragma unroll
-                for (int i = 0; i < 16; ++i) S[i] *= dP[i];
-                pack16(pk, S);
-                sp_mma_acc(dK[kb], qt, pk);           // dK^T += Q^T dS
-                char* img = sT + kb * 2048;
-                *reinterpret_cast<uint2*>(img + ds_off(r, 0, h)) = make_uint2(pk[0].x, pk[0].y);
-                *reinterpret_cast<uint2*>(img + ds_off(r, 1, h)) = make_uint2(pk[0].z, pk[0].w);
-                *reinterpret_cast<uint2*>(img + ds_off(r, 2, h)) = make_uint2(pk[1].x, pk[1].y);
-                *reinterpret_cast<uint2*>(img + ds_off(r, 3, h)) = make_uint2(pk[1].z, pk[1].w);
-                if (kb > 0) {                          // dQ += dS K of the PREVIOUS block: its image has long been written
-                    uint4 a[2];
-                    read_ds_tr(a, sT + (kb - 1) * 2048, lane);
-                    if (kb == 1) sp_mma_dq<true>(dQp, a, kd[0]);
-                    else sp_mma_dq<false>(dQp, a, kd[kb - 1]);
-                }
-                if (kb + 1 < SP_KB) { S = Sn; dP = dPn; }
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(pwr + g * 64 * 16) = f32x4{dQp[4 * g], dQp[4 * g + 1], dQp[4 * g + 2], dQp[4 * g + 3]};
             }
-            {
-                uint4 a[2];
-                read_ds_tr(a, sT + (SP_KB - 1) * 2048, lane);
-                sp_mma_dq<false>(dQp, a, kd[SP_KB - 1]);
-            }
-            // the previous step's partials (published by the last barrier) leave as atomics while the last products finish: the
-            // partial below is read from MFMA results by ds_write (MFMA -> non-MFMA read: tests/test_isa_hazards.py)
-            __builtin_amdgcn_sched_barrier(0);
-            reduce_step((st - 1) & 1, st > 0 ? (st - 1) * 32 : 0);
-            __builtin_amdgcn_sched_barrier(0);
-            char* pw = sPart + (st & 1) * SP_PART + (wave * 4 * 64 + lane) * 16;
+            SP_W(0); SP_W(1);
+            // slot 10: dK, second k-step
+            SP_SLOT(sp_mfma_a(dK[kb], qt[1], dw1));
+            SP_W(2); SP_W(3);
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<f32x4*>(pw + g * 64 * 16) = f32x4{dQp[4 * g], dQp[4 * g + 1], dQp[4 * g + 2], dQp[4 * g + 3]};
-        } else {
-            reduce_step((st - 1) & 1, st > 0 ? (st - 1) * 32 : 0);
+            for (int s = 0; s < 2; ++s) { dsa0[s] = dsa1[s]; }
+#pragma unroll
+            for (int s = 0; s < ((ABL & 8) ? 0 : 2); ++s) {  // this block's dS, transposed: consumed in slots 6 / 8 of the block after next
+                const h16x4 lo = SVOL_DS_READ_TR16_H16((lds_bf16x4_ptr)(img + o_rl + 1024 * s));
+                const h16x4 hi = SVOL_DS_READ_TR16_H16((lds_bf16x4_ptr)(img + o_rh + 1024 * s));
+                dsa1[s] = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#undef SP_SLOT
+#undef SP_E
+#undef SP_CP
+#undef SP_M2
+#undef SP_CD
+#undef SP_W
+            S = Sn;
+            dP = dPn;
         }
-        // tile t + 1 (5 LDS-DMA instructions, issued at the top of this tile) is older than this tile's 16 atomics
-        if (sub == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        sp_barrier();
+        // tile tl + 1 (5 LDS-DMA instructions, issued at the top of this tile) is first read when the operands of its step 0 are
+        // fetched: two steps ahead with one block per wave, in the last step of this tile otherwise; 4 atomics per step behind it
+        if (ABL & 16) { }
+        else if (sub == (NKB == 1 ? 1 : 2) && tl >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NKB == 1 ? 8 : 12) : "memory");
+        // the partial written in block KBW must be in LDS before the barrier.  LDS operations of a wave complete in order and the
+        // step's last eight are W(0..3) and the four transposed reads of its last block: at most those may still be in flight
+        if (ABL & 4) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
+        }
     }
-    reduce_step((nsteps - 1) & 1, (nsteps - 1) * 32);
-    if (LIVE) {
-        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the last asm MFMAs' results are read by compiler-generated code below
-        h16_t* dKo = reinterpret_cast<h16_t*>(p.dk) + (int64_t)b * p.Lk * p.lddk + hh * 32;
-        h16_t* dVo = reinterpret_cast<h16_t*>(p.dv) + (int64_t)b * p.Lk * p.lddv + hh * 32;
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the last asm MFMAs' results are read by compiler-generated code below
+    if (tail_out) {   // fp32 partial [2][keys of the workgroup][32]: raw sums, attn_dq_round_bf16 adds the four parts and scales
+        const int nk = 4 * 32 * NKB;
 #pragma unroll
-        for (int kb = 0; kb < SP_KB; ++kb) {
-            store_acc(dK[kb], dKo, p.lddk, key0 + kb * 32 + r, true, 32, h, p.scale / p.premul);
-            store_acc(dV[kb], dVo, p.lddv, key0 + kb * 32 + r, true, 32, h, 1.f);
+        for (int kb = 0; kb < NKB; ++kb) {
+            float* ok = tail_out + (int64_t)(wave * 32 * NKB + kb * 32 + r) * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<f32x4*>(ok + 8 * g + 4 * h) = f32x4{dK[kb][4 * g], dK[kb][4 * g + 1], dK[kb][4 * g + 2], dK[kb][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(ok + (int64_t)nk * 32 + 8 * g + 4 * h) = f32x4{dV[kb][4 * g], dV[kb][4 * g + 1], dV[kb][4 * g + 2], dV[kb][4 * g + 3]};
+            }
         }
+        return;
+    }
+    h16_t* dKo = reinterpret_cast<h16_t*>(p.dk) + (int64_t)b * p.Lk * p.lddk + hh * 32;
+    h16_t* dVo = reinterpret_cast<h16_t*>(p.dv) + (int64_t)b * p.Lk * p.lddv + hh * 32;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        store_acc(dK[kb], dKo, p.lddk, key0 + kb * 32 + r, true, 32, h, p.scale / p.premul);
+        store_acc(dV[kb], dVo, p.lddv, key0 + kb * 32 + r, true, 32, h, 1.f);
     }
 }
+// workgroup id -> work.  [0, n_main): the full 512-key groups, heads dealt to the XCDs as block_coords does (nxt = full groups per
+// head).  [n_main, n_main + 4 B H): the tail groups, four query quarters each, on the same head -> XCD deal.
+struct SpWork { int hh, b, kbase, t0, t1, part; bool tail; };
+__device__ __forceinline__ SpWork sp_work(const Args& p) {
+    SpWork w;
+    const int nfull = p.Lk / SP_KEYS, n_main = p.B * p.H * nfull, nt = p.Lq / KT;
+    int id = blockIdx.x;
+    w.tail = id >= n_main;
+    if (w.tail) id -= n_main;
+    const int xcd = id & 7, slot = id >> 3, per = w.tail ? 4 : nfull;   // work items per head
+    int hl, xt;
+    if (p.head_xcd == 2) { const int g = slot / (2 * per), r = slot - g * 2 * per; hl = g * 2 + (r & 1); xt = r >> 1; }
+    else { hl = slot / per; xt = slot - hl * per; }
+    const int head = p.head_xcd == 2 ? (((hl >> 1) * 8 + xcd) * 2 + (hl & 1)) : hl * 8 + xcd;
+    w.hh = head % p.H;
+    w.b = head / p.H;
+    w.part = w.tail ? xt : 0;
+    w.kbase = w.tail ? nfull * SP_KEYS : xt * SP_KEYS;
+    w.t0 = w.tail ? xt * nt / 4 : 0;
+    w.t1 = w.tail ? (xt + 1) * nt / 4 : nt;
+    return w;
+}
+// tail partial of (head, part): [B*H][4][2][tail keys][32] floats behind the fp32 dQ image
+__device__ __forceinline__ float* sp_tail_ptr(const Args& p, const SpWork& w) {
+    const int tk = p.Lk % SP_KEYS;
+    return p.ws_dq + (int64_t)p.B * p.Lq * p.H * 32 + ((int64_t)(w.b * p.H + w.hh) * 4 + w.part) * 2 * tk * 32;
+}
+template <int ABL>
+__device__ __forceinline__ void attn_bwd_sp_dispatch(const Args& p, char* smem) {
+    const SpWork w = sp_work(p);
+    if (!w.tail) { attn_bwd_sp_body<4, ABL>(p, smem, w.hh, w.b, w.kbase, w.t0, w.t1, nullptr); return; }
+    float* to = sp_tail_ptr(p, w);
+    const int tk = p.Lk % SP_KEYS;         // workgroup-uniform; Lk % 128 == 0
+    if (w.t1 <= w.t0) {                    // fewer than four query tiles: this part is empty — its partial still has to exist
+        for (int i = threadIdx.x; i < 2 * tk * 32; i += 256) to[i] = 0.f;
+        return;
+    }
+    if (tk == 384) attn_bwd_sp_body<3, ABL>(p, smem, w.hh, w.b, w.kbase, w.t0, w.t1, to);
+    else if (tk == 256) attn_bwd_sp_body<2, ABL>(p, smem, w.hh, w.b, w.kbase, w.t0, w.t1, to);
+    else attn_bwd_sp_body<1, ABL>(p, smem, w.hh, w.b, w.kbase, w.t0, w.t1, to);
+}
+#ifdef SP_LAB
+template <int ABL>
+__global__ __launch_bounds__(256, 1) void attn_bwd_sp_lab(Args p) {
+    __shared__ __attribute__((aligned(1024))) char smem[SP_LDS];
+    attn_bwd_sp_dispatch<ABL>(p, smem);
+}
+#endif
 __global__ __launch_bounds__(256, 1) void attn_bwd_sp_bf16(Args p) {
     __shared__ __attribute__((aligned(1024))) char smem[SP_LDS];
-    int xt, hh, b;
-    block_coords(p, xt, hh, b);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // wave-uniform (Lk % 128 == 0): the last workgroup of a head may own fewer than 512 keys; its key-less waves only help with
-    // staging, the reduction and the barriers (same number of barriers and vector-memory instructions on both paths)
-    if (xt * SP_KEYS + wave * SP_WKEYS < p.Lk) attn_bwd_sp_body<true>(p, smem, xt, hh, b);
-    else attn_bwd_sp_body<false>(p, smem, xt, hh, b);
+    attn_bwd_sp_dispatch<0>(p, smem);
 }
+// workgroups of the launch above
+// blocks of attn_dq_round_bf16: the image (8 elements per thread, rounded up to whole blocks), then the tail partials
+static inline unsigned sp_round_grid(int B, int H, int Lq, int Lk) {
+    return (unsigned)(((int64_t)B * Lq * H * 32 + 2047) / 2048 + ((int64_t)B * H * 2 * (Lk % SP_KEYS) * 32 + 2047) / 2048);
+}
+static inline unsigned sp_grid(int B, int H, int Lk) { return (unsigned)(B * H * (Lk / SP_KEYS + (Lk % SP_KEYS ? 4 : 0))); }
 
 }  // namespace
 
@@ -1920,8 +2141,9 @@ static int plan_ksplit(int B, int H, int Lq, int Lk, int dh, int64_t ws_floats, 
 static bool sp_shape_ok(int B, int H, int Lq, int Lk, int dh) {
     static const bool no_sp = getenv("SVOL_ATTN_NO_SP") != nullptr;
     static const int min_lk = getenv("SVOL_ATTN_SP_MIN_LK") ? atoi(getenv("SVOL_ATTN_SP_MIN_LK")) : 2 * SP_KEYS;
-    return !no_sp && dh == 32 && H <= 8 && (B * H) % 8 == 0 && Lq % KT == 0 && Lk % KT == 0 && Lk >= min_lk;
+    return !no_sp && dh == 32 && H == 8 && (B * H) % 8 == 0 && Lq % KT == 0 && Lk % KT == 0 && Lk >= min_lk;
 }
+static int64_t sp_ws_floats(int B, int H, int Lq, int Lk) { return (int64_t)B * Lq * H * 32 + (int64_t)B * H * 4 * 2 * (Lk % SP_KEYS) * 32; }
 int64_t svol_attn_ws_floats_bf16(int B, int H, int Lq, int Lk, int dh) {
     int tps;
     const int ks = plan_ksplit(B, H, Lq, Lk, dh, INT64_MAX, &tps);
@@ -1929,7 +2151,7 @@ int64_t svol_attn_ws_floats_bf16(int B, int H, int Lq, int Lk, int dh) {
         // key-tile classes of the masked fast kernels (one int per (batch, key tile)), or the redo flags of the unmasked fast
         // forward (one int per workgroup: (batch, head, 128-query tile)) — whichever is larger
         const int64_t cls = (int64_t)B * ((Lk + KT - 1) / KT), redo = (int64_t)B * H * ((Lq + 127) / 128);
-        const int64_t sp = sp_shape_ok(B, H, Lq, Lk, dh) ? (int64_t)B * Lq * H * dh : 0;   // fp32 dQ image of the single-pass backward
+        const int64_t sp = sp_shape_ok(B, H, Lq, Lk, dh) ? sp_ws_floats(B, H, Lq, Lk) : 0;   // single-pass backward: fp32 dQ image + tail partials
         const int64_t m = cls > redo ? cls : redo;
         return m > sp ? m : sp;
     }
@@ -2037,18 +2259,16 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
             hipLaunchKernelGGL(attn_bwd_dq_bf16_pre_masked, gq2, dim3(256), 0, s, pq);
             hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre_masked, gk2, dim3(256), 0, s, pk);
         } else {
-            if (pq.head_xcd && sp_shape_ok(B, H, Lq, Lk, dh) && ws && ws_bytes >= (int64_t)B * Lq * H * dh * 4) {
+            if (pq.head_xcd && sp_shape_ok(B, H, Lq, Lk, dh) && ws && ws_bytes >= 4 * sp_ws_floats(B, H, Lq, Lk)) {
                 // single pass: row constants + zeroed fp32 dQ image, the key-stationary kernel, rounding of dQ
                 Args ps = pq;
                 const int64_t n = (int64_t)B * H * Lq;
                 ps.ws_dq = ws;
                 ps.nl2 = reinterpret_cast<unsigned*>(delta + n);     // here: plain fp32 -lse2
                 ps.nd2 = reinterpret_cast<unsigned*>(delta + 2 * n);  //       plain fp32 -delta
-                ps.nxt = (Lk + SP_KEYS - 1) / SP_KEYS;
-                ps.tail_last = (Lk % SP_KEYS != 0 && ps.nxt > 1) ? 1 : 0;
                 hipLaunchKernelGGL(attn_bwd_sp_prep_bf16, dim3((unsigned)((int64_t)B * Lq / 32)), dim3(256), 0, s, ps);
-                hipLaunchKernelGGL(attn_bwd_sp_bf16, dim3((unsigned)(B * H * ps.nxt)), dim3(256), 0, s, ps);
-                hipLaunchKernelGGL(attn_dq_round_bf16, dim3((unsigned)(((int64_t)B * Lq * H * 32 / 8 + 255) / 256)), dim3(256), 0, s, ps);
+                hipLaunchKernelGGL(attn_bwd_sp_bf16, dim3(sp_grid(B, H, Lk)), dim3(256), 0, s, ps);
+                hipLaunchKernelGGL(attn_dq_round_bf16, dim3(sp_round_grid(B, H, Lq, Lk)), dim3(256), 0, s, ps);
                 return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
             }
             static const bool no_dq_rot = getenv("SVOL_ATTN_NO_DQ_ROT") != nullptr;

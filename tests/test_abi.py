@@ -42,7 +42,7 @@ def test_argument_validation_without_gpu():
     assert L.svol_attn_fwd(0, 8, 0, 8, 0, 8, 0, 8, 0, 0, 1, 1, 1, 1, 8, 1.0, 0.0, 0, 0, 1, 0) == -1
     # few queries: key-split partials; many queries: one int per (batch, 128-key tile) for the masked fast kernels or one per
     # workgroup (batch, head, 128-query tile) for the fast forward's redo flags, whichever is larger
-    assert L.svol_attn_ws_bytes(8, 8, 100, 6272, 32) > 8 * 49 * 4 and L.svol_attn_ws_bytes(8, 8, 6272, 6272, 32) == 8 * 8 * 49 * 4
+    assert L.svol_attn_ws_bytes(8, 8, 100, 6272, 32) > 8 * 49 * 4 and L.svol_attn_ws_bytes(8, 8, 6272, 6272, 32) == (8 * 6272 * 256 + 64 * 4 * 2 * 128 * 32) * 4   # single-pass backward: fp32 dQ image + tail partials
     assert L.svol_cast(0, 0, 0, 1, 10, 0) == -1
 
 

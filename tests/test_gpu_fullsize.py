@@ -229,6 +229,53 @@ def test_attention_values_at_the_benchmark_launch_shape(B, H, L, dtype):
     assert errs['dq'] <= 2 * tol and errs['dk'] <= 2 * tol and errs['dv'] <= 2 * tol, errs
 
 
+@pytest.mark.parametrize('L,dtype', [(1024, torch.bfloat16), (1152, torch.bfloat16), (1280, torch.bfloat16), (1408, torch.bfloat16),
+                                     (1152, torch.float16), (2176, torch.bfloat16)],
+                         ids=['L1024', 'L1152-tail128', 'L1280-tail256', 'L1408-tail384', 'L1152-fp16', 'L2176-17tiles'])
+def test_single_pass_backward_key_tails_and_query_quarters(L, dtype):
+    """Round 4: the unmasked backward at these shapes is ONE pass (csrc/attention_bf16.hip: attn_bwd_sp_bf16 — key-stationary 512-key
+    workgroups, dQ as fp32 atomics into a scratch image, svol_attn_ws_bytes() sizes it).  A head whose key count is not a multiple of
+    512 ends in a TAIL group of 128 / 256 / 384 keys: one / two / three 32-key blocks per wave (three more instantiations of the loop)
+    swept by FOUR workgroups, a quarter of the query tiles each, whose fp32 dK / dV partials a last kernel adds.  Every variant against
+    fp64 (every batch and head), same metric and bars as the launch-shape test; L = 2176 = 17 tiles makes the quarters uneven (4,4,4,5)."""
+    import math
+    from svol_amd import _lib, ops
+    B, H, dh = 2, 8, 32
+    assert _lib.lib().svol_attn_ws_bytes(B, H, L, L, dh) >= B * L * H * dh * 4      # (the scratch that selects the single pass)
+    tol = 1.2e-2 if dtype == torch.bfloat16 else 1.5e-3
+    d = H * dh
+    g = torch.Generator().manual_seed(11 + L)
+    pm = 1.4426950408889634 / math.sqrt(dh)
+    q = torch.randn((B * L, d), generator=g) * 1.5
+    k = torch.randn((B * L, d), generator=g) * 1.5
+    v = torch.randn((B * L, d), generator=g)
+    do = torch.randn((B * L, d), generator=g)
+    qkv = torch.cat([(q.double() * pm).float(), k, v], 1).to(dtype)
+    dob = do.to(dtype)
+    qkv_d, do_d = qkv.cuda(), dob.cuda()
+    qd, kd, vd = qkv_d[:, :d], qkv_d[:, d:2 * d], qkv_d[:, 2 * d:]
+    o, lse2 = ops.attn_fwd(qd, kd, vd, B, H, L, L, dh, None, pm)
+    dqkv = torch.full_like(qkv_d, float('nan'))
+    ops.attn_bwd(qd, kd, vd, o, do_d, lse2, B, H, L, L, dh, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], None, pm)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dqkv).all())
+    _, _, dq_r, dk_r, dv_r = _attn_heads_fp64(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], dob, B, H, L, L, dh, pm, batches=list(range(B)))
+    for name, got, ref in (('dq', dqkv[:, :d], dq_r), ('dk', dqkv[:, d:2 * d], dk_r), ('dv', dqkv[:, 2 * d:], dv_r)):
+        got = got.double().cpu()
+        for b in range(B):
+            for h in range(H):   # per (batch, head, 128-row tile): a wrong tail group or query quarter must not hide behind a tensor-wide maximum
+                rs, cs = slice(b * L, (b + 1) * L), slice(h * dh, (h + 1) * dh)
+                scale = float(ref[rs, cs].abs().max())
+                e = (got[rs, cs] - ref[rs, cs]).abs().reshape(L // 128, 128 * dh).max(1).values / scale
+                assert float(e.max()) <= 2 * tol, (name, b, h, int(e.argmax()), float(e.max()))
+    # run-to-run: dK / dV have no atomics (bit-reproducible); dQ is reproducible to fp32 summation order
+    dqkv2 = torch.empty_like(qkv_d)
+    ops.attn_bwd(qd, kd, vd, o, do_d, lse2, B, H, L, L, dh, dqkv2[:, :d], dqkv2[:, d:2 * d], dqkv2[:, 2 * d:], None, pm)
+    torch.cuda.synchronize()
+    assert torch.equal(dqkv2[:, d:], dqkv[:, d:])
+    assert float((dqkv2[:, :d].float() - dqkv[:, :d].float()).abs().max()) <= 2.0 ** -6 * float(dqkv[:, :d].float().abs().max())
+
+
 @pytest.mark.parametrize('dtype,qv,kv', [(torch.bfloat16, 16.0, 4.0), (torch.float16, 16.0, 4.0), (torch.float16, 2.0, 1.5)],
                          ids=['bf16', 'fp16', 'fp16-2^24'])
 def test_fast_forward_flags_overflow_and_the_safe_kernel_repairs_it(dtype, qv, kv):
