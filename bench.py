@@ -155,12 +155,23 @@ def main():
     local_dev = local_rank % torch.cuda.device_count() if backend != 'nccl' else local_rank
     torch.cuda.set_device(local_dev)
     dev = torch.device('cuda', local_dev)
+    force_ar = world == 1 and os.environ.get('SVOL_FORCE_ALLREDUCE') == '1'
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('SVOL_DP_SPANS', '1')   # per-bucket (launch -> done) spans on the communication stream, exposed wait in finish()
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    elif force_ar:
+        # a ONE-rank RCCL communicator: the bucketed all-reduce really runs on the communication stream (svol_amd.parallel: force), so the
+        # stream choreography of the N > 1 path executes against RCCL on a one-GPU box; the numbers of this mode are not the N = 1 line
+        import socket
+        sk = socket.socket()
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=dev)
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
     cores_rank = None
     if world > 1:
@@ -348,6 +359,7 @@ def main():
             del qkv, o_, lse_, do_, dqkv
         except Exception as e:  # a measurement aid must not take the bench line down
             alone = {'error': repr(e)}
+    ar_report = reducer.allreduce_report() if (world > 1 or force_ar) else None   # last issued step (the device is idle: events are final)
     issue_per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -382,7 +394,7 @@ def main():
     roof = None
     if fwd and bwd:
         # backward = 2x forward algorithmically (dV, dP, dQ, dK products; the S recompute gets no credit)
-        which = 'attn_bwd (delta + dQ pass + dK/dV pass)' if bwd[1] >= fwd[1] else 'attn_fwd'
+        which = 'attn_bwd (row constants + single-pass key-stationary kernel + dQ rounding)' if bwd[1] >= fwd[1] else 'attn_fwd'
         flop, ms = (2.0 * attn_fwd_flop, bwd[1]) if bwd[1] >= fwd[1] else (attn_fwd_flop, fwd[1])
         ach = flop / (ms * 1e-3) / 1e12
         # memory-side bytes per launch of the dominant kernel(s): from the NEWEST committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
@@ -399,7 +411,8 @@ def main():
                                key=lambda f_: int(re.search(r'round(\d+)_', os.path.basename(f_)).group(1)))
                 tj = json.load(open(files[-1]))
                 meta = tj.pop('_meta', {})
-                pick = (['attn_bwd_dq_bf16_pre|', 'attn_bwd_dq_bf16_rot|', 'attn_bwd_dkdv_bf16_pre|', 'attn_bwd_dkdv_bf16_pre_dma|', 'attn_delta_bf16|'] if bwd[1] >= fwd[1]
+                pick = (['attn_bwd_dq_bf16_pre|', 'attn_bwd_dq_bf16_rot|', 'attn_bwd_dkdv_bf16_pre|', 'attn_bwd_dkdv_bf16_pre_dma|', 'attn_delta_bf16|',
+                         'attn_bwd_sp_prep_bf16|', 'attn_bwd_sp_bf16|', 'attn_dq_round_bf16|'] if bwd[1] >= fwd[1]
                         else ['attn_fwd_bf16_pre|', 'attn_fwd_bf16_fast|'])
                 tot = sum((v['read_MB'] + v['write_MB']) * 1048576.0 for k_, v in tj.items() if any(k_.startswith(q_) for q_ in pick))
                 if tot > 0:
@@ -409,18 +422,26 @@ def main():
             except (OSError, ValueError, KeyError, IndexError, AttributeError):
                 pass
         # at d_h = 32 the attention core is bound by instruction ISSUE (softmax exp / VALU beside the MFMAs), not by the
-        # matrix pipe.  Floor per 32x32 score block from the guide's issue costs (MFMA 32x32x16: 32 cycles of pipe, 8 of issue; v_exp 8;
-        # other VALU 4; costs add per SIMD — profiles/round2_pmc_attention.md): forward 309, dQ pass 338, dK/dV pass 452 cycles.
-        CLK_GHZ, SIMDS = 2.4, 256 * 4
+        # matrix pipe.  Forward floor per 32x32 score block from the guide's issue costs (MFMA 32x32x16: 32 cycles of pipe, 8 of issue;
+        # v_exp 8; other VALU 4 — profiles/round2_pmc_attention.md): 309 cycles.  Backward (round 4, single pass): the in-kernel
+        # ablations of profiles/round4_attention_lab.md show the costs ADDING — 32 cycles per MFMA + ~5.7 per any other instruction,
+        # no overlap — so the floor of the pass is its minimal instruction set: 10 MFMAs + 16 v_exp + 16 v_cvt_pk + 8 v_pk_mul + 8 LDS
+        # per block = 320 + 48 * 5.7 = 594 cycles.  Priced at the clock the attention kernels HOLD (2.08 GHz: s_memtime against
+        # s_memrealtime in the round-4 lab; GRBM cycles / duration in profiles/round3_pmc_attention.md say 2.0), not at the 2.4 GHz maximum.
+        CLK_GHZ, SIMDS = 2.08, 256 * 4
         blocks = B * args.nheads * (L / 32.0) ** 2
         floor_fwd_ms = blocks * 309 / (SIMDS * CLK_GHZ * 1e9) * 1e3
-        floor_bwd_ms = blocks * (338 + 452) / (SIMDS * CLK_GHZ * 1e9) * 1e3
-        issue = {'model': 'per 32x32 block: fwd 309, dQ 338, dK/dV 452 issue cycles per SIMD (exp 8, VALU 4, MFMA issue 8 + LDS), '
-                          '%d SIMDs at %.1f GHz' % (SIMDS, CLK_GHZ),
+        floor_bwd_ms = blocks * 594 / (SIMDS * CLK_GHZ * 1e9) * 1e3
+        issue = {'model': 'per 32x32 block: fwd 309 issue cycles per SIMD (exp 8, VALU 4, MFMA issue 8 + LDS); bwd (single pass) 594 = 10 MFMAs x 32 '
+                          '+ 48 other instructions x 5.7 (costs add, measured: profiles/round4_attention_lab.md); %d SIMDs at the %.2f GHz the '
+                          'kernels hold' % (SIMDS, CLK_GHZ),
                  'fwd_floor_ms': floor_fwd_ms, 'bwd_floor_ms': floor_bwd_ms,
                  'fwd_frac_of_issue_floor': floor_fwd_ms / fwd[1], 'bwd_frac_of_issue_floor': floor_bwd_ms / bwd[1]}
+        # algorithmic bytes of one launch: backward reads q, k, v, o, dO and writes dq, dk, dv once; forward reads q, k, v, writes o
+        alg_bytes = (8 if bwd[1] >= fwd[1] else 4) * B * L * args.hidden_dim * 2.0
         roof = {'bound': 'mfma', 'kernel': which, 'achieved': ach, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': ach / PEAK_BF16_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes per launch (HBM side)',
+                'traffic_ratio': (traffic / alg_bytes) if traffic else None, 'algorithmic_bytes': alg_bytes,
                 'traffic_source': traffic_src,
                 'launch_ms': ms, 'launches_timed': bwd[0] if bwd[1] >= fwd[1] else fwd[0],
                 'attn_fwd_ms': fwd[1], 'attn_bwd_ms': bwd[1],
@@ -436,8 +457,7 @@ def main():
                 else (attn_fwd_flop / (alone['attn_fwd_ms'] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS),
                 'issue_bound_frac': (floor_bwd_ms / alone['attn_bwd_ms']) if bwd[1] >= fwd[1] else (floor_fwd_ms / alone['attn_fwd_ms']),
                 'note': 'measured right after the timed region with nothing else on the device; in the step the weight-gradient GEMMs '
-                        'are gated to run beside the attention backward (SVOL_NO_WGRAD_GATE=1 moves them beside the LayerNorm / dgelu '
-                        'kernels instead: launch_ms ~1.27, step +0.13 ms)'}
+                        'are gated to run beside the attention backward and take CUs from it'}
         elif alone:
             roof['same_launches_alone'] = alone
 
@@ -464,6 +484,11 @@ def main():
             'host_wall_ms_first_last': [round(x, 2) for x in host_ms[:3] + host_ms[-3:]],
             'launch_mode': 'hipGraph replay (whole step captured)' if use_graph else 'eager',
         }
+        if ar_report is not None:
+            # rank 0's last step: what finish() had to wait for behind backward, and every bucket's span on the communication stream
+            res['allreduce_exposed_ms'] = ar_report['exposed_ms']
+            res['allreduce_buckets'] = ar_report['buckets']
+            res['allreduce_backend'] = 'nccl (RCCL), forced at world size 1' if force_ar else backend
         if issue_per_rank is not None:
             res['host_issue_ms_per_rank'] = issue_per_rank
             res['host_cores_per_rank'] = cores_rank
@@ -472,7 +497,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or force_ar:
         dist.destroy_process_group()
 
 

@@ -95,6 +95,14 @@ class BucketedGradAllReduce:
             self._make_bucket(g)
         self._handles = []
         self._hooks = []
+        # SVOL_FORCE_ALLREDUCE=1: run the collective path at world size 1 too (a 1-rank RCCL communicator is a real communicator: the
+        # all-reduce is enqueued on the communication stream behind the same producer-stream waits, finish() joins it) — how the
+        # stream choreography is exercised against RCCL on a one-GPU box (tests/test_gpu_parallel.py)
+        import os
+        self.force = self.world == 1 and dist.is_initialized() and os.environ.get('SVOL_FORCE_ALLREDUCE') == '1'
+        self.spans = []            # per launched bucket: (bucket index, start event, end event) on the communication stream (GPU only)
+        self.exposed = None        # (event, event) around finish()'s wait for the communication stream: the exchange backward did not hide
+        self.record_spans = self.force or os.environ.get('SVOL_DP_SPANS') == '1'
         self.pending_scale = 1.0   # see finish(mean=False)
         self.fire_order: List[int] = []   # diagnostics: bucket index of every hook of the current step, in firing order
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
@@ -155,7 +163,7 @@ class BucketedGradAllReduce:
         return out
 
     def _launch(self, b):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.on_gpu:
             # The hook runs on the autograd thread under the stream guard of the LAST-arriving parameter's node.  That
@@ -169,7 +177,14 @@ class BucketedGradAllReduce:
             for s in self._producer_streams():
                 self.comm_stream.wait_stream(s)
             with torch.cuda.stream(self.comm_stream):
+                if self.record_spans:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.comm_stream)
                 h = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.record_spans:
+                    h.wait()       # (stream-side wait: orders the communication stream behind the collective, does not block the host)
+                    e1.record(self.comm_stream)
+                    self.spans.append((next(i for i, x in enumerate(self.buckets) if x is b), e0, e1))
         else:
             h = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._handles.append((h, b))
@@ -181,6 +196,7 @@ class BucketedGradAllReduce:
             from . import ops
             ops.drop_pending_wgrad()   # weight-gradient launches a failed backward left queued must not land in the zeroed buckets
         self.fire_order = []
+        self.spans = []
         for b in self.buckets:
             b['flat'].zero_()
             b['pending'] = b['n']
@@ -202,15 +218,23 @@ class BucketedGradAllReduce:
             ops.flush_wgrad()
             for s in list(cmt.side_streams(self.device)) + list(ops.wgrad_streams(self.device)):
                 torch.cuda.current_stream().wait_stream(s)
+        collective = self.world > 1 or self.force
         for b in self.buckets:
-            if b['pending'] != 0 and self.world > 1:
+            if b['pending'] != 0 and collective:
                 # a parameter of this bucket got no gradient this step (should not happen for a fixed
                 # architecture); reduce what we have so that ranks stay in lock-step
                 self._launch(b)
         for h, b in self._handles:
             h.wait()
-        if self.on_gpu and self.world > 1:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self.on_gpu and collective:
+            cur = torch.cuda.current_stream()
+            if self.record_spans:   # what the caller's stream waits here is the exchange that backward did not cover
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record(cur)
+            cur.wait_stream(self.comm_stream)
+            if self.record_spans:
+                eb.record(cur)
+                self.exposed = (ea, eb)
         if self.world > 1:
             inv = 1.0 / self.world
             if mean:
@@ -219,6 +243,17 @@ class BucketedGradAllReduce:
             else:
                 self.pending_scale = inv
         self._handles.clear()
+
+    def allreduce_report(self):
+        """after a synchronised step with span recording on (SVOL_FORCE_ALLREDUCE / SVOL_DP_SPANS): per launched bucket (index, MiB, ms
+        from the first recorded start, duration ms) on the communication stream, and the ms the caller's stream waited in finish()."""
+        if not self.spans:
+            return {'buckets': [], 'exposed_ms': 0.0}
+        t0 = self.spans[0][1]
+        out = [{'bucket': bi, 'mib': round(self.buckets[bi]['flat'].numel() * 4 / 2 ** 20, 2), 'start_ms': round(t0.elapsed_time(e0), 3),
+                'ms': round(e0.elapsed_time(e1), 3)} for bi, e0, e1 in self.spans]
+        exposed = self.exposed[0].elapsed_time(self.exposed[1]) if self.exposed else 0.0
+        return {'buckets': out, 'exposed_ms': round(exposed, 4)}
 
     def bucket_fire_spans(self):
         """diagnostics after a backward: per bucket (first, last) position of its hooks in the step's firing order —

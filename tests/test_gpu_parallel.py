@@ -34,6 +34,29 @@ def test_two_ranks_on_one_gpu(case):
     assert p.stdout.count('reducer == mean of per-rank gradients') == 2, p.stdout[-2000:]
 
 
+def test_rccl_world1_forced_allreduce():
+    """the RCCL path executes.  One rank, backend nccl, SVOL_FORCE_ALLREDUCE=1: every bucket of the full cfg2 step is
+    all-reduced by RCCL on the communication stream behind the producer-stream waits (tests/rccl_world1_worker.py); gradients equal the
+    un-reduced run, buckets complete in order, no deadlock with the weight-gradient gate (the worker runs under a timeout)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', SVOL_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, os.path.join(HERE, 'rccl_world1_worker.py')], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert 'rccl world-1:' in p.stdout and 'all-reduced on the communication stream' in p.stdout, p.stdout[-2000:]
+    print(p.stdout.strip().splitlines()[-1])
+
+
+def test_bench_reports_allreduce_spans_with_rccl_at_world1():
+    """bench.py under SVOL_FORCE_ALLREDUCE=1: a 1-rank RCCL communicator, `allreduce_exposed_ms` and the per-bucket spans in the line."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', SVOL_FORCE_ALLREDUCE='1')
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), 'bench.py'), '--steps', '4', '--warmup', '2', '--no-cpu-baseline'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line['allreduce_backend'].startswith('nccl') and line['allreduce_exposed_ms'] >= 0.0
+    assert len(line['allreduce_buckets']) >= 4 and all(b['ms'] > 0 for b in line['allreduce_buckets']), line['allreduce_buckets']
+
+
 @pytest.mark.gpu
 def test_flat_adamw_matches_torch_adamw():
     """svol_amd.parallel.FlatAdamW (one kernel per gradient bucket) against torch.optim.AdamW on the same gradients, 4 steps;
