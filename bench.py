@@ -243,9 +243,17 @@ def main():
         pix_video = torch.randn((B, T, 3, 224, 224), device=dev, generator=g)
         pix_sketch = torch.randn((B, 1, 3, 224, 224), device=dev, generator=g)
 
-    loss_scale = a.loss_scale if a.loss_scale is not None else (1024.0 if a.dtype == 'fp16' else 1.0)
+    # fp16 operands: dynamic loss scaling with overflow skip on the device (svol_amd.parallel.DynamicLossScaler; the reference's fp16 mode
+    # is apex amp); --loss-scale X pins a static scale instead.  bf16 / fp32: none.
+    scaler = None
+    loss_scale = a.loss_scale if a.loss_scale is not None else 1.0
     if not use_graph:
-        opt.loss_scale = loss_scale
+        if a.dtype == 'fp16' and a.loss_scale is None:
+            scaler = opt.scaler = parallel.DynamicLossScaler(dev, init_scale=2.0 ** 12)
+        else:
+            opt.loss_scale = loss_scale
+    elif loss_scale != 1.0:
+        raise SystemExit('--graph keeps torch.optim.AdamW, which does not unscale: no --loss-scale with --graph')
 
     fence = parallel.StepFence(a.max_inflight) if a.max_inflight > 0 else None
 
@@ -257,7 +265,7 @@ def main():
         out = model(inp['src_sketch'], inp['src_sketch_mask'], inp['src_video'], inp['src_video_mask'])
         ld = crit(out, tg)
         loss = crit.weighted_total()  # = sum(ld[k] * wd[k] for k in ld if k in wd) (train.py:227-228), one multiply + one reduction
-        (loss * loss_scale if loss_scale != 1.0 else loss).backward()
+        (scaler.scale(loss) if scaler is not None else (loss * loss_scale if loss_scale != 1.0 else loss)).backward()
         reducer.finish(mean=use_graph)   # the 1 / world of the gradient mean rides FlatAdamW's update kernel
         opt.step()
         return loss

@@ -77,6 +77,18 @@ int svol_cast_split(const float* src, int64_t ld_src, void* dst_hilo, int64_t R,
  *   p -= lr/(1 - b1^step) * m / (sqrt(v)/sqrt(1 - b2^step) + eps).          step counts from 1. */
 int svol_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int64_t step, float grad_scale, void* stream);
+/* Dynamic loss scaling for fp16 operands (the reference's fp16 mode is apex amp: dynamic scale, overflowed steps skipped,
+ * configs.py:52-61, train.py:111-114,231-232), without a host synchronisation.  scaler_state: four floats on the DEVICE —
+ * [0] the loss scale (the caller multiplies the loss by it ON THE DEVICE), [1] overflow flag of the current step, [2] clean steps since
+ * the scale last changed, [3] optimizer steps really taken.  Per step: svol_grad_finite over every gradient range (sets [1] on an
+ * inf / NaN), svol_adamw_flat_scaled over every range (g' = g * grad_mul / state[0]; a no-op when [1] is set; the bias corrections use
+ * step = state[3] + 1), then svol_loss_scaler_update once: overflow -> scale *= backoff_factor (>= min_scale), else state[3]++ and
+ * after growth_interval clean steps scale *= growth_factor (<= max_scale); clears [1]. */
+int svol_grad_finite(const float* g, int64_t n, float* scaler_state, void* stream);
+int svol_adamw_flat_scaled(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, float grad_mul, const float* scaler_state, void* stream);
+int svol_loss_scaler_update(float* scaler_state, float growth_factor, float backoff_factor, int64_t growth_interval, float min_scale,
+                            float max_scale, void* stream);
 
 /* ---- GEMMs (nn.Linear and its backward) --------------------------------- */
 /* C[M,N] = act((A[M,K] * B[N,K]^T + bias[N]) * colscale[N]) + residual[M,N]

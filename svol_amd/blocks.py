@@ -157,11 +157,15 @@ class BlockPlan:
         W = ops.weights
         dev = self.params[0].device
 
+        self.casts = []    # (weight, dtype, wc, wt) / (weight, row0, rows, ws): the copies whose POINTERS sit in the template
+        self.epoch = W.epoch
+
         def both(name, w, dtype, name_t=None):
             wc, wt = W.get(w, dtype)
             t.set_t(name, wc)
             t.set_t(name_t or (name + '_T'), wt)
             self.keep += [wc, wt]
+            self.casts.append((w, dtype, wc, wt))
 
         def qscale(dtype, n):
             if dtype == torch.float32:
@@ -184,6 +188,7 @@ class BlockPlan:
                 hl = W.get_split(m.in_proj_weight, 2 * D, D)
                 t.set_t('WV_HILO', hl)
                 self.keep.append(hl)
+                self.casts.append((m.in_proj_weight, 2 * D, D, hl))
             t.set_t('QSCALE', qscale(dt, 2 * D))
         elif block == QS:
             m = layer.token_self_attn
@@ -195,6 +200,7 @@ class BlockPlan:
                 hl = W.get_split(m.in_proj_weight, 2 * D, D)
                 t.set_t('WV_HILO', hl)
                 self.keep.append(hl)
+                self.casts.append((m.in_proj_weight, 2 * D, D, hl))
             t.set_t('QSCALE', qscale(qdt, 2 * D))
         else:
             m, mlp = layer.content_token_cross_attn, layer.mlp2
@@ -210,6 +216,7 @@ class BlockPlan:
                 hl = W.get_split(m.in_proj_weight, 2 * D, D)
                 t.set_t('WV_HILO', hl)
                 self.keep.append(hl)
+                self.casts.append((m.in_proj_weight, 2 * D, D, hl))
             t.set_t('QSCALE', qscale(dt, D))   # the attention core's dtype decides (ops.AttnLNFn: premul follows dkv)
         # gradient targets: the reducer's bucket views where there are sinks
         self.sinks = [ops._claim(p, p.requires_grad) for p in self.params]
@@ -238,6 +245,23 @@ class BlockPlan:
 
     def valid(self):
         return self.layer() is not None and self._key() == self.key
+
+    def fresh_copies(self):
+        """The compute-dtype / transposed / split weight copies behind the template's pointers are those of the CURRENT parameter
+        values: the per-op path re-validated every copy on every call (version counter + cache epoch, ops._WeightCache.get),
+        a plan caches raw pointers.  Same check here, once per use: a hit costs a dictionary lookup; a copy that an in-place update
+        made stale (a torch optimizer step, load_state_dict, copy_ — anything that bumps ``_version`` — or a new cache epoch) is
+        re-cast INTO ITS BUFFER, so the template stays valid; a copy that moved invalidates the plan."""
+        W = ops.weights
+        for c in self.casts:
+            if len(c) == 4 and isinstance(c[1], torch.dtype):
+                wc, wt = W.get(c[0], c[1])
+                if wc is not c[2] or wt is not c[3]:
+                    return False
+            else:
+                if W.get_split(c[0], c[1], c[2]) is not c[3]:
+                    return False
+        return True
 
     def grad_buffers(self, tbl, dev):
         """parameters without a sink: one zeroed flat buffer, views returned to autograd."""
@@ -291,7 +315,7 @@ def plan(layer, block, dt, qdt):
         per = _PLANS[layer] = {}
     k = (block, dt, qdt)
     pl = per.get(k)
-    if pl is None or not pl.valid():
+    if pl is None or not pl.valid() or not pl.fresh_copies():
         pl = per[k] = BlockPlan(block, layer, dt, qdt)
     return pl
 

@@ -409,6 +409,102 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
 }
 }  // namespace
 
+// ---- dynamic loss scaling (fp16 operands; the reference's fp16 mode is apex amp with dynamic scaling and overflow skip, configs.py:60-61) ----
+// scaler state, four floats on the device: [0] loss scale, [1] overflow flag of the current step (0 / 1), [2] clean steps since the
+// last change of the scale, [3] optimizer steps really taken (bias-correction exponent).  No host synchronisation anywhere.
+namespace {
+__global__ __launch_bounds__(256) void grad_finite_kernel(const float* __restrict__ g, int64_t n4, int64_t n, float* __restrict__ state) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(g + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bad |= !(fabsf(v[e]) <= 3.0e38f);   // inf or NaN
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t j = 4 * n4; j < n; ++j) bad |= !(fabsf(g[j]) <= 3.0e38f);
+    if (__any(bad) && (threadIdx.x & 63) == 0) state[1] = 1.f;   // (benign race: every writer stores the same value)
+}
+__global__ __launch_bounds__(256) void adamw_flat_scaled_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                                float* __restrict__ v, int64_t n4, int64_t n, float lr, float wd, float b1,
+                                                                float b2, float eps, float gmul, const float* __restrict__ state) {
+    if (state[1] != 0.f) return;   // an overflowed step is skipped whole: parameters and moments keep their values
+    const float gscale = gmul / state[0];
+    const float step = state[3] + 1.f;
+    const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
+    const float decay = 1.f - lr * wd, step_size = lr / bc1, inv_bc2_sqrt = 1.f / sqrtf(bc2);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) {
+        f32x4 pp = *reinterpret_cast<f32x4*>(p + 4 * i), mm = *reinterpret_cast<f32x4*>(m + 4 * i), vv = *reinterpret_cast<f32x4*>(v + 4 * i);
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = gg[e] * gscale;
+            pp[e] *= decay;
+            mm[e] = mm[e] + (gr - mm[e]) * (1.f - b1);
+            vv[e] = vv[e] * b2 + (1.f - b2) * gr * gr;
+            pp[e] -= step_size * (mm[e] / (sqrtf(vv[e]) * inv_bc2_sqrt + eps));
+        }
+        *reinterpret_cast<f32x4*>(p + 4 * i) = pp;
+        *reinterpret_cast<f32x4*>(m + 4 * i) = mm;
+        *reinterpret_cast<f32x4*>(v + 4 * i) = vv;
+    } else if (i == n4) {
+        for (int64_t j = 4 * n4; j < n; ++j) {
+            const float gr = g[j] * gscale;
+            float pj = p[j] * decay;
+            const float mj = m[j] + (gr - m[j]) * (1.f - b1);
+            const float vj = v[j] * b2 + (1.f - b2) * gr * gr;
+            pj -= step_size * (mj / (sqrtf(vj) * inv_bc2_sqrt + eps));
+            p[j] = pj; m[j] = mj; v[j] = vj;
+        }
+    }
+}
+__global__ void loss_scaler_update_kernel(float* state, float growth, float backoff, float interval, float min_scale, float max_scale) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (state[1] != 0.f) {
+        state[0] = fmaxf(state[0] * backoff, min_scale);
+        state[2] = 0.f;
+    } else {
+        state[3] += 1.f;
+        state[2] += 1.f;
+        if (state[2] >= interval) { state[0] = fminf(state[0] * growth, max_scale); state[2] = 0.f; }
+    }
+    state[1] = 0.f;
+}
+}  // namespace
+
+extern "C" int svol_grad_finite(const float* g, int64_t n, float* scaler_state, void* stream) {
+    if (!g || !scaler_state || n < 0) return SVOL_E_INVALID;
+    if (n == 0) return SVOL_OK;
+    if (!aligned16(g)) return SVOL_E_UNSUPPORTED;
+    const int64_t n4 = n / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(grad_finite_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, n4, n, scaler_state);
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+extern "C" int svol_adamw_flat_scaled(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                                      float weight_decay, float grad_mul, const float* scaler_state, void* stream) {
+    if (!p || !g || !m || !v || !scaler_state || n < 0) return SVOL_E_INVALID;
+    if (n == 0) return SVOL_OK;
+    if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return SVOL_E_UNSUPPORTED;
+    const int64_t n4 = n / 4;
+    const int64_t blocks = (n4 + 1 + 255) / 256;
+    if (blocks >= (1ll << 31)) return SVOL_E_UNSUPPORTED;
+    hipLaunchKernelGGL(adamw_flat_scaled_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n4, n,
+                       lr, weight_decay, beta1, beta2, eps, grad_mul, scaler_state);
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+extern "C" int svol_loss_scaler_update(float* scaler_state, float growth_factor, float backoff_factor, int64_t growth_interval, float min_scale,
+                                       float max_scale, void* stream) {
+    if (!scaler_state || growth_factor < 1.f || backoff_factor <= 0.f || backoff_factor > 1.f || growth_interval < 1) return SVOL_E_INVALID;
+    hipLaunchKernelGGL(loss_scaler_update_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), scaler_state, growth_factor,
+                       backoff_factor, (float)growth_interval, min_scale, max_scale);
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
 extern "C" int svol_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                                float weight_decay, int64_t step, float grad_scale, void* stream) {
     if (!p || !g || !m || !v || n < 0 || step <= 0) return SVOL_E_INVALID;

@@ -191,11 +191,19 @@ class CrossModalTransformer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
         self.d_model, self.nhead, self.num_layers = d_model, nhead, num_layers
+        self._epoch_seen = -1
 
     def forward(self, src_vid32, src_skch32, kbias, vid_pos, query_embed):
         """src_vid32 [B,L,d] fp32 (projected video tokens = start of the fp32 residual stream),
         src_skch32 [B,d] fp32, kbias [B,L] fp32 additive key mask, vid_pos [B,L,d] compute dtype,
         query_embed [N,d] fp32 parameter.  Returns hs [num_layers,B,N,d] fp32."""
+        # The compute-dtype weight copies are refreshed once per cache EPOCH; the heads that own this module (SVANet, the
+        # svanet_variants) open one per forward.  Driven on its own (a training loop around the bare transformer), nobody does:
+        # open it here, or an optimizer that rewrites parameters without bumping their version counters (torch's fused AdamW on ROCm)
+        # would leave every copy stale (ADVICE r3)
+        if ops.weights.epoch == self._epoch_seen:
+            ops.weights.new_epoch()
+        self._epoch_seen = ops.weights.epoch
         B = src_vid32.shape[0]
         dt = torch.float32 if QUERY_FP32 else vid_pos.dtype   # element type of the QUERY stream's GEMM operands
         qpos = ops.cast_ag(query_embed, dt)

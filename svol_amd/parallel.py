@@ -274,6 +274,32 @@ class BucketedGradAllReduce:
                     del p._svol_sink
 
 
+class DynamicLossScaler:
+    """apex-amp style dynamic loss scaling for fp16 operands (the reference's fp16 mode: configs.py:52-61, ``amp.scale_loss`` at
+    train.py:231-232) kept entirely on the device: ``scale(loss)`` multiplies by the scale tensor, ``FlatAdamW.step()`` checks the
+    flat gradient buckets for inf / NaN, SKIPS the whole update when one is found (parameters, moments and the bias-correction step
+    count keep their values), and halves / grows the scale — no host synchronisation, no ``.item()``.  ``state_dict()`` speaks the
+    ``amp`` entry of the reference's checkpoints (``{'loss_scaler0': {'loss_scale', 'unskipped'}}``)."""
+
+    def __init__(self, device, init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, min_scale=1.0,
+                 max_scale=2.0 ** 24):
+        self.state = torch.tensor([float(init_scale), 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        self.min_scale, self.max_scale = float(min_scale), float(max_scale)
+
+    def scale(self, loss):
+        return loss * self.state[0]
+
+    def state_dict(self):   # (a host read: checkpoint time only)
+        st = self.state.tolist()
+        return {'loss_scaler0': {'loss_scale': st[0], 'unskipped': int(st[2])}}
+
+    def load_state_dict(self, sd):
+        e = sd.get('loss_scaler0', sd)
+        self.state[0] = float(e['loss_scale'])
+        self.state[2] = float(e.get('unskipped', 0))
+
+
 class FlatAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW (decoupled weight decay, amsgrad off; the reference's optimizer, train.py:98-99) over the reducer's
     flat buckets: the parameters of a bucket are re-homed into ONE flat fp32 buffer (``param.data`` becomes a view, like
@@ -307,6 +333,7 @@ class FlatAdamW(torch.optim.Optimizer):
         # the loss was multiplied by this before backward (fp16 operands: gradients of ~1e-6 underflow otherwise); divided back out
         # inside the update kernel
         self.loss_scale = 1.0
+        self.scaler: Optional[DynamicLossScaler] = None   # set for fp16 training: overflow check + skip + dynamic scale (see step())
         self.flat = []      # per bucket: flat parameters / first / second moments
         self._slot = {}     # id(param) -> (bucket index, offset, numel)
         for bi, b in enumerate(reducer.buckets):
@@ -331,6 +358,23 @@ class FlatAdamW(torch.optim.Optimizer):
         from .ops import _ptr, _stream
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
+        if self.scaler is not None:
+            # dynamic loss scaling (a static scale with no overflow check lets one inf gradient poison p, m and v for good):
+            # the buckets are checked first, every update kernel is a no-op on an overflowed step, then the scale moves
+            sc = self.scaler
+            gmul = float(self.reducer.pending_scale)
+            self.reducer.pending_scale = 1.0
+            self.t += 1    # (host-side count of step() calls; the bias corrections use the DEVICE count of steps really taken)
+            for b in self.reducer.buckets:
+                _lib.check(_lib.lib().svol_grad_finite(_ptr(b['flat']), b['flat'].numel(), _ptr(sc.state), _stream()), 'svol_grad_finite')
+            for b, st in zip(self.reducer.buckets, self.flat):
+                rc = _lib.lib().svol_adamw_flat_scaled(_ptr(st['p']), _ptr(b['flat']), _ptr(st['m']), _ptr(st['v']), st['p'].numel(),
+                                                       float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
+                                                       float(g['weight_decay']), gmul, _ptr(sc.state), _stream())
+                _lib.check(rc, 'svol_adamw_flat_scaled')
+            _lib.check(_lib.lib().svol_loss_scaler_update(_ptr(sc.state), sc.growth_factor, sc.backoff_factor, sc.growth_interval,
+                                                          sc.min_scale, sc.max_scale, _stream()), 'svol_loss_scaler_update')
+            return loss
         self.t += 1
         gscale = float(self.reducer.pending_scale) / float(self.loss_scale)
         self.reducer.pending_scale = 1.0

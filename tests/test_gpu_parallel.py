@@ -88,6 +88,63 @@ def test_flat_adamw_matches_torch_adamw():
 
 
 @pytest.mark.gpu
+def test_dynamic_loss_scaler_skips_overflowed_steps_and_follows_torch_adamw():
+    """fp16 training used a static loss scale and never checked for overflow — one inf gradient went straight into p, m and
+    v.  DynamicLossScaler (apex-amp semantics, state on the device): gradients arrive multiplied by the scale; a clean step equals
+    torch.optim.AdamW on the unscaled gradients; a step with an inf / NaN anywhere in any bucket changes NOTHING (parameters, both
+    moments, the bias-correction step count) and halves the scale; the scale grows after `growth_interval` clean steps."""
+    import torch
+    from svol_amd import parallel
+    torch.manual_seed(0)
+    shapes = [(64, 33), (33,), (128, 128), (5, 3, 2), (1,)]
+    pa = [torch.nn.Parameter(torch.randn(s, device='cuda')) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    red = parallel.BucketedGradAllReduce(pa, bucket_bytes=40000)
+    assert len(red.buckets) >= 2
+    opt_a = parallel.FlatAdamW(red, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    sc = opt_a.scaler = parallel.DynamicLossScaler(torch.device('cuda'), init_scale=1024.0, growth_interval=3)
+    opt_b = torch.optim.AdamW(pb, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    scale = 1024.0
+    clean_run = 0
+    for step in range(9):
+        red.zero_grad()
+        opt_b.zero_grad()
+        overflow = step in (2, 6)
+        gs = [torch.randn(a.shape, device='cuda') * (1.0 + step) for a in pa]
+        for i, (a, g) in enumerate(zip(pa, gs)):
+            a.grad.copy_(g * scale)                      # what backward of (loss * scale) leaves in the buckets
+        if overflow:
+            pa[3].grad.view(-1)[7] = float('inf') if step == 2 else float('nan')
+        before = [p.detach().clone() for p in pa]
+        mom = [(st['m'].clone(), st['v'].clone()) for st in opt_a.flat]
+        opt_a.step()
+        torch.cuda.synchronize()
+        st_host = sc.state.tolist()
+        if overflow:
+            assert all(torch.equal(a, b) for a, b in zip(before, pa))
+            assert all(torch.equal(m, st['m']) and torch.equal(v, st['v']) for (m, v), st in zip(mom, opt_a.flat))
+            scale *= 0.5
+            clean_run = 0
+        else:
+            for b, g in zip(pb, gs):
+                b.grad = g.clone()
+            opt_b.step()
+            clean_run += 1
+            if clean_run == 3:
+                scale *= 2.0
+                clean_run = 0
+            for a, b in zip(pa, pb):
+                assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), (step, float((a - b).abs().max()))
+        assert st_host[0] == scale and st_host[1] == 0.0, (step, st_host, scale)
+    assert sc.state.tolist()[3] == 7.0                  # 9 calls, 2 skipped
+    sd = sc.state_dict()
+    assert sd['loss_scaler0']['loss_scale'] == scale
+    sc2 = parallel.DynamicLossScaler(torch.device('cuda'))
+    sc2.load_state_dict(sd)
+    assert sc2.state.tolist()[0] == scale
+
+
+@pytest.mark.gpu
 def test_flat_adamw_checkpoints_interoperate_with_torch_adamw():
     """FlatAdamW speaks torch.optim.AdamW's state-dict schema.  torch AdamW, 2 steps -> state_dict ->
     FlatAdamW.load_state_dict -> 2 more steps on both == same weights; and back: FlatAdamW.state_dict() resumes a fresh

@@ -179,3 +179,56 @@ print(blocks.trace_dump())
     r2 = subprocess.run([sys.executable, '-c', 'from svol_amd import blocks; print(repr(blocks.trace_dump()))'], env=env, capture_output=True,
                         text=True, timeout=300, cwd=root)
     assert r2.returncode == 0 and r2.stdout.strip() == "''", (r2.stdout, r2.stderr[-500:])
+
+
+@pytest.mark.parametrize('opt_kind', ['sgd', 'copy_'])
+def test_bare_transformer_sees_in_place_weight_updates(opt_kind):
+    """a block plan caches the raw pointers of the compute-dtype / transposed weight copies.  A bare CrossModalTransformer
+    (no SVANet around it to open a weight-cache epoch per forward) trained with a torch optimizer — or written with ``copy_`` — must
+    still compute with the CURRENT weights, forward (W) and backward (W^T): three steps with the block programs on against the same
+    three steps on the per-op path (blocks.ENABLED = False), which re-validates every copy on every call."""
+    from svol_amd import blocks, ops
+    from svol_amd.modeling.cross_modal_transformer import CrossModalTransformer
+    B, L, N, d = 2, 256, 16, 64
+
+    def run(enabled):
+        old = blocks.ENABLED
+        blocks.ENABLED = enabled
+        try:
+            torch.manual_seed(3)
+            tr = CrossModalTransformer(d_model=d, nhead=8, num_layers=2, dim_feedforward=128).cuda()
+            qe = torch.nn.Parameter(torch.randn(N, d, device='cuda') * 0.5)
+            g = torch.Generator(device='cuda').manual_seed(5)
+            vid = torch.randn(B, L, d, device='cuda', generator=g)
+            sk = torch.randn(B, d, device='cuda', generator=g)
+            pos = (torch.randn(B, L, d, device='cuda', generator=g) * 0.1).to(torch.bfloat16)
+            kb = torch.zeros(B, L, device='cuda')
+            params = list(tr.parameters()) + [qe]
+            opt = torch.optim.SGD(params, lr=0.05)
+            outs = []
+            for step in range(3):
+                opt.zero_grad(set_to_none=True)
+                hs = tr(vid, sk, kb, pos, qe)
+                (hs.float() ** 2).mean().backward()
+                outs.append(hs.detach().float().clone())
+                if opt_kind == 'sgd':
+                    opt.step()
+                else:   # rewrite every parameter in place without an optimizer
+                    with torch.no_grad():
+                        for p in params:
+                            if p.grad is not None:
+                                p.copy_(p - 0.05 * p.grad)
+            torch.cuda.synchronize()
+            return outs, [p.detach().clone() for p in params]
+        finally:
+            blocks.ENABLED = old
+
+    o_blk, p_blk = run(True)
+    o_ref, p_ref = run(False)
+    assert float((o_blk[0] - o_ref[0]).abs().max()) <= 2e-2                       # same programs, same kernels
+    moved = float((o_ref[2] - o_ref[0]).abs().max())
+    assert moved > 0.05                                                              # the updates really change the outputs ...
+    for a, b in zip(o_blk[1:], o_ref[1:]):
+        assert float((a - b).abs().max()) <= 0.1 * moved + 2e-2, (float((a - b).abs().max()), moved)   # ... and the plans see them
+    for a, b in zip(p_blk, p_ref):                                                   # backward used the current W^T too
+        assert float((a - b).abs().max()) <= 2e-2 * max(1.0, float(b.abs().max()))
