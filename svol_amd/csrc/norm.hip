@@ -245,7 +245,8 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) y[i] = from_f32<T>(to_f32(x[i]) * dropout_scale(seed, (uint64_t)i, p, inv_keep));
 }
-__global__ __launch_bounds__(256) void dropout_add_kernel(const float* __restrict__ t, const float* __restrict__ res, float* __restrict__ out,
+// (t, res and out may alias — ops.dropout_add runs in place on t: no __restrict__)
+__global__ __launch_bounds__(256) void dropout_add_kernel(const float* t, const float* res, float* out,
                                                           int64_t n, float p, float inv_keep, uint64_t seed) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;

@@ -8,8 +8,9 @@ every decoder layer, losses, backward, fused AdamW — is captured ONCE and repl
 
 Per step the host only (1) copies the new inputs into the static input tensors, (2) flattens the new
 targets into the fixed-capacity static target buffers (`StaticPackedTargets.load`) and (3) replays.
-The dropout masks stay fresh because their seed is offset by a device-side step counter that the
-graph itself increments.
+The SVANet input-projection dropout masks stay fresh because their seed is offset by a device-side step
+counter that the graph itself increments.  The enc/dec Transformer's attention / residual / FFN dropouts
+take their seeds from the host and REFUSE capture in training mode (svol_amd/modeling/transformer.py::_drop).
 """
 from __future__ import annotations
 

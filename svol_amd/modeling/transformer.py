@@ -64,6 +64,12 @@ def _drop(mod, seed, site_a, site_b):
     residual dropout1, cross-attention probabilities / dropout2, FFN hidden dropout / the FFN's residual dropout."""
     if not (mod.training and mod.dropout_p > 0.0):
         return None
+    if torch.cuda.is_current_stream_capturing():
+        # the seeds are host integers passed BY VALUE into the launches: a captured graph would replay one step's masks forever
+        # (ADVICE r3).  The SVANet input projections take a device-side seed offset (svol_layernorm_fwd's seed_offset_dev) and can be
+        # captured; the enc/dec Transformer's attention / residual / FFN dropouts cannot.
+        raise RuntimeError('training-mode dropout of the enc/dec Transformer cannot be captured in a hipGraph (its mask seeds are host '
+                           'values): run the step eagerly, or set --dropout 0')
     if seed is None:
         mod._own_step = getattr(mod, '_own_step', 0) + 1
         seed = (0x5EED << 40) + (mod._own_step << 20)
@@ -245,13 +251,22 @@ class Transformer(nn.Module):
         self.d_model = d_model
         self.nhead = nhead
         self.compute_dtype = _DTYPES[compute_dtype]
-        self.drop_base_seed = 1     # dropout masks are a function of (drop_base_seed, training step, layer, site, element)
+        # dropout masks are a function of (drop_base_seed + rank, training step, layer, site, element): different on every rank of a
+        # data-parallel job (each rank sees its own videos AND its own masks, as with torch's per-process generators), continued
+        # after a resume through dropout_state() / load_dropout_state() (svol_amd.utils.checkpoint keeps them in the file)
+        self.drop_base_seed = 1
         self._drop_step = 0
 
     def _reset_parameters(self):
         for p in self.parameters():
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
+
+    def dropout_state(self):
+        return {'drop_base_seed': int(self.drop_base_seed), 'drop_step': int(self._drop_step)}
+
+    def load_dropout_state(self, st):
+        self.drop_base_seed, self._drop_step = int(st['drop_base_seed']), int(st['drop_step'])
 
     def forward(self, src, mask, query_embed, pos_embed, need_weights: bool = True):
         """src [B,L,d] (fp32: it starts the fp32 residual stream), mask [B,L] bool with True on PADDED positions (or
@@ -274,10 +289,18 @@ class Transformer(nn.Module):
         seed = None
         if self.training:
             self._drop_step += 1
-            seed = (int(self.drop_base_seed) << 44) + (self._drop_step << 12)
+            seed = ((int(self.drop_base_seed) + _rank()) << 44) + (self._drop_step << 12)
         mem32, mem, mempos = self.encoder(src32.contiguous(), pos.contiguous(), kbias, seed)
         hs, att = self.decoder(mem, mempos, qpos, kbias, need_weights, seed)
         return hs, mem32, att
+
+
+def _rank():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank()
+    import os
+    return int(os.environ.get('RANK', 0))
 
 
 def build_transformer(args):

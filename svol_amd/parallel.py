@@ -145,6 +145,12 @@ class BucketedGradAllReduce:
         b = self.buckets[bi]
         self.fire_order.extend([bi] * n)
         b['pending'] -= n
+        if b['pending'] < 0:
+            # a second backward() without zero_grad() in between (gradient accumulation): the bucket was already handed to the
+            # exchange once — reducing it again would double-count
+            raise RuntimeError('BucketedGradAllReduce: more gradients arrived for a bucket than it has parameters — call zero_grad() '
+                               'before every backward() (gradient accumulation over several backward passes is not supported by the '
+                               'block programs\' gradient sinks)')
         if b['pending'] == 0:
             self._launch(b)
 
@@ -207,7 +213,10 @@ class BucketedGradAllReduce:
                                        'BucketedGradAllReduce.zero_grad() instead of optimizer.zero_grad()')
 
     def finish(self, mean: bool = True):
-        """Wait for every in-flight bucket and turn sums into means.  Call after backward().
+        """Wait for every in-flight bucket and turn sums into means.  Call after backward() — MANDATORY before anything reads
+        ``param.grad`` (a gradient-norm log, clipping, a torch optimizer), also at world size 1: the block programs write the gradient
+        buckets from the query-half and weight-gradient streams without autograd edges to the parameters, so ``backward()``
+        returning does not order those streams against the caller's; this call does.
         mean=False: leave the SUMS in the buckets and remember the factor (``pending_scale`` = 1 / world) for ``FlatAdamW.step()``,
         which applies it inside its one pass over the gradients (no multiply launch per bucket)."""
         if self.on_gpu:

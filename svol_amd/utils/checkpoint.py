@@ -46,6 +46,11 @@ def save_checkpoint(path, model, optimizer, lr_scheduler, iter_i: int, args, amp
     ckpt = {'model': sd, 'optimizer': optimizer.state_dict() if optimizer is not None else None,
             'lr_scheduler': lr_scheduler.state_dict() if lr_scheduler is not None else None,
             'amp': amp_state if amp_state is not None else NEUTRAL_AMP_STATE, 'iter': int(iter_i), 'args': args}
+    # not in the reference's schema (its drivers ignore unknown entries): where the stateless dropout masks of the enc/dec Transformer
+    # continue after a resume — module path -> {'drop_base_seed', 'drop_step'}.  (amp_state: pass DynamicLossScaler.state_dict() for fp16.)
+    rng = {n: m.dropout_state() for n, m in model.named_modules() if hasattr(m, 'dropout_state')}
+    if rng:
+        ckpt['svol_dropout'] = rng
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     torch.save(ckpt, path)
     return path
@@ -71,6 +76,11 @@ def load_checkpoint(path, model, optimizer=None, lr_scheduler=None, resume_all: 
             sd.pop(k)
     model.load_state_dict(sd)  # strict: a missing or unexpected head key is an error, as in the reference
     info = {'iter': ckpt.get('iter'), 'set_aside': set_aside, 'amp': ckpt.get('amp')}
+    if resume_all and ckpt.get('svol_dropout'):
+        mods = dict(model.named_modules())
+        for n, st in ckpt['svol_dropout'].items():
+            if n in mods and hasattr(mods[n], 'load_dropout_state'):
+                mods[n].load_dropout_state(st)
     if resume_all:
         if optimizer is not None and ckpt.get('optimizer') is not None:
             optimizer.load_state_dict(ckpt['optimizer'])

@@ -43,3 +43,34 @@ def test_round_trip_with_ddp_prefix_and_foreign_backbone(tmp_path):
     for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
     assert opt2.param_groups[0]['lr'] == 1e-4
+
+
+def test_dropout_stream_position_survives_a_resume(tmp_path):
+    """the enc/dec Transformer's stateless dropout masks are a function of (base seed + rank, training step, ...); the step
+    counter is host state and used to restart from 0 after a resume.  It travels in the checkpoint (an entry the reference's drivers
+    ignore) and the rank is folded into the seed."""
+    from svol_amd import synthetic as syn
+    from svol_amd.modeling import transformer as T
+    from svol_amd.modeling.svanet_variants import build_svanet
+    args = syn.encdec_args(dropout=0.1, input_dropout=0.0)
+    torch.manual_seed(1)
+    m1 = build_svanet(args)
+    tr = [m for m in m1.modules() if isinstance(m, T.Transformer)][0]
+    tr._drop_step, tr.drop_base_seed = 1234, 7
+    path = C.save_checkpoint(str(tmp_path / 'x.ckpt'), m1, None, None, 3, args)
+    raw = torch.load(path, weights_only=False)
+    assert list(raw['svol_dropout'].values()) == [{'drop_base_seed': 7, 'drop_step': 1234}]
+    m2 = build_svanet(args)
+    C.load_checkpoint(path, m2, resume_all=True)
+    tr2 = [m for m in m2.modules() if isinstance(m, T.Transformer)][0]
+    assert (tr2._drop_step, tr2.drop_base_seed) == (1234, 7)
+    import os
+    old = os.environ.get('RANK')
+    try:
+        os.environ['RANK'] = '3'
+        assert T._rank() == 3
+    finally:
+        if old is None:
+            os.environ.pop('RANK')
+        else:
+            os.environ['RANK'] = old

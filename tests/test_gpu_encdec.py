@@ -123,6 +123,26 @@ def test_training_mode_dropout_changes_masks_every_step_and_eval_is_deterministi
     assert o1.shape == (2, args.num_queries, 2)
 
 
+def test_training_mode_dropout_refuses_graph_capture():
+    """the mask seeds are host values baked into a captured launch — every replay would reuse one step's masks.  Refused."""
+    from svol_amd import synthetic as syn
+    from svol_amd.modeling.svanet_variants import build_svanet
+    args = syn.encdec_args(dropout=0.1, input_dropout=0.0)
+    torch.manual_seed(1)
+    model = build_svanet(args).cuda().train()
+    inp = syn.synth_encdec_inputs(args, 2, 16, 2)
+    a = tuple(inp[k].cuda() for k in ('src_sketch', 'src_sketch_mask', 'src_video', 'src_video_mask'))
+    model(*a)                                  # warm: allocations, weight copies
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with pytest.raises(RuntimeError, match='cannot be captured'):
+        with torch.cuda.stream(s), torch.cuda.graph(g, stream=s):
+            model(*a)
+    torch.cuda.synchronize()
+
+
 def test_sketch_detr_criterion_is_per_frame():
     """loss.py:159-190: with --sketch_head sketch_detr the criterion returns one loss dict per frame output, each matched
     against the video's targets; checked against the oracle criterion run on the same outputs."""
