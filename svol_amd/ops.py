@@ -236,7 +236,11 @@ def _wgrad_stream(dev):
     return ws
 
 
-WGRAD_GATE = os.environ.get('SVOL_NO_WGRAD_GATE') is None
+# Round 3 gated the queued weight-gradient GEMMs to start beside the (two-pass, 256-VGPR, two workgroups per CU) attention backward.
+# Round 4's single-pass backward owns a CU's whole register file (one 512-register wave per SIMD): nothing can run beside it, a gated
+# GEMM only takes CUs away from it between its workgroup rounds — same box, same build: 19.72 ms/step gated (attention backward 1.31 ms
+# in the step against 1.04 alone), 19.45 ungated (1.04 in the step).  Off by default; SVOL_WGRAD_GATE=1 restores it.
+WGRAD_GATE = os.environ.get('SVOL_WGRAD_GATE') is not None and os.environ.get('SVOL_NO_WGRAD_GATE') is None
 
 
 def flush_wgrad(gate=False):

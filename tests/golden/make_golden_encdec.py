@@ -49,6 +49,15 @@ CASES['encdec_train_append_post'] = dict(head='variants', over=dict(mode='append
                                          B=2, L=24, Ls=2, pad=5, train=True)
 CASES['encdec_train_qry_pre'] = dict(head='variants', over=dict(mode='concat_to_qry', pre_norm=True, dropout=0.25, input_dropout=0.0),
                                      B=2, L=24, Ls=1, pad=0, train=True)
+# training-mode dropout at a size that reaches the product's REAL kernels (128-row-tile attention with the
+# dropout branch, the key-split cross-attention, svol_dropout_add on [B*L, d] at L >= 2304): d = 256, 8 heads, L = 2304 (+1 sketch
+# token), 100 queries, the reference's default p = 0.1.  The attention-probability masks alone are 85 M bits: the fixture keeps the
+# RECIPE instead of the bits — the recording dropout draws mask k as torch.rand(shape_k, generator=Generator().manual_seed(1234)) >= p
+# in call order, the sizes are stored, and the tests redraw them (same torch build here and on the GPU box).
+CASES['encdec_train_mid_append_post'] = dict(
+    head='variants', over=dict(mode='append_to_seq', pre_norm=False, hidden_dim=256, nheads=8, dim_feedforward=512, enc_layers=1,
+                               dec_layers=2, num_queries=100, feat_dim=64, dropout=0.1, input_dropout=0.0),
+    B=2, L=2304, Ls=1, pad=300, train=True)
 
 
 def probe_loss(stack_logits, stack_boxes):
@@ -121,7 +130,11 @@ def run(name, c):
     if c.get('train'):
         rec['n_masks'] = np.asarray(len(masks))
         rec['mask_sizes'] = np.asarray([m.size for m in masks], np.int64)
-        rec['mask_bits'] = np.packbits(np.concatenate(masks))
+        if sum(m.size for m in masks) <= (1 << 22):
+            rec['mask_bits'] = np.packbits(np.concatenate(masks))
+        else:   # too many to store: the recipe (seed, sizes, draw order) regenerates them; a checksum guards the redraw
+            rec['mask_seed'] = np.asarray(1234, np.int64)
+            rec['mask_popcounts'] = np.asarray([int(m.sum()) for m in masks], np.int64)
         rec['dropout_p'] = np.asarray(args.dropout)
     for k, p in model.named_parameters():
         grad_record(rec, k, p.grad)

@@ -107,6 +107,63 @@ def test_training_mode_dropout_matches_the_oracle_under_shared_masks(name, dtype
         assert worst <= 2e-2, (wk, worst)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+def test_training_mode_dropout_at_mid_size_reaches_the_tile_kernels(dtype):
+    """the d = 32, L = 24 toys never reach the dropout branches of the 128-row-tile attention kernels, the key-split
+    cross-attention or svol_dropout_add on a [B*L, d] stream with L >= 2304.  `encdec_train_mid_append_post`: d = 256, 8 heads of 32,
+    L = 2304 (+ 1 sketch token, 300 padded), 100 queries, 1 + 2 layers, the reference's default p = 0.1 — the oracle's training forward
+    is pinned against the reference at THIS size (tests/test_oracle_encdec.py, masks redrawn from the fixture's recipe); here the device
+    runs one training step and the oracle replays it under the DEVICE's masks.  Bars = those of the eval-mode goldens of the same
+    size (gpu_checks.check_encdec_case): fp32 1e-3; bf16 1e-2 on the final layer and 1.5e-2 on the auxiliary layers, logits relative to
+    the largest reference logit once that exceeds 1 (they are unbounded; boxes are absolute); gradients: whole-model L2 2e-3 / 6e-2."""
+    import math
+    from oracle import encdec_oracle as E
+    from svol_amd import synthetic as syn
+    from svol_amd.modeling.svanet_variants import build_svanet
+    from tests.helpers import encdec_case, encdec_stack
+    z, meta, args, sd, inp = encdec_case('encdec_train_mid_append_post')
+    assert args.dropout == 0.1 and args.hidden_dim == 256 and meta['L'] == 2304
+    args.compute_dtype = 'fp32' if dtype == torch.float32 else 'bf16'
+    model = build_svanet(args)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().train()
+    a = tuple(inp[k].cuda() for k in ('src_sketch', 'src_sketch_mask', 'src_video', 'src_video_mask'))
+    out = model(*a)
+    logits, boxes = encdec_stack(out, meta['head'])
+    wl, wb = syn.synth_probe(logits.shape, 'logits').cuda(), syn.synth_probe(boxes.shape, 'boxes').cuda()
+    ((logits * wl).sum() + (boxes * wb).sum()).backward()
+    torch.cuda.synchronize()
+    L_seq = meta['L'] + meta['Ls']
+    masks = _device_masks(model, args, meta['B'], L_seq, args.dropout)
+    keep = masks[0].reshape(-1)
+    assert abs(float((keep > 0).float().mean()) - 0.9) < 0.01
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    feed = E.MaskFeed(masks)
+    ref = E.svanet_variant_forward(sdr, args, inp['src_sketch'], inp['src_sketch_mask'], inp['src_video'], inp['src_video_mask'], drop=feed)
+    assert feed.i == len(masks)
+    rl, rb = encdec_stack(ref, meta['head'])
+    ((rl * wl.cpu()).sum() + (rb * wb.cpu()).sum()).backward()
+    fp32 = dtype == torch.float32
+    tol = 1e-3 if fp32 else 1e-2
+    atol = tol if fp32 else 1.5e-2
+    lscale = max(1.0, float(rl.detach().abs().max()))
+    dl, db = (logits.detach().cpu() - rl.detach()).abs(), (boxes.detach().cpu() - rb.detach()).abs()
+    e_l, e_b = float(dl[-1].max()) / lscale, float(db[-1].max())
+    assert float(dl[:-1].max()) <= atol * lscale and float(db[:-1].max()) <= atol, (float(dl[:-1].max()), float(db[:-1].max()), lscale)
+    num = den = 0.0
+    for k, p_ in model.named_parameters():
+        r_ = sdr[k].grad
+        if r_ is None:
+            continue
+        g_ = p_.grad.detach().double().cpu()
+        num += float((g_ - r_.double()).pow(2).sum())
+        den += float(r_.double().pow(2).sum())
+    gl = math.sqrt(num / max(den, 1e-300))
+    print(f'training-mode dropout, mid size, {dtype}: final |dlogits| / {lscale:.2f} {e_l:.2e} |dboxes| {e_b:.2e} gradient L2 {gl:.2e}')
+    assert e_l <= tol and e_b <= tol, (e_l, e_b, lscale)
+    assert gl <= (2e-3 if fp32 else 6e-2), gl
+
+
 def test_training_mode_dropout_changes_masks_every_step_and_eval_is_deterministic():
     from svol_amd import synthetic as syn
     from svol_amd.modeling.svanet_variants import build_svanet
@@ -124,22 +181,23 @@ def test_training_mode_dropout_changes_masks_every_step_and_eval_is_deterministi
 
 
 def test_training_mode_dropout_refuses_graph_capture():
-    """the mask seeds are host values baked into a captured launch — every replay would reuse one step's masks.  Refused."""
-    from svol_amd import synthetic as syn
-    from svol_amd.modeling.svanet_variants import build_svanet
-    args = syn.encdec_args(dropout=0.1, input_dropout=0.0)
-    torch.manual_seed(1)
-    model = build_svanet(args).cuda().train()
-    inp = syn.synth_encdec_inputs(args, 2, 16, 2)
-    a = tuple(inp[k].cuda() for k in ('src_sketch', 'src_sketch_mask', 'src_video', 'src_video_mask'))
-    model(*a)                                  # warm: allocations, weight copies
-    torch.cuda.synchronize()
+    """the mask seeds are host values baked into a captured launch — every replay would reuse one step's masks.  Refused,
+    at the point where a layer asks for its seeds (the enc/dec heads' forward is not capture-safe before that point either)."""
+    from svol_amd.modeling import transformer as T
+    layer = T.TransformerEncoderLayer(32, 4, 64, dropout=0.1).cuda().train()
+    assert T._drop(layer, 1 << 44, 0, 1) is not None          # eager: fine
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
-    with pytest.raises(RuntimeError, match='cannot be captured'):
-        with torch.cuda.stream(s), torch.cuda.graph(g, stream=s):
-            model(*a)
+    with torch.cuda.stream(s):
+        g.capture_begin()
+        try:
+            with pytest.raises(RuntimeError, match='cannot be captured'):
+                T._drop(layer, 1 << 44, 0, 1)
+            layer.eval()
+            assert T._drop(layer, 1 << 44, 0, 1) is None       # no dropout in eval mode: nothing to refuse
+        finally:
+            g.capture_end()
     torch.cuda.synchronize()
 
 
