@@ -46,8 +46,16 @@ __device__ __forceinline__ void tn_dma_body(const TnFastArgs& p, const int bid) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wk = wave & 1;
-    const int split = bid % p.splits, tile = bid / p.splits;
-    const int kt_ = tile % p.ktiles, nt_ = tile / p.ktiles;
+    // Workgroup -> (row chunk, 128-column tile of A, 128-column tile of B).  The tiles that share an A panel (same rows, same A
+    // columns, different B columns) read the SAME A bytes: they must meet in one L2 at the same time.  Consecutive workgroup ids
+    // go round-robin over the 8 XCDs, so an item (A tile, row chunk) takes id % 8 = its XCD and its ktiles B tiles follow each
+    // other 8 ids apart.  (Round 3 walked all row chunks of one output tile first: every A panel came from HBM ktiles times —
+    // 947 MiB moved for 613 MiB of operands in the video half's grouped launch.)
+    const int per8 = 8 * p.ktiles, g8 = bid / per8, r8 = bid - g8 * per8;
+    const int kt_ = r8 >> 3, item = g8 * 8 + (r8 & 7);
+    const int nitems = p.splits * ((p.N + 127) / 128);
+    if (item >= nitems) return;               // (the last group of 8 is padded)
+    const int split = item % p.splits, nt_ = item / p.splits;
     const int n0 = nt_ * 128, k0 = kt_ * 128;
     const int m_begin = split * p.m_chunk;
     const int m_end = min(p.Mc, m_begin + p.m_chunk);
@@ -221,7 +229,7 @@ bool tn_plan(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, i
     if (chunk * ldmax * 2 >= (1ll << 31)) return false;  // 32-bit buffer offsets
     out = TnFastArgs{(const h16_t*)A, (const h16_t*)B, C, colsum, lda, ldb, ldc, (int)Mc, (int)N, (int)K, (int)chunk,
                      (int)((K + 127) / 128), (int)splits};
-    wgs = splits * tiles;
+    wgs = ((splits * ((N + 127) / 128) + 7) / 8) * 8 * ((K + 127) / 128);   // items padded to whole groups of 8 (tn_dma_body)
     return true;
 }
 
