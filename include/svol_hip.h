@@ -196,6 +196,11 @@ int svol_posenc_sine(const float* mask, void* pos, int64_t B, int64_t L, int64_t
  * Unmasked bf16 launches with dh == 32 and pre-multiplied q use it for one int per workgroup (batch, head, 128-query tile): the
  * fast forward anchors the softmax once per query and FLAGS a workgroup whose row sums overflowed; the per-tile-maximum kernel
  * launched right behind it recomputes exactly the flagged ones.  Without scratch only the per-tile-maximum kernel runs.
+ * Unmasked 16-bit launches with H == 8, dh == 32, pre-multiplied q, Lq and Lk multiples of 128 and Lk >= 1024 (the video
+ * self-attention) run the BACKWARD as one pass when the scratch holds B*Lq*H*dh + B*H*4*2*(Lk % 512)*dh floats: an fp32 dQ image that
+ * key-stationary 512-key workgroups add to with fp32 atomics (rounded into dq at the end) and the dK / dV partials of a head's tail key
+ * group (csrc/attention_bf16.hip: attn_bwd_sp_bf16; 10 instead of 16 matrix products per score block and one exp pass instead of two).
+ * dK / dV are bit-reproducible, dQ to fp32 summation order.  Without that much scratch the two-pass kernels run.
  * svol_attn_ws_bytes() returns the largest of these needs for the shape.  Nothing is allocated inside the library.
  * Replaces the core of nn.MultiheadAttention (cross_modal_transformer.py:139,147,154). */
 int64_t svol_attn_ws_bytes(int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t dh);
@@ -250,6 +255,17 @@ int svol_gate_vectors_fwd(const float* skch, const float* W_in, const float* b_i
                           int64_t H, void* stream);
 int svol_gate_vectors_bwd(const float* du, const float* skch, const float* W_in, const float* q, float* dq_ws, float* dskch,
                           float* dW_in, float* db_in, int64_t B, int64_t D, int64_t H, void* stream);
+/* The gate vectors of up to SVOL_GATE_VEC_MAX_LAYERS layers that read the SAME sketch token, one launch forward and two backward for
+ * all of them (the reference computes them layer by layer inside nn.MultiheadAttention, cross_modal_transformer.py:122-123; they
+ * depend on the sketch token and the layer's parameters only).  Every pointer argument except skch is a HOST array of n_layers device
+ * pointers with the meaning of the single-layer entry; dskch[l] receives layer l's sketch gradient (the caller adds them up), the
+ * array or an entry of it may be NULL. */
+#define SVOL_GATE_VEC_MAX_LAYERS 8
+int svol_gate_vectors_fwd_multi(const float* skch, const float* const* W_in, const float* const* b_in, float* const* q_out,
+                                float* const* u_out, int64_t n_layers, int64_t B, int64_t D, int64_t H, void* stream);
+int svol_gate_vectors_bwd_multi(const float* const* du, const float* skch, const float* const* W_in, const float* const* q,
+                                float* const* dq_ws, float* const* dskch, float* const* dW_in, float* const* db_in, int64_t n_layers,
+                                int64_t B, int64_t D, int64_t H, void* stream);
 
 /* ---- set matching + criterion (matcher.py:38-159, loss.py:39-157) -------
  * A "problem" is one LSAP block the reference solves with scipy: one video for

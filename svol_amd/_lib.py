@@ -69,6 +69,8 @@ SIGNATURES = {
                       _p],
     'svol_gate_vectors_fwd': [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
     'svol_gate_vectors_bwd': [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
+    'svol_gate_vectors_fwd_multi': [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
+    'svol_gate_vectors_bwd_multi': [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     'svol_match_cost': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _f32, _f32, _f32, _p, _p],
     'svol_lsap_batched': [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p],
     'svol_set_loss': [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _f32, _p, _i32, _p, _p, _i32, _p],

@@ -459,9 +459,9 @@ __global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const float* __rest
 // forward: block = one (head, batch element), 256 threads.  Phase 1: the head's d_h rows of W_q, one wave per row (lanes split the
 // d columns, 16-byte loads, wave reduction) -> q[b, h*dh .. ]; phase 2: thread = column c, u[b,h,c] = sc * sum_e q[e] W_k[h*dh+e][c]
 // (row reads coalesced over the threads).
-__global__ __launch_bounds__(256) void gate_vec_fwd_kernel(const float* __restrict__ skch, const float* __restrict__ W,
-                                                           const float* __restrict__ bias, float* __restrict__ q_out,
-                                                           float* __restrict__ u_out, int D, int H) {
+__device__ __forceinline__ void gate_vec_fwd_body(const float* __restrict__ skch, const float* __restrict__ W,
+                                                  const float* __restrict__ bias, float* __restrict__ q_out,
+                                                  float* __restrict__ u_out, int D, int H) {
     __shared__ float s_q[GP * 256];
     const int hh = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, dh = D / H;
     float sv[GP][4];
@@ -495,9 +495,13 @@ __global__ __launch_bounds__(256) void gate_vec_fwd_kernel(const float* __restri
         u_out[((int64_t)b * H + hh) * D + c] = acc * sc;
     }
 }
+__global__ __launch_bounds__(256) void gate_vec_fwd_kernel(const float* skch, const float* W, const float* bias, float* q_out,
+                                                           float* u_out, int D, int H) {
+    gate_vec_fwd_body(skch, W, bias, q_out, u_out, D, H);
+}
 // backward A: block = one (head, batch element): dq[b, h*dh+e] = sc * du[b,h,:] . W_k[h*dh+e,:], one wave per row
-__global__ __launch_bounds__(256) void gate_vec_bwd_a_kernel(const float* __restrict__ du, const float* __restrict__ W,
-                                                             float* __restrict__ dq_out, int D, int H) {
+__device__ __forceinline__ void gate_vec_bwd_a_body(const float* __restrict__ du, const float* __restrict__ W,
+                                                    float* __restrict__ dq_out, int D, int H) {
     const int hh = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, dh = D / H;
     const float sc = rsqrtf((float)dh);
     float gv[GP][4];
@@ -527,10 +531,13 @@ __global__ __launch_bounds__(256) void gate_vec_bwd_a_kernel(const float* __rest
 // backward B: blocks 0 .. D-1 = one row e of W_q and of W_k: dW_q[e][c] += sum_b dq[b][e] s[b][c] ; dW_k[e][c] += sc * sum_b q[b][e]
 // du[b][h(e)][c] ; db_q[e] += sum_b dq[b][e] (every output element has one owner: plain read-modify-write into the gradient, sink
 // or zeroed buffer); blocks D .. D+B-1 = one batch element: dskch[b][c] = sum_e dq[b][e] W_q[e][c] (row reads coalesced over c).
-__global__ __launch_bounds__(256) void gate_vec_bwd_b_kernel(const float* __restrict__ du, const float* __restrict__ skch,
-                                                             const float* __restrict__ q, const float* __restrict__ dq,
-                                                             const float* __restrict__ W, float* __restrict__ dW,
-                                                             float* __restrict__ db, float* __restrict__ dskch, int B, int D, int H) {
+__global__ __launch_bounds__(256) void gate_vec_bwd_a_kernel(const float* du, const float* W, float* dq_out, int D, int H) {
+    gate_vec_bwd_a_body(du, W, dq_out, D, H);
+}
+__device__ __forceinline__ void gate_vec_bwd_b_body(const float* __restrict__ du, const float* __restrict__ skch,
+                                                    const float* __restrict__ q, const float* __restrict__ dq,
+                                                    const float* __restrict__ W, float* __restrict__ dW,
+                                                    float* __restrict__ db, float* __restrict__ dskch, int B, int D, int H) {
     const int tid = threadIdx.x, dh = D / H;
     if ((int)blockIdx.x >= D) {
         const int b = blockIdx.x - D;
@@ -576,6 +583,37 @@ __global__ __launch_bounds__(256) void gate_vec_bwd_b_kernel(const float* __rest
         for (int b = 0; b < B; ++b) bsum += dq[(int64_t)b * D + e];
         db[e] += bsum;
     }
+}
+__global__ __launch_bounds__(256) void gate_vec_bwd_b_kernel(const float* du, const float* skch, const float* q, const float* dq,
+                                                             const float* W, float* dW, float* db, float* dskch, int B, int D, int H) {
+    gate_vec_bwd_b_body(du, skch, q, dq, W, dW, db, dskch, B, D, H);
+}
+
+// All layers' gate vectors in one launch each way (blockIdx.z = layer).  Round 4: the six per-layer backward pairs (13 + 50 us of
+// latency-bound B*d-sized algebra each) ran one after the other at the very END of backward — their autograd nodes are the oldest —
+// with nothing else left to overlap: 0.38 ms of the step.  The layers are independent; side by side they take one pair's time.
+struct GateVecMulti {
+    const float* du[SVOL_GATE_VEC_MAX_LAYERS];
+    const float* W[SVOL_GATE_VEC_MAX_LAYERS];
+    const float* bias[SVOL_GATE_VEC_MAX_LAYERS];
+    float* q[SVOL_GATE_VEC_MAX_LAYERS];
+    float* u[SVOL_GATE_VEC_MAX_LAYERS];
+    float* dq[SVOL_GATE_VEC_MAX_LAYERS];
+    float* dW[SVOL_GATE_VEC_MAX_LAYERS];
+    float* db[SVOL_GATE_VEC_MAX_LAYERS];
+    float* dskch[SVOL_GATE_VEC_MAX_LAYERS];
+};
+__global__ __launch_bounds__(256) void gate_vec_fwd_multi_kernel(const float* skch, GateVecMulti g, int D, int H) {
+    const int l = blockIdx.z;
+    gate_vec_fwd_body(skch, g.W[l], g.bias[l], g.q[l], g.u[l], D, H);
+}
+__global__ __launch_bounds__(256) void gate_vec_bwd_a_multi_kernel(GateVecMulti g, int D, int H) {
+    const int l = blockIdx.z;
+    gate_vec_bwd_a_body(g.du[l], g.W[l], g.dq[l], D, H);
+}
+__global__ __launch_bounds__(256) void gate_vec_bwd_b_multi_kernel(const float* skch, GateVecMulti g, int B, int D, int H) {
+    const int l = blockIdx.z;
+    gate_vec_bwd_b_body(g.du[l], skch, g.q[l], g.dq[l], g.W[l], g.dW[l], g.db[l], g.dskch[l], B, D, H);
 }
 
 int rows_per_wave(int64_t rows, int64_t target_waves) {
@@ -690,6 +728,42 @@ int svol_gate_vectors_bwd(const float* du, const float* skch, const float* W_in,
     hipLaunchKernelGGL(gate_vec_bwd_a_kernel, dim3((unsigned)H, (unsigned)B), dim3(256), 0, s, du, W_in, dq_ws, (int)D, (int)H);
     hipLaunchKernelGGL(gate_vec_bwd_b_kernel, dim3((unsigned)(D + B)), dim3(256), 0, s, du, skch, q, dq_ws, W_in, dW_in, db_in, dskch,
                        (int)B, (int)D, (int)H);
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+// n_layers problems that share skch: per-layer pointer arrays (host arrays of n_layers device pointers).  dskch: per-layer [B, D]
+// outputs (the caller sums them: every layer's sketch gradient has its own owner, no atomics), or NULL.
+int svol_gate_vectors_fwd_multi(const float* skch, const float* const* W_in, const float* const* b_in, float* const* q_out,
+                                float* const* u_out, int64_t n_layers, int64_t B, int64_t D, int64_t H, void* stream) {
+    if (!skch || !W_in || !b_in || !q_out || !u_out || B <= 0 || D <= 0 || H <= 0 || n_layers <= 0) return SVOL_E_INVALID;
+    if (D % 4 || D > GP * 256 || H > GH || D % H || B > 65535 || n_layers > SVOL_GATE_VEC_MAX_LAYERS) return SVOL_E_UNSUPPORTED;
+    GateVecMulti g{};
+    for (int l = 0; l < n_layers; ++l) {
+        if (!W_in[l] || !b_in[l] || !q_out[l] || !u_out[l] || !aligned16(W_in[l])) return SVOL_E_INVALID;
+        g.W[l] = W_in[l]; g.bias[l] = b_in[l]; g.q[l] = q_out[l]; g.u[l] = u_out[l];
+    }
+    hipLaunchKernelGGL(gate_vec_fwd_multi_kernel, dim3((unsigned)H, (unsigned)B, (unsigned)n_layers), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), skch, g, (int)D, (int)H);
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_gate_vectors_bwd_multi(const float* const* du, const float* skch, const float* const* W_in, const float* const* q,
+                                float* const* dq_ws, float* const* dskch, float* const* dW_in, float* const* db_in, int64_t n_layers,
+                                int64_t B, int64_t D, int64_t H, void* stream) {
+    if (!du || !skch || !W_in || !q || !dq_ws || !dW_in || !db_in || B <= 0 || D <= 0 || H <= 0 || n_layers <= 0) return SVOL_E_INVALID;
+    if (D % 4 || D > GP * 256 || H > GH || D % H || B > 65535 || n_layers > SVOL_GATE_VEC_MAX_LAYERS) return SVOL_E_UNSUPPORTED;
+    GateVecMulti g{};
+    for (int l = 0; l < n_layers; ++l) {
+        if (!du[l] || !W_in[l] || !q[l] || !dq_ws[l] || !dW_in[l] || !db_in[l] || !aligned16(W_in[l])) return SVOL_E_INVALID;
+        g.du[l] = du[l]; g.W[l] = W_in[l]; g.q[l] = const_cast<float*>(q[l]); g.dq[l] = dq_ws[l]; g.dW[l] = dW_in[l]; g.db[l] = db_in[l];
+        g.dskch[l] = dskch ? dskch[l] : nullptr;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(gate_vec_bwd_a_multi_kernel, dim3((unsigned)H, (unsigned)B, (unsigned)n_layers), dim3(256), 0, s, g, (int)D, (int)H);
+    hipLaunchKernelGGL(gate_vec_bwd_b_multi_kernel, dim3((unsigned)(D + B), 1, (unsigned)n_layers), dim3(256), 0, s, skch, g, (int)B,
+                       (int)D, (int)H);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }

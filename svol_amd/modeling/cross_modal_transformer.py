@@ -113,6 +113,74 @@ class _GateVectorsFn(torch.autograd.Function):
         return dskch, (None if sW is not None else dW), (None if sb is not None else db), None
 
 
+def _ptr_array(tensors):
+    """host array of device pointers (None -> NULL) for the *_multi entry points"""
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+class _GateVectorsAllFn(torch.autograd.Function):
+    """_GateVectorsFn for ALL layers at once (they read the same sketch token): svol_gate_vectors_fwd_multi / _bwd_multi, one launch
+    forward and two backward instead of one and two PER LAYER.  The node is the oldest of the step, so the engine runs its backward
+    last, when every layer's du exists.  Inputs: skch, h, then (in_proj_weight, in_proj_bias) per layer; outputs: one u per layer."""
+
+    @staticmethod
+    def forward(ctx, skch, h, *params):
+        from .. import _lib
+        B, d = skch.shape
+        n = len(params) // 2
+        skch = skch.contiguous().float()
+        dev = skch.device
+        Ws, bs = params[0::2], params[1::2]
+        q = torch.empty((n, B, d), dtype=torch.float32, device=dev)
+        us = [torch.empty((B, h, d), dtype=torch.float32, device=dev) for _ in range(n)]
+        rc = _lib.lib().svol_gate_vectors_fwd_multi(ops._ptr(skch), _ptr_array([w.detach() for w in Ws]), _ptr_array([b.detach() for b in bs]),
+                                                    _ptr_array(list(q.unbind(0))), _ptr_array(us), n, B, d, h, ops._stream())
+        _lib.check(rc, 'svol_gate_vectors_fwd_multi')
+        ctx.save_for_backward(skch, q, *Ws)
+        ctx.h, ctx.n = h, n
+        ctx.sinks = [(ops._claim(Ws[l], ctx.needs_input_grad[2 + 2 * l]), ops._claim(bs[l], ctx.needs_input_grad[3 + 2 * l])) for l in range(n)]
+        return tuple(us)
+
+    @staticmethod
+    def backward(ctx, *dus):
+        from .. import _lib
+        skch, q = ctx.saved_tensors[:2]
+        Ws = ctx.saved_tensors[2:]
+        h, n = ctx.h, ctx.n
+        B, d = skch.shape
+        dev = skch.device
+        dus = [torch.zeros((B, h, d), dtype=torch.float32, device=dev) if g is None else g.contiguous().float() for g in dus]
+        dWs = [sW.view if sW is not None else torch.zeros((3 * d, d), dtype=torch.float32, device=dev) for sW, _ in ctx.sinks]
+        dbs = [sb.view if sb is not None else torch.zeros((3 * d,), dtype=torch.float32, device=dev) for _, sb in ctx.sinks]
+        ws = torch.empty((n, B, d), dtype=torch.float32, device=dev)
+        dsk = torch.empty((n, B, d), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        rc = _lib.lib().svol_gate_vectors_bwd_multi(_ptr_array(dus), ops._ptr(skch), _ptr_array([w.detach() for w in Ws]),
+                                                    _ptr_array(list(q.unbind(0))), _ptr_array(list(ws.unbind(0))),
+                                                    None if dsk is None else _ptr_array(list(dsk.unbind(0))), _ptr_array(dWs),
+                                                    _ptr_array(dbs), n, B, d, h, ops._stream())
+        _lib.check(rc, 'svol_gate_vectors_bwd_multi')
+        grads = [None if dsk is None else dsk.sum(0), None]
+        for l, (sW, sb) in enumerate(ctx.sinks):
+            grads += [None if sW is not None else dWs[l], None if sb is not None else dbs[l]]
+        return tuple(grads)
+
+
+GATE_VECTORS_MULTI_MAX = 8      # SVOL_GATE_VEC_MAX_LAYERS (include/svol_hip.h)
+
+
+def all_gate_vectors(layers, skch):
+    """[layer.gate_vectors(skch) for layer in layers] in one launch each way when the layers allow it"""
+    import os
+    if len(layers) > GATE_VECTORS_MULTI_MAX or len(layers) < 2 or os.environ.get('SVOL_GATE_VEC_PER_LAYER') is not None:
+        return [layer.gate_vectors(skch) for layer in layers]
+    params = []
+    for layer in layers:
+        a = layer.sketch_video_cross_attn
+        params += [a.in_proj_weight, a.in_proj_bias]
+    return list(_GateVectorsAllFn.apply(skch, layers[0].nhead, *params))
+
+
 class CrossModalTransformerLayer(nn.Module):
     def __init__(self, d_model=512, nhead=8, dim_feedforward=D_FF):
         super().__init__()
@@ -219,7 +287,7 @@ class CrossModalTransformer(nn.Module):
         # waits for a CU beside the other streams' kernels (15 us each).  Their autograd nodes get the lowest sequence numbers of the
         # transformer, so the engine runs their backward (two tiny launches per layer, 65 us each in the middle of the backward)
         # after everything else: 6 x 14 us at the end.  (svol_amd.parallel.arrival_order puts these parameters last accordingly.)
-        us = [layer.gate_vectors(src_skch32) for layer in self.layers]
+        us = all_gate_vectors(list(self.layers), src_skch32)
         if not OVERLAP_QUERY_STREAM:
             out = initial_queries()
             for layer, u in zip(self.layers, us):

@@ -274,7 +274,7 @@ def check_attn_weights():
 def check_gemm_tn():
     res = {}
     for dt in DTYPES16:
-        for (Mc, N, K) in [(1000, 64, 32), (333, 200, 136), (64, 8, 8), (5000, 256, 256), (70, 2048, 32)]:
+        for (Mc, N, K) in [(1000, 64, 32), (333, 200, 136), (333, 136, 200), (64, 8, 8), (5000, 256, 256), (70, 2048, 32), (1500, 256, 2048)]:
             A = _rnd((Mc, N), dt, 7)
             Bm = _rnd((Mc, K), dt, 8)
             # asymmetric integer-valued data catches row/col swaps exactly

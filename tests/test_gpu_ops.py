@@ -1,5 +1,7 @@
 """GPU parity tests (run with -m gpu on the MI355X box): every HIP op, through the C-ABI, against
 fp64 torch math / the CPU oracle on identical inputs."""
+import os
+
 import pytest
 import torch
 
@@ -20,7 +22,7 @@ def G():
 
 def test_native_library_loaded():
     from svol_amd import _lib
-    assert _lib.lib().svol_abi_version() == 3
+    assert _lib.lib().svol_abi_version() == 4
 
 
 def test_gemm_nt(G):
@@ -100,3 +102,35 @@ def test_attention_forward_is_deterministic():
         for _ in range(3):
             o1, l1 = ops.attn_fwd(q, k, v, B, H, L, L, DH, None, pm)
             assert torch.equal(o0, o1) and torch.equal(l0, l1)
+
+
+def test_gate_vectors_of_all_layers_in_one_launch_match_the_per_layer_entry():
+    """svol_gate_vectors_fwd_multi / _bwd_multi against the single-layer entry: same u (bit for bit: the same kernel body), same
+    parameter gradients, sketch gradient up to the order of the sum over layers."""
+    import torch
+    from svol_amd.modeling import cross_modal_transformer as C
+    torch.manual_seed(3)
+    layers = [C.CrossModalTransformerLayer(256, 8, 512).cuda() for _ in range(6)]
+    sk = torch.randn(8, 256, device='cuda')
+    rs = [torch.randn(8, 8, 256, device='cuda') for _ in layers]
+
+    def run(per_layer):
+        for l in layers:
+            l.zero_grad(set_to_none=True)
+        s = sk.clone().requires_grad_(True)
+        if per_layer:
+            os.environ['SVOL_GATE_VEC_PER_LAYER'] = '1'
+        try:
+            us = C.all_gate_vectors(layers, s)
+        finally:
+            os.environ.pop('SVOL_GATE_VEC_PER_LAYER', None)
+        sum((u * r).sum() for u, r in zip(us, rs)).backward()
+        a = [l.sketch_video_cross_attn for l in layers]
+        return [u.detach().clone() for u in us], s.grad.clone(), [m.in_proj_weight.grad.clone() for m in a], [m.in_proj_bias.grad.clone() for m in a]
+
+    u1, g1, w1, b1 = run(True)
+    u2, g2, w2, b2 = run(False)
+    for x, y in zip(u1 + w1 + b1, u2 + w2 + b2):
+        assert torch.equal(x, y)
+    assert float((g1 - g2).abs().max()) <= 1e-5 * float(g1.abs().max())
+    assert float(g1.abs().max()) > 0 and all(float(w.abs().max()) > 0 for w in w1)
