@@ -291,6 +291,10 @@ def main():
             fence.tick()
         return out_
 
+    if os.environ.get('SVOL_MAIN_PRIO') is not None:   # lab: the step's main stream above the side streams in queue priority
+        hp = torch.cuda.Stream(priority=int(os.environ['SVOL_MAIN_PRIO']))
+        hp.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hp)
     for _ in range(a.warmup):
         loss = step()
     if not use_graph:

@@ -40,6 +40,7 @@ typedef f16x2 h16x2;
 #define svol_gemm_tn_bf16_grouped svol_gemm_tn_f16_grouped
 #define svol_gemm_ws_bf16 svol_gemm_ws_f16
 #define svol_gemm_n256_bf16 svol_gemm_n256_f16
+#define svol_mlp_chain_bf16 svol_mlp_chain_f16
 #define svol_attn_fwd_bf16_launch svol_attn_fwd_f16_launch
 #define svol_attn_bwd_bf16_launch svol_attn_bwd_f16_launch
 #define svol_attn_ws_floats_bf16 svol_attn_ws_floats_f16

@@ -271,6 +271,38 @@ def check_attn_weights():
     return res
 
 
+def check_mlp_chain():
+    """svol_mlp_chain (both products of the MLP in one launch) against fp64 on the same 16-bit operands: the hidden tensors to the
+    rounding of their type, the second product against the hidden tensor the kernel itself wrote (what the two-launch form reads back)."""
+    import math
+    res = {}
+    for dt in DTYPES16[1:]:
+        eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+        for (M, F) in [(256, 64), (1000, 512), (4352, 2048)]:
+            X = _rnd((M, 256), dt, 1, 1.0)
+            Wa, Wb = _rnd((F, 256), dt, 2, 1.0 / 16), _rnd((256, F), dt, 3, 1.0 / math.sqrt(F))
+            ba, bb = _rnd((F,), torch.float32, 4, 0.5), _rnd((256,), torch.float32, 5, 0.5)
+            r32 = _rnd((M, 256), torch.float32, 6, 1.0)
+            hid, dpre, Y = ops.mlp_chain_fwd(X.to(DEV), Wa.to(DEV), ba.to(DEV), Wb.to(DEV), bb.to(DEV), r32.to(DEV))
+            T = X.double() @ Wa.double().t() + ba.double()
+            Phi = 0.5 * (1 + torch.erf(T / math.sqrt(2)))
+            g = T * Phi
+            dg = Phi + T * torch.exp(-0.5 * T * T) / math.sqrt(2 * math.pi)
+            tag = f'mlp_chain/{dt}/M{M}F{F}'
+            res[tag + '/fwd/hid'] = (float(((hid.cpu().double() - g).abs() / (g.abs() + 1e-2)).max()), 1.2 * eps)
+            res[tag + '/fwd/dpre'] = (float(((dpre.cpu().double() - dg).abs() / (dg.abs() + 1e-2)).max()), 1.2 * eps)
+            Yr = hid.cpu().double() @ Wb.double().t() + bb.double() + r32.double()
+            res[tag + '/fwd/Y'] = (rel_err(Y, Yr), 2e-6)
+            dY = _rnd((M, 256), dt, 7, 1.0)
+            Wbt, Wat = Wb.t().contiguous(), Wa.t().contiguous()   # [F,256], [256,F]
+            dT, dX = ops.mlp_chain_bwd(dY.to(DEV), Wbt.to(DEV), dpre, Wat.to(DEV))
+            dTr = (dY.double() @ Wbt.double().t()) * dpre.cpu().double()
+            res[tag + '/bwd/dT'] = (float(((dT.cpu().double() - dTr).abs() / (dTr.abs() + 1e-2)).max()), 1.2 * eps)
+            dXr = dT.cpu().double() @ Wat.double().t()
+            res[tag + '/bwd/dX'] = (float((dX.cpu().double() - dXr).abs().max() / dXr.abs().max()), 1.2 * eps)
+    return res
+
+
 def check_gemm_tn():
     res = {}
     for dt in DTYPES16:

@@ -46,6 +46,10 @@ def test_attention_weights_mean(G):
     _assert(G.check_attn_weights())
 
 
+def test_mlp_chain(G):
+    _assert(G.check_mlp_chain())
+
+
 def test_gemm_tn(G):
     _assert(G.check_gemm_tn())
 
