@@ -342,8 +342,8 @@ def main():
             eager_step()
         torch.cuda.synchronize()
         ops.timer.disable()
-    # the same two attention launches ALONE (nothing else on the device), right after the timed region: inside the step the backward
-    # launch shares the CUs with the step's weight-gradient GEMMs, which are gated to run beside it
+    # the same two attention launches ALONE (nothing else on the device), right after the timed region: inside the step the query
+    # stream's and the weight-gradient stream's kernels run beside them
     alone = None
     if rank == 0 and a.dtype != 'fp32':
         try:
