@@ -471,8 +471,8 @@ def main():
                 'frac': (2.0 * attn_fwd_flop / (alone['attn_bwd_ms'] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS) if bwd[1] >= fwd[1]
                 else (attn_fwd_flop / (alone['attn_fwd_ms'] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS),
                 'issue_bound_frac': (floor_bwd_ms / alone['attn_bwd_ms']) if bwd[1] >= fwd[1] else (floor_fwd_ms / alone['attn_fwd_ms']),
-                'note': 'measured right after the timed region with nothing else on the device; in the step the weight-gradient GEMMs '
-                        'are gated to run beside the attention backward and take CUs from it'}
+                'note': 'measured right after the timed region with nothing else on the device; in the step the query stream and the '
+                        'weight-gradient stream run beside these launches (the weight-gradient gate of round 3 is off since round 4)'}
         elif alone:
             roof['same_launches_alone'] = alone
 
