@@ -214,10 +214,15 @@ bool tn_plan(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, i
     if (N % 8 || K % 8 || lda % 8 || ldb % 8 || !aligned16(A) || !aligned16(B)) return false;
     if (Mc < 1 || Mc > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return false;
     const int64_t tiles = ((N + 127) / 128) * ((K + 127) / 128);
-    // split the contraction: few, long-running workgroups for small outputs (the final fp32 atomics dominate
-    // there), ~2 per CU otherwise; a multiple of the 8 XCDs so that the tiles of one row chunk share an L2
+    // split the contraction: every split ends in fp32 atomics over its whole output tile, and the kernel shares the chip with the
+    // backward's critical path (it runs on the weight-gradient stream): ~128 workgroups per problem.  Round 4, same box, ms per step
+    // of bench.py against this target: 32 -> 20.1, 64 -> 19.0, 96 -> 18.9, **128 -> 18.6-18.8**, 160 -> 18.9, 256 / 512 by tile count
+    // (rounds 2-3: the best for the kernel ALONE, 146 us against ~200 for the MLP pair) -> 19.1, 512 -> 19.5, 1024 -> 20.9.  A
+    // multiple of the 8 XCDs so that the tiles of one row chunk share an L2.  SVOL_TN_WGS / SVOL_TN_WGS2 (problems with more
+    // than 8 output tiles) override.
     static const int force_wgs = getenv("SVOL_TN_WGS") ? atoi(getenv("SVOL_TN_WGS")) : 0;
-    const int target_wgs = force_wgs ? force_wgs : (tiles <= 8 ? 256 : 512);
+    static const int force_wgs2 = getenv("SVOL_TN_WGS2") ? atoi(getenv("SVOL_TN_WGS2")) : force_wgs;
+    const int target_wgs = tiles <= 8 ? (force_wgs ? force_wgs : 128) : (force_wgs2 ? force_wgs2 : 128);
     int64_t want = (target_wgs + tiles - 1) / tiles;
     if (want > 8) want = want / 8 * 8;
     int64_t chunk = (Mc + want - 1) / want;
