@@ -2126,7 +2126,8 @@ static int plan_ksplit(int B, int H, int Lq, int Lk, int dh, int64_t ws_floats, 
     const int64_t wgs = (int64_t)((Lq + 127) / 128) * H * B;
     *tiles_per_split = nt;
     if (wgs >= 192 || nt < 8) return 1;
-    int want = (int)((512 + wgs - 1) / wgs);
+    static const int target = getenv("SVOL_ATTN_KSPLIT_WGS") ? atoi(getenv("SVOL_ATTN_KSPLIT_WGS")) : 256;   // (these launches run on the query stream beside the video half: 256 -> 18.98 / 19.07 ms per step, 512 -> 19.12, 1024 -> 19.28)
+    int want = (int)((target + wgs - 1) / wgs);
     if (want > 16) want = 16;
     int tps = (nt + want - 1) / want;
     if (tps < 2) tps = 2;
