@@ -618,8 +618,9 @@ static int tn_generic_plan(const void* A, int64_t lda, const void* B, int64_t ld
     static const int force_wgs = getenv("SVOL_TN_WGS") ? atoi(getenv("SVOL_TN_WGS")) : 0;
     // fp32 with few rows (the query stream's weight gradients, Mc = 800): every split adds a full tile of fp32 atomics — 13 splits of the
     // [256, 2048] MLP gradients were 6.8 M atomics per problem, which is what their 87 us were (atomic rate ~128 per clock, tools/micro/
-    // atomic_rate) — so few splits: ~128 workgroups per problem
-    static const int small_wgs = getenv("SVOL_TN_SMALL_WGS") ? atoi(getenv("SVOL_TN_SMALL_WGS")) : 128;
+    // atomic_rate) — so few splits: ~64 workgroups per problem
+    // (round 4, in the step: 64 -> 18.75-18.92 ms, 128 -> 18.94-18.97, 32 -> 18.82, 256 -> 18.90: these launches run beside the video half)
+    static const int small_wgs = getenv("SVOL_TN_SMALL_WGS") ? atoi(getenv("SVOL_TN_SMALL_WGS")) : 64;
     const int target_wgs = force_wgs ? force_wgs : ((dtype == SVOL_F32 && Mc <= 4096) ? small_wgs : (tiles <= 8 ? 256 : 512));
     int64_t want = (target_wgs + tiles - 1) / tiles;
     int64_t chunk = (Mc + want - 1) / want;
