@@ -180,13 +180,14 @@ int svol_layernorm_bwd(const float* dy32, const void* dy, const void* dy2, const
                        uint64_t seed, const int64_t* seed_offset_dev, int dtype, void* stream);
 
 /* ---- stand-alone dropout (the enc/dec Transformer in training mode: transformer.py:165-215 encoder, :225-295 decoder) ----
- * y[i] = x[i] * keep(seed, i), keep = 0 with probability p else 1/(1-p): a stateless counter-based mask of the ELEMENT INDEX, so the
- * backward pass (and a test that wants the mask itself: x = ones) regenerates it from (seed, n).  y may alias x.  The FFN dropout
- * after the activation (:168,:238) and the backward of the residual dropouts. */
-int svol_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
-/* out32[i] = res32[i] + t32[i] * keep(seed, i): the residual dropouts src + dropout1(src2) (:171,:177,:232-247) on the fp32 stream;
+ * y[r, k] = x[r, k] * keep(seed, r, k) over the [n / row_len, row_len] view, keep = 0 with probability p else 1/(1-p): a stateless
+ * counter-based mask of (seed, row, column), so the backward pass (and a test that wants the mask itself: x = ones) regenerates it.
+ * y may alias x.  The FFN dropout after the activation (:168,:238) and the backward of the residual dropouts.  (Round 4: the mask is
+ * keyed by row and column instead of the flat element index — same contract, a five times cheaper generator; row_len <= 2^32.) */
+int svol_dropout(const void* x, void* y, int64_t n, int64_t row_len, float p, uint64_t seed, int dtype, void* stream);
+/* out32 = res32 + t32 * keep(seed, r, k): the residual dropouts src + dropout1(src2) (:171,:177,:232-247) on the fp32 stream;
  * out32 may alias t32. */
-int svol_dropout_add(const float* t32, const float* res32, float* out32, int64_t n, float p, uint64_t seed, void* stream);
+int svol_dropout_add(const float* t32, const float* res32, float* out32, int64_t n, int64_t row_len, float p, uint64_t seed, void* stream);
 
 /* ---- sine positional encoding (position_encoding.py:51-71) -------------- */
 /* mask [B,L] float (1 = valid) -> pos [B,L,D] (dtype). */
@@ -228,8 +229,8 @@ int svol_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const 
                   int dtype, void* stream);
 
 /* The same with attention-probability dropout (nn.MultiheadAttention(dropout = p) in training mode, transformer.py:158-160): the softmax
- * numerators that feed P V are multiplied by keep(seed, ((b*H + h)*Lq + q)*Lk + key) — svol_dropout over a ones tensor [B,H,Lq,Lk] with
- * the same seed IS the mask; lse2 stays the undropped softmax's.  dropout_p > 0 runs on the general kernels (no anchored fast path). */
+ * numerators that feed P V are multiplied by keep(seed, row = (b*H + h)*Lq + q, column = key) — svol_dropout over a ones tensor
+ * [B,H,Lq,Lk] with row_len = Lk and the same seed IS the mask; lse2 stays the undropped softmax's.  dropout_p > 0 runs on the general kernels (no anchored fast path). */
 int svol_attn_fwd_dropout(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                           int64_t ldo, float* lse2, const float* kbias, int64_t B, int64_t H, int64_t Lq, int64_t Lk,
                           int64_t dh, float scale, float q_premul, void* ws, int64_t ws_bytes, float dropout_p, uint64_t seed,

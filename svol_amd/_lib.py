@@ -63,8 +63,8 @@ SIGNATURES = {
                               _f32, _u64, _int, _p],
     'svol_attn_bwd_dropout': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64,
                               _i64, _i64, _i64, _i64, _i64, _f32, _f32, _p, _i64, _f32, _u64, _int, _p],
-    'svol_dropout': [_p, _p, _i64, _f32, _u64, _int, _p],
-    'svol_dropout_add': [_p, _p, _p, _i64, _f32, _u64, _p],
+    'svol_dropout': [_p, _p, _i64, _i64, _f32, _u64, _int, _p],
+    'svol_dropout_add': [_p, _p, _p, _i64, _i64, _f32, _u64, _p],
     'svol_gate_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p],
     'svol_gate_bwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _int,
                       _p],

@@ -183,9 +183,9 @@ struct AttnArgs {
     uint64_t drop_seed;
 };
 
-// keep-mask scale of score element (row, key); rowbase = ((b*H + h)*Lq + q) * Lk
-__device__ __forceinline__ float attn_drop(uint64_t seed, uint64_t rowbase, int key, float p, float inv) {
-    return dropout_scale(seed, rowbase + (uint64_t)key, p, inv);
+// keep-mask scale of score element (row, key); row = (b*H + h)*Lq + q
+__device__ __forceinline__ float attn_drop(uint64_t seed, uint64_t row, int key, float p, float inv) {
+    return dropout_scale(seed, row, (uint32_t)key, p, inv);
 }
 
 template <typename T> struct Smem {
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) O[i] *= alpha;
             if (p.drop_p > 0.f) {
-                const uint64_t rb = (((uint64_t)b * p.H + hh) * p.Lq + (qvalid ? qrow : 0)) * (uint64_t)p.Lk;
+                const uint64_t rb = (((uint64_t)b * p.H + hh) * p.Lq + (qvalid ? qrow : 0));
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
                     const float pe = __builtin_amdgcn_exp2f(S[4 * g + e] * sc + bb[e] - lse);
                     float dpe = dP[4 * g + e];
                     if (p.drop_p > 0.f)
-                        dpe *= attn_drop(p.drop_seed, (((uint64_t)b * p.H + hh) * p.Lq + (qvalid ? qrow : 0)) * (uint64_t)p.Lk,
+                        dpe *= attn_drop(p.drop_seed, (((uint64_t)b * p.H + hh) * p.Lq + (qvalid ? qrow : 0)),
                                          kt + sub * 32 + 8 * g + 4 * h + e, p.drop_p, p.drop_inv);
                     S[4 * g + e] = pe * (dpe - dl) * p.scale;
                 }
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int qi = min(qt + sub * 32 + 8 * g + 4 * h + e, p.Lq - 1);
-                        MS[4 * g + e] = attn_drop(p.drop_seed, (((uint64_t)b * p.H + hh) * p.Lq + qi) * (uint64_t)p.Lk, kvalid ? krow : 0,
+                        MS[4 * g + e] = attn_drop(p.drop_seed, (((uint64_t)b * p.H + hh) * p.Lq + qi), kvalid ? krow : 0,
                                                   p.drop_p, p.drop_inv);
                     }
             }

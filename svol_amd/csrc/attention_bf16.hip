@@ -50,8 +50,8 @@ struct Args {
     uint64_t drop_seed;
     int dq_rot;                   // != 0: the unmasked dQ kernel runs its rotated schedule (dq_phase; SVOL_ATTN_NO_DQ_ROT=1 clears it)
 };
-__device__ __forceinline__ float attn_drop(uint64_t seed, uint64_t rowbase, int key, float p, float inv) {
-    return dropout_scale(seed, rowbase + (uint64_t)key, p, inv);
+__device__ __forceinline__ float attn_drop(uint64_t seed, uint64_t row, int key, float p, float inv) {
+    return dropout_scale(seed, row, (uint32_t)key, p, inv);
 }
 
 typedef __attribute__((address_space(3))) h16x4* lds_bf16x4_ptr;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(Args p) {
             }
         l += (ls[0] + ls[1]) + (ls[2] + ls[3]);
         if (p.drop_p > 0.f) {   // row sums stay those of the undropped softmax; only what feeds P V is masked
-            const uint64_t rb = (((uint64_t)b * p.H + hh) * p.Lq + (qvalid ? qrow : 0)) * (uint64_t)p.Lk;
+            const uint64_t rb = (((uint64_t)b * p.H + hh) * p.Lq + (qvalid ? qrow : 0));
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16(Args p) {
             read_rows(a, vimg, sub * 32 + r, h);
             f32x16 dP = mma_first(a, dob);
             if (p.drop_p > 0.f) {
-                const uint64_t rb = (((uint64_t)b * p.H + hh) * p.Lq + (qvalid ? qrow : 0)) * (uint64_t)p.Lk;
+                const uint64_t rb = (((uint64_t)b * p.H + hh) * p.Lq + (qvalid ? qrow : 0));
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_bf16(Args p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int qi = min(t * KT + sub * 32 + 8 * g + 4 * h + e, p.Lq - 1);
-                        MS[4 * g + e] = attn_drop(p.drop_seed, (((uint64_t)b * p.H + hh) * p.Lq + qi) * (uint64_t)p.Lk, kvalid ? krow : 0,
+                        MS[4 * g + e] = attn_drop(p.drop_seed, (((uint64_t)b * p.H + hh) * p.Lq + qi), kvalid ? krow : 0,
                                                   p.drop_p, p.drop_inv);
                     }
                 f32x16 Pd = S;

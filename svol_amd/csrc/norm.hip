@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float r = (v[j][e] - mu) * rs * gv[j].get(e) + bv[j].get(e);
-                if (p > 0.f) r *= dropout_scale(seed, (uint64_t)(row * D + c + e), p, inv_keep);
+                if (p > 0.f) r *= dropout_scale(seed, (uint64_t)row, (uint32_t)(c + e), p, inv_keep);
                 o.set(e, r);
                 o32.set(e, r);
                 if (pr) op.set(e, r + pv[j].get(e));
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float d = (dy32 ? cur.a32[j].get(e) : 0.f) + (dy ? cur.a[j].get(e) : 0.f) + (dy2 ? cur.b[j].get(e) : 0.f);
-                    if (p > 0.f) d *= dropout_scale(seed, (uint64_t)(row * D + c + e), p, inv_keep);
+                    if (p > 0.f) d *= dropout_scale(seed, (uint64_t)row, (uint32_t)(c + e), p, inv_keep);
                     const float h = (cur.xv[j].get(e) - mu) * rs;
                     xh[j][e] = h;
                     dg[j][e] += d * h;
@@ -237,20 +237,43 @@ __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ m
 
 
 // ---- stand-alone dropout (the enc/dec Transformer's residual / FFN dropouts, transformer.py:165-215,225-295) -------------------------
-// Stateless keep mask of the element index (dropout_scale, common.h): forward and backward regenerate the same mask from (seed, i).
+// Stateless keep mask of (row, column) of the [n / row_len, row_len] view (dropout_scale, common.h): forward and backward regenerate
+// the same mask from (seed, row, column).  A thread walks along a row chunk: the row's share of the hash is computed once per chunk.
 template <typename T>
-__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p, float inv_keep,
-                                                      uint64_t seed) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) y[i] = from_f32<T>(to_f32(x[i]) * dropout_scale(seed, (uint64_t)i, p, inv_keep));
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, int64_t row_len, float p,
+                                                      float inv_keep, uint64_t seed) {
+    const uint32_t s0 = drop_seed32(seed);
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (; i < n; i += stride) {
+        int64_t r = i / row_len;
+        int64_t k = i - r * row_len;
+        uint32_t rm = drop_row(s0, (uint64_t)r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (i + e >= n) break;
+            y[i + e] = from_f32<T>(to_f32(x[i + e]) * drop_scale_rk(rm, (uint32_t)k, p, inv_keep));
+            if (++k == row_len) { k = 0; ++r; rm = drop_row(s0, (uint64_t)r); }
+        }
+    }
 }
 // (t, res and out may alias — ops.dropout_add runs in place on t: no __restrict__)
-__global__ __launch_bounds__(256) void dropout_add_kernel(const float* t, const float* res, float* out,
-                                                          int64_t n, float p, float inv_keep, uint64_t seed) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) out[i] = res[i] + t[i] * dropout_scale(seed, (uint64_t)i, p, inv_keep);
+__global__ __launch_bounds__(256) void dropout_add_kernel(const float* t, const float* res, float* out, int64_t n, int64_t row_len, float p,
+                                                          float inv_keep, uint64_t seed) {
+    const uint32_t s0 = drop_seed32(seed);
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (; i < n; i += stride) {
+        int64_t r = i / row_len;
+        int64_t k = i - r * row_len;
+        uint32_t rm = drop_row(s0, (uint64_t)r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (i + e >= n) break;
+            out[i + e] = res[i + e] + t[i + e] * drop_scale_rk(rm, (uint32_t)k, p, inv_keep);
+            if (++k == row_len) { k = 0; ++r; rm = drop_row(s0, (uint64_t)r); }
+        }
+    }
 }
 }  // namespace
 
@@ -331,28 +354,28 @@ int svol_layernorm_bwd(const float* dy32, const void* dy, const void* dy2, const
     return SVOL_OK;
 }
 
-int svol_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream) {
-    if (!x || !y || n < 0 || !(p >= 0.f && p < 1.f)) return SVOL_E_INVALID;
+int svol_dropout(const void* x, void* y, int64_t n, int64_t row_len, float p, uint64_t seed, int dtype, void* stream) {
+    if (!x || !y || n < 0 || row_len <= 0 || row_len > 0xffffffffll || !(p >= 0.f && p < 1.f)) return SVOL_E_INVALID;
     if (n == 0) return SVOL_OK;
     const float inv = 1.f / (1.f - p);
-    int64_t g = (n + 255) / 256;
+    int64_t g = (n + 1023) / 1024;
     if (g > 8192) g = 8192;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == SVOL_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3((unsigned)g), dim3(256), 0, s, (const float*)x, (float*)y, n, p, inv, seed);
-    else if (dtype == SVOL_BF16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, n, p, inv, seed);
-    else if (dtype == SVOL_F16) hipLaunchKernelGGL(dropout_kernel<f16_t>, dim3((unsigned)g), dim3(256), 0, s, (const f16_t*)x, (f16_t*)y, n, p, inv, seed);
+    if (dtype == SVOL_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3((unsigned)g), dim3(256), 0, s, (const float*)x, (float*)y, n, row_len, p, inv, seed);
+    else if (dtype == SVOL_BF16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, n, row_len, p, inv, seed);
+    else if (dtype == SVOL_F16) hipLaunchKernelGGL(dropout_kernel<f16_t>, dim3((unsigned)g), dim3(256), 0, s, (const f16_t*)x, (f16_t*)y, n, row_len, p, inv, seed);
     else return SVOL_E_INVALID;
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }
 
-int svol_dropout_add(const float* t32, const float* res32, float* out32, int64_t n, float p, uint64_t seed, void* stream) {
-    if (!t32 || !res32 || !out32 || n < 0 || !(p >= 0.f && p < 1.f)) return SVOL_E_INVALID;
+int svol_dropout_add(const float* t32, const float* res32, float* out32, int64_t n, int64_t row_len, float p, uint64_t seed, void* stream) {
+    if (!t32 || !res32 || !out32 || n < 0 || row_len <= 0 || row_len > 0xffffffffll || !(p >= 0.f && p < 1.f)) return SVOL_E_INVALID;
     if (n == 0) return SVOL_OK;
-    int64_t g = (n + 255) / 256;
+    int64_t g = (n + 1023) / 1024;
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(dropout_add_kernel, dim3((unsigned)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), t32, res32, out32, n, p,
-                       1.f / (1.f - p), seed);
+    hipLaunchKernelGGL(dropout_add_kernel, dim3((unsigned)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), t32, res32, out32, n,
+                       row_len, p, 1.f / (1.f - p), seed);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }

@@ -447,18 +447,19 @@ def _attn_ws(q, B, H, Lq, Lk, dh, masked):
 
 
 def dropout(x, p, seed, out=None):
-    """x * keep(seed, element index) (0 or 1/(1-p)); out may be x (in place).  x contiguous."""
+    """x * keep(seed, row, column) (0 or 1/(1-p)) over x viewed as [-1, x.shape[-1]]; out may be x (in place).  x contiguous."""
     assert x.is_contiguous()
     out = torch.empty_like(x) if out is None else out
-    _lib.check(_lib.lib().svol_dropout(_ptr(x), _ptr(out), x.numel(), float(p), int(seed), _dt(x), _stream()), 'svol_dropout')
+    _lib.check(_lib.lib().svol_dropout(_ptr(x), _ptr(out), x.numel(), max(1, x.shape[-1] if x.dim() else 1), float(p), int(seed), _dt(x),
+                                       _stream()), 'svol_dropout')
     return out
 
 
 def dropout_add(t32, res32, p, seed):
-    """res32 + dropout(t32), fp32, written over t32."""
+    """res32 + dropout(t32), fp32, written over t32 (rows = t32.shape[-1] wide)."""
     assert t32.is_contiguous() and res32.is_contiguous() and t32.dtype == torch.float32 and res32.dtype == torch.float32
-    _lib.check(_lib.lib().svol_dropout_add(_ptr(t32), _ptr(res32), _ptr(t32), t32.numel(), float(p), int(seed), _stream()),
-               'svol_dropout_add')
+    _lib.check(_lib.lib().svol_dropout_add(_ptr(t32), _ptr(res32), _ptr(t32), t32.numel(), max(1, t32.shape[-1]), float(p), int(seed),
+                                           _stream()), 'svol_dropout_add')
     return t32
 
 

@@ -303,6 +303,59 @@ def check_mlp_chain():
     return res
 
 
+def dropout_keep_numpy(shape, p, seed):
+    """numpy twin of the device keep mask (svol_amd/csrc/common.h: drop_seed32 / drop_row / drop_scale_rk) over a tensor viewed as
+    [-1, shape[-1]]: True where the element is kept."""
+    import numpy as np
+    M64 = (1 << 64) - 1
+
+    def hash_u64(x):
+        x &= M64
+        x ^= x >> 33
+        x = (x * 0xff51afd7ed558ccd) & M64
+        x ^= x >> 33
+        x = (x * 0xc4ceb9fe1a85ec53) & M64
+        x ^= x >> 33
+        return x & 0xffffffff
+    s0 = hash_u64((int(seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & M64)
+    n = int(np.prod(shape))
+    L = int(shape[-1])
+    i = np.arange(n, dtype=np.uint64)
+    r, k = i // np.uint64(L), i % np.uint64(L)
+    m32 = np.uint64(0xffffffff)
+    x = (np.uint64(s0) ^ (((r & m32) * np.uint64(0x9E3779B1)) & m32) ^ (((r >> np.uint64(32)) * np.uint64(0x7F4A7C15)) & m32)
+         ^ ((k * np.uint64(0x85EBCA6B)) & m32)) & m32
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & m32
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & m32
+    x ^= x >> np.uint64(16)
+    u = (x >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return (u >= np.float32(p)).reshape(shape)
+
+
+def check_dropout_mask():
+    """the stateless keep mask: svol_dropout over ones == the numpy twin, element for element (all dtypes); svol_dropout_add and the
+    attention kernels' mask are the same function (the enc/dec tests replay it through the oracle); keep rate at 4M elements."""
+    import numpy as np
+    res = {}
+    for shape, p, seed in [((7, 13), 0.25, 5), ((3, 5, 64), 0.1, (7 << 44) + (3 << 12) + 1), ((2, 8, 100, 130), 0.1, 123456789012345),
+                           ((1, 4097), 0.5, 0), ((2048, 2048), 0.1, 99)]:
+        want = dropout_keep_numpy(shape, p, seed)
+        for dt in DTYPES16:
+            got = ops.dropout(torch.ones(shape, dtype=dt, device=DEV), p, seed).float().cpu().numpy()
+            keep = got > 0
+            res[f'dropout_mask/{dt}/{shape}/bits'] = (float((keep != want).mean()), 0.0)
+            res[f'dropout_mask/{dt}/{shape}/scale'] = (float(np.abs(got[keep] - np.float32(1.0 / (1.0 - p))).max()) if keep.any() else 0.0,
+                                                       1e-2 if dt != torch.float32 else 1e-6)
+        t = torch.ones(shape, dtype=torch.float32, device=DEV)
+        r = torch.full(shape, 2.0, dtype=torch.float32, device=DEV)
+        got = ops.dropout_add(t, r, p, seed).cpu().numpy()
+        res[f'dropout_add/{shape}'] = (float(np.abs(got - (2.0 + want.astype(np.float32) / np.float32(1.0 - p))).max()), 1e-6)
+    res['dropout_mask/keep_rate'] = (abs(float(dropout_keep_numpy((2048, 2048), 0.1, 99).mean()) - 0.9), 1e-3)
+    return res
+
+
 def check_gemm_tn():
     res = {}
     for dt in DTYPES16:

@@ -46,6 +46,10 @@ def test_attention_weights_mean(G):
     _assert(G.check_attn_weights())
 
 
+def test_dropout_mask_matches_the_numpy_twin(G):
+    _assert(G.check_dropout_mask())
+
+
 def test_mlp_chain(G):
     _assert(G.check_mlp_chain())
 
