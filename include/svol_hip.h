@@ -183,7 +183,8 @@ int svol_layernorm_bwd(const float* dy32, const void* dy, const void* dy2, const
  * y[r, k] = x[r, k] * keep(seed, r, k) over the [n / row_len, row_len] view, keep = 0 with probability p else 1/(1-p): a stateless
  * counter-based mask of (seed, row, column), so the backward pass (and a test that wants the mask itself: x = ones) regenerates it.
  * y may alias x.  The FFN dropout after the activation (:168,:238) and the backward of the residual dropouts.  (Round 4: the mask is
- * keyed by row and column instead of the flat element index — same contract, a five times cheaper generator; row_len <= 2^32.) */
+ * keyed by row and column instead of the flat element index — same contract, a several times cheaper generator; the drop probability
+ * is p rounded up to a multiple of 2^-16; row_len <= 2^32.) */
 int svol_dropout(const void* x, void* y, int64_t n, int64_t row_len, float p, uint64_t seed, int dtype, void* stream);
 /* out32 = res32 + t32 * keep(seed, r, k): the residual dropouts src + dropout1(src2) (:171,:177,:232-247) on the fp32 stream;
  * out32 may alias t32. */

@@ -187,6 +187,12 @@ struct AttnArgs {
 __device__ __forceinline__ float attn_drop(uint64_t seed, uint64_t row, int key, float p, float inv) {
     return dropout_scale(seed, row, (uint32_t)key, p, inv);
 }
+// the same for keys key0 (EVEN) and key0 + 1 of one row: one generator call for the pair
+__device__ __forceinline__ void attn_drop2(uint32_t rowmix, int key0, uint32_t thr16, float inv, float& s0, float& s1) {
+    const uint32_t bits = drop_bits(rowmix, (uint32_t)key0 >> 1);
+    s0 = drop_pick(bits, 0u, thr16, inv);
+    s1 = drop_pick(bits, 1u, thr16, inv);
+}
 
 template <typename T> struct Smem {
     static constexpr int NAT = 64 * AT<T>::NAT_ROW;
@@ -262,12 +268,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) O[i] *= alpha;
             if (p.drop_p > 0.f) {
-                const uint64_t rb = (((uint64_t)b * p.H + hh) * p.Lq + (qvalid ? qrow : 0));
+                const uint32_t rm = drop_row(drop_seed32(p.drop_seed), (((uint64_t)b * p.H + hh) * p.Lq + (qvalid ? qrow : 0)));
+                const uint32_t thr = drop_thr16(p.drop_p);
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        S[4 * g + e] *= attn_drop(p.drop_seed, rb, kt + sub * 32 + 8 * g + 4 * h + e, p.drop_p, p.drop_inv);
+                    for (int e = 0; e < 4; e += 2) {   // (the lane's keys 8g + 4h + e: pairs share one generator call)
+                        float s0, s1;
+                        attn_drop2(rm, kt + sub * 32 + 8 * g + 4 * h + e, thr, p.drop_inv, s0, s1);
+                        S[4 * g + e] *= s0;
+                        S[4 * g + e + 1] *= s1;
+                    }
             }
             uint4 va[AT<T>::NA];
             read_tr<T>(va, sVt, r, h, sub);

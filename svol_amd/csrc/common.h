@@ -194,20 +194,29 @@ __device__ __forceinline__ uint32_t hash_u64(uint64_t x) {
 // 64-bit hash of the flat element index — two 64 x 64 multiplies, i.e. ~8 quarter-rate integer multiplies per ELEMENT, five times
 // the rest of an attention score's work (bench.py --workload encdec --dropout 0.1: 54 ms per step against 22 without dropout).
 // Now: the seed goes through the 64-bit hash once per kernel (uniform), a row contributes one multiply that is loop-invariant
-// wherever a lane walks along its row (and strength-reduced where it walks along rows), the column likewise, and the element pays
-// the two multiplies of a 32-bit finaliser (lowbias32).  Keep rate 0.9000 +- 2e-4 and neighbour / lag correlations within noise on
+// wherever a lane walks along its row (and strength-reduced where it walks along rows), the column likewise, and a PAIR of neighbouring
+// columns pays the two multiplies of a 32-bit finaliser (lowbias32): 16 mask bits per element.  Keep rate 0.9000 +- 2e-4 and neighbour / lag correlations within noise on
 // 8M samples; tests/gpu_checks.py::check_dropout_mask pins the function against a numpy twin.
 __device__ __forceinline__ uint32_t drop_seed32(uint64_t seed) { return hash_u64(seed * 0x9E3779B97F4A7C15ULL + 0x632BE59BD9B4E019ULL); }
 __device__ __forceinline__ uint32_t drop_row(uint32_t s0, uint64_t r) {
     return s0 ^ ((uint32_t)r * 0x9E3779B1u) ^ ((uint32_t)(r >> 32) * 0x7F4A7C15u);
 }
-__device__ __forceinline__ float drop_scale_rk(uint32_t rowmix, uint32_t k, float p, float inv_keep) {
-    uint32_t x = rowmix ^ (k * 0x85EBCA6Bu);
+// 32 mask bits of the column PAIR (2 kh, 2 kh + 1) of a row: 16 per column
+__device__ __forceinline__ uint32_t drop_bits(uint32_t rowmix, uint32_t khalf) {
+    uint32_t x = rowmix ^ (khalf * 0x85EBCA6Bu);
     x ^= x >> 16; x *= 0x7FEB352Du;
     x ^= x >> 15; x *= 0x846CA68Bu;
     x ^= x >> 16;
-    const float u = (float)(x >> 8) * (1.0f / 16777216.0f);
-    return u < p ? 0.0f : inv_keep;
+    return x;
+}
+// dropped iff the column's 16-bit field < ceil(p * 65536): drop probability p rounded UP to a multiple of 2^-16 (0.1 -> 0.100006)
+__device__ __forceinline__ uint32_t drop_thr16(float p) { return (uint32_t)ceilf(p * 65536.0f); }
+__device__ __forceinline__ float drop_pick(uint32_t bits, uint32_t odd, uint32_t thr16, float inv_keep) {
+    const uint32_t u = odd ? bits >> 16 : bits & 0xffffu;
+    return u < thr16 ? 0.0f : inv_keep;
+}
+__device__ __forceinline__ float drop_scale_rk(uint32_t rowmix, uint32_t k, float p, float inv_keep) {
+    return drop_pick(drop_bits(rowmix, k >> 1), k & 1u, drop_thr16(p), inv_keep);
 }
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t r, uint32_t k, float p, float inv_keep) {
     return drop_scale_rk(drop_row(drop_seed32(seed), r), k, p, inv_keep);

@@ -324,14 +324,15 @@ def dropout_keep_numpy(shape, p, seed):
     r, k = i // np.uint64(L), i % np.uint64(L)
     m32 = np.uint64(0xffffffff)
     x = (np.uint64(s0) ^ (((r & m32) * np.uint64(0x9E3779B1)) & m32) ^ (((r >> np.uint64(32)) * np.uint64(0x7F4A7C15)) & m32)
-         ^ ((k * np.uint64(0x85EBCA6B)) & m32)) & m32
+         ^ (((k >> np.uint64(1)) * np.uint64(0x85EBCA6B)) & m32)) & m32
     x ^= x >> np.uint64(16)
     x = (x * np.uint64(0x7FEB352D)) & m32
     x ^= x >> np.uint64(15)
     x = (x * np.uint64(0x846CA68B)) & m32
     x ^= x >> np.uint64(16)
-    u = (x >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
-    return (u >= np.float32(p)).reshape(shape)
+    field = np.where((k & np.uint64(1)) == 1, x >> np.uint64(16), x & np.uint64(0xffff))   # 16 mask bits per column, a pair per call
+    thr = np.uint64(int(np.ceil(np.float32(p) * np.float32(65536.0))))
+    return (field >= thr).reshape(shape)
 
 
 def check_dropout_mask():
@@ -353,6 +354,9 @@ def check_dropout_mask():
         got = ops.dropout_add(t, r, p, seed).cpu().numpy()
         res[f'dropout_add/{shape}'] = (float(np.abs(got - (2.0 + want.astype(np.float32) / np.float32(1.0 - p))).max()), 1e-6)
     res['dropout_mask/keep_rate'] = (abs(float(dropout_keep_numpy((2048, 2048), 0.1, 99).mean()) - 0.9), 1e-3)
+    m = dropout_keep_numpy((2048, 2048), 0.1, 99).astype(np.float64)
+    m -= m.mean()
+    res['dropout_mask/neighbour_correlation'] = (abs(float((m[:, 1:] * m[:, :-1]).mean() / (m * m).mean())), 2e-3)
     return res
 
 
