@@ -131,7 +131,8 @@ int svol_gemm_nt_dact(const void* A, int64_t lda, const void* B, int64_t ldb, vo
  *                        Y (fp32, ldy) = hid Wb^T + bb + res32 (ldr)            == svol_gemm_nt(SVOL_ACT_GELU_D) + svol_gemm_nt(res)
  *   mode 1 (backward):   hid = T * aux_in ([M, F], ldaux), Y (16-bit, ldy) = hid Wb^T   == svol_gemm_nt_dact(SVOL_ACT_GELU_D) + svol_gemm_nt
  *                        (WITHOUT the column sums of hid: take the bias gradient from svol_gemm_tn's colsum)
- * SVOL_E_UNSUPPORTED for D != 256, F % 64, fp32, unaligned operands: the caller then issues the two products. */
+ * SVOL_E_UNSUPPORTED for D != 256, F % 32, F > 12288 (mode 0 keeps ba in LDS), fp32, unaligned operands: the caller then issues the two
+ * products. */
 int svol_mlp_chain(const void* X, int64_t ldx, const void* Wa, const void* Wb, void* hid, int64_t ldh, const void* aux_in, void* aux_out,
                    int64_t ldaux, void* Y, int64_t ldy, const float* ba, const float* bb, const float* res32, int64_t ldr, int mode,
                    int64_t M, int64_t D, int64_t F, int dtype, void* stream);
