@@ -86,3 +86,13 @@ def test_option_surface_defaults():
     assert configs.reference_defaults() == ref
     a = configs.parse_args(['--num_layers', '6', '--matcher', 'video_matcher', '--num_queries', '100'])
     assert a.num_layers == 6 and a.matcher == 'video_matcher' and a.compute_dtype == 'bf16'
+
+
+def test_driver_build_entry_agrees_with_the_library_version():
+    """__graft_entry__.build() asserts the ABI version it was written against: keep it in step with svol_abi_version()."""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), '__graft_entry__.py')).read()
+    m = re.search(r'svol_abi_version\(\) == (\d+)', src)
+    assert m, 'no ABI assertion in __graft_entry__.build()'
+    from svol_amd import _lib
+    assert int(m.group(1)) == _lib.lib().svol_abi_version()
