@@ -1921,9 +1921,13 @@ __device__ __forceinline__ void attn_bwd_sp_body(const Args& p, char* smem, int 
 #pragma unroll
         for (int w2 = 0; w2 < 4; ++w2) v[w2] = *reinterpret_cast<const f32x4*>(pr_base + buf * SP_PART + w2 * 4 * 64 * 16);
     };
-    auto reduce_add = [&](const f32x4 (&v)[4], int qstep) {   // qstep: local step whose partial this is (< 0: an empty buffer)
+    // qstep: local step whose partial this is.  < 0: an empty buffer (the first steps); >= 4 ntl: a DRAIN step's partial — exact zeros
+    // (P = exp2(-inf)).  Both are added to a row of this workgroup's own range: the drain steps' natural target lies past it — for the
+    // last batch element past the END of the image (cfg5, B = 1: the image ends the allocation; a write fault on a read-only page).
+    const int last_step = 4 * ntl - 1;
+    auto reduce_add = [&](const f32x4 (&v)[4], int qstep) {
         const f32x4 acc = (v[0] + v[1]) + (v[2] + v[3]);
-        float* dst = dq_base + (int64_t)(qstep > 0 ? qstep : 0) * 32 * dqw + dq_lane;
+        float* dst = dq_base + (int64_t)min(max(qstep, 0), last_step) * 32 * dqw + dq_lane;
 #ifdef SP_ABLATE   // lab only (tools/micro/attn_lab_sp -DSP_ABLATE=1): plain stores in place of the atomics — same instruction and vmcnt counts
 #pragma unroll
         for (int e = 0; e < 4; ++e) __builtin_nontemporal_store(acc[e], dst + e * dqw);

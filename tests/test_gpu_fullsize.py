@@ -276,6 +276,45 @@ def test_single_pass_backward_key_tails_and_query_quarters(L, dtype):
     assert float((dqkv2[:, :d].float() - dqkv[:, :d].float()).abs().max()) <= 2.0 ** -6 * float(dqkv[:, :d].float().abs().max())
 
 
+@pytest.mark.parametrize('B,L', [(1, 1024), (2, 1536)], ids=['B1-L1024', 'B2-L1536'])
+def test_single_pass_backward_stays_inside_its_scratch(B, L):
+    """The single-pass backward's drain steps carry all-zero dQ partials; their natural target rows lie past the workgroup's queries —
+    for the last batch element past the END of the fp32 image (found at cfg5, B = 1, L = 32768, where the image ends the allocation:
+    'write access to a read-only page').  Here the scratch is followed by a guard of -0.0: an fp32 atomic add of +0.0 would flip
+    the sign.  Key counts without a tail group (L % 512 == 0): nothing legitimate lives behind the image."""
+    import ctypes
+    import math
+    from svol_amd import _lib, ops
+    H, dh = 8, 32
+    d = H * dh
+    dtype = torch.bfloat16
+    lib = _lib.lib()
+    need = int(lib.svol_attn_ws_bytes(B, H, L, L, dh)) // 4
+    image = B * L * H * dh
+    assert need >= image and L % 512 == 0
+    guard = 128 * d
+    buf = torch.full((max(need, image) + guard,), -0.0, dtype=torch.float32, device='cuda')
+    g = torch.Generator().manual_seed(5)
+    pm = 1.4426950408889634 / math.sqrt(dh)
+    qkv = torch.cat([torch.randn((B * L, d), generator=g) * pm, torch.randn((B * L, d), generator=g), torch.randn((B * L, d), generator=g)],
+                    1).to(dtype).cuda()
+    do = torch.randn((B * L, d), generator=g).to(dtype).cuda()
+    qd, kd, vd = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    o, lse2 = ops.attn_fwd(qd, kd, vd, B, H, L, L, dh, None, pm)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((3, B, H, L), dtype=torch.float32, device='cuda')
+    P = ops._ptr
+    rc = lib.svol_attn_bwd(P(qd), qd.stride(0), P(kd), kd.stride(0), P(vd), vd.stride(0), P(o), o.stride(0), P(do), do.stride(0), P(lse2),
+                           P(delta), None, P(dqkv[:, :d]), dqkv.stride(0), P(dqkv[:, d:2 * d]), dqkv.stride(0), P(dqkv[:, 2 * d:]),
+                           dqkv.stride(0), B, H, L, L, dh, 1.0 / math.sqrt(dh), pm, P(buf), need * 4, ops._dt(qd), ops._stream())
+    _lib.check(rc, 'svol_attn_bwd')
+    torch.cuda.synchronize()
+    tail = buf[max(need, image):]
+    assert bool((tail == 0).all()) and bool(torch.signbit(tail).all()), 'the backward wrote behind its scratch'
+    if need == image:   # (the image really was the last thing in the scratch)
+        assert bool(torch.isfinite(dqkv.float()).all())
+
+
 @pytest.mark.parametrize('dtype,qv,kv', [(torch.bfloat16, 16.0, 4.0), (torch.float16, 16.0, 4.0), (torch.float16, 2.0, 1.5)],
                          ids=['bf16', 'fp16', 'fp16-2^24'])
 def test_fast_forward_flags_overflow_and_the_safe_kernel_repairs_it(dtype, qv, kv):
