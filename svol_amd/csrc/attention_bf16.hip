@@ -2088,6 +2088,340 @@ __device__ __forceinline__ void attn_bwd_sp_body(const Args& p, char* smem, int 
         store_acc(dV[kb], dVo, p.lddv, key0 + kb * 32 + r, true, 32, h, 1.f);
     }
 }
+// ---- round 5: the body of a FULL workgroup (four 32-key blocks per wave), every instruction re-placed by the issue rules measured
+// with tools/micro/gen_mfma_fillers.py (profiles/round5_mfma_fillers.md).  Same algorithm, same LDS map and scratch as the template
+// above (which keeps serving the tail groups); what changed is WHERE things issue:
+//   * a gap (the instructions between two MFMAs) hides 24 issue cycles: exp 8, cvt_pk 5, mul / add 4.  Every gap carries 21-30.
+//   * v_pk_mul_f32 does not overlap an MFMA at all (one per gap: 32 -> 50 cycles): plain v_mul_f32.
+//   * an LDS operation costs a lone wave 5 cycles right BEHIND an MFMA and 14-25 in front of the next one; stores go through a
+//     path the four SIMDs share (24 cycles per ds_write_b64 when all four waves store): every LDS operation is the FIRST
+//     instruction of a gap, at most one store per gap, the step's operand / constant / partial traffic is dealt over the gaps of
+//     the four blocks instead of standing in clusters at the step boundary.
+//   * the exponentials of block j + 1 start in the last two gaps of block j (its scores are complete by then), so no gap runs
+//     short of vector work and none has to take more than two exps.
+//   * the dQ product runs ONE block behind (was two): the transposed read-back of dS is issued in gap 10 / gap 1 and consumed by
+//     the MFMAs behind gaps 5 / 7 — five gaps of latency cover; 8 registers less.
+// Gap k = what follows MFMA k.  MFMAs: 1, 2 score of the next block, 3, 4 its dP, 5 / 9 dV, 7 / 10 dK, 6 / 8 dQ of the previous block.
+template <int ABL = 0>
+__device__ __forceinline__ void attn_bwd_sp_body4(const Args& p, char* smem, int hh, int b, int kbase, int t_begin, int t_end) {
+    constexpr int NKB = 4;
+    float* sL = reinterpret_cast<float*>(smem);   // [2][KT] -lse2
+    float* sD = sL + 2 * KT;                      // [2][KT] -delta
+    float* sNeg = sL + 4 * KT;                    // [KT]    -inf (drain steps)
+    char* sQ = smem + SP_OFF_Q;            // [2][IMG]   Q tiles (128 queries); dO tiles 2 * IMG behind
+    char* sPart = smem + SP_OFF_P;         // [2][SP_PART] dQ partials
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    constexpr int dqw = 8 * 32;
+    const h16_t* Q = reinterpret_cast<const h16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * 32;
+    const h16_t* dO = reinterpret_cast<const h16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * 32;
+    const h16_t* K = reinterpret_cast<const h16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * 32;
+    const h16_t* V = reinterpret_cast<const h16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * 32;
+    const float* nl_g = reinterpret_cast<const float*>(p.nl2) + ((int64_t)b * p.H + hh) * p.Lq;
+    const float* nd_g = reinterpret_cast<const float*>(p.nd2) + ((int64_t)b * p.H + hh) * p.Lq;
+    const int key0 = kbase + wave * 32 * NKB;
+    char* sT = smem + SP_OFF_T + wave * IMG;   // this wave's dS images: [NKB][32 keys][32 q]
+    const int ntl = t_end - t_begin;       // tiles of this workgroup (>= 1)
+
+    u32x4 kbk[NKB][2], vbk[NKB][2], kd[NKB][2];
+    f32x16 dK[NKB], dV[NKB];
+    {   // this wave's K rows, then its V rows, through ITS quarter of the (still unused) Q / dO buffers
+        char* sS = sQ + wave * IMG;
+#pragma unroll
+        for (int pc = 0; pc < 2 * NKB; ++pc) dma_piece(sS, K, p.ldk, key0, pc, lane);
+        dma_wait_all();
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            uint4 t0[2], t1[2];
+            read_rows(t0, sS, kb * 32 + r, h);
+            read_tr_nat(t1, sS, kb, lane);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { kbk[kb][s] = to_acc(as_u32x4(t0[s])); kd[kb][s] = to_acc(as_u32x4(t1[s])); }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int pc = 0; pc < 2 * NKB; ++pc) dma_piece(sS, V, p.ldv, key0, pc, lane);
+        dma_wait_all();
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            uint4 t0[2];
+            read_rows(t0, sS, kb * 32 + r, h);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) vbk[kb][s] = to_acc(as_u32x4(t0[s]));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            dK[kb] = zero16();
+            dV[kb] = zero16();
+            asm volatile("; accumulators -> AGPR" : "+a"(dK[kb]), "+a"(dV[kb]));
+        }
+    }
+#pragma unroll
+    for (int buf = 0; buf < 2; ++buf)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(sPart + buf * SP_PART + ((wave * 4 + g) * 64 + lane) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < KT) sNeg[tid] = -INFINITY;
+    // the wave's dS images start as zeros: the stream's first block reads "the previous block's" dS^T (image 3) before anything wrote it
+#pragma unroll
+    for (int g = 0; g < IMG / 1024; ++g) *reinterpret_cast<f32x4*>(sT + (g * 64 + lane) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- addresses: everything lane dependent is computed ONCE ----
+    const int prow = t_begin * KT + 32 * wave + (lane >> 2), pch = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
+    const h16_t* gq = Q + (int64_t)prow * p.ldq + pch;
+    const h16_t* gdo = dO + (int64_t)prow * p.lddo + pch;
+    const float* gst = (wave < 2 ? nl_g : nd_g) + t_begin * KT + (wave & 1) * 64 + (lane & 15) * 4;
+    const unsigned lds_q = (unsigned)(size_t)(lds_vptr)sQ + wave * 2048, lds_st = (unsigned)(size_t)(lds_vptr)((wave < 2 ? sL : sD) + (wave & 1) * 64);
+    auto dma_tile_at = [&](int tl, int buf) {   // local tile tl -> buffer buf: 5 vector-memory instructions per wave
+        const h16_t* a = gq + (int64_t)tl * KT * p.ldq;
+        const h16_t* c = gdo + (int64_t)tl * KT * p.lddo;
+        const unsigned dq_ = __builtin_amdgcn_readfirstlane(lds_q + buf * IMG), dd_ = dq_ + 2 * IMG;
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dq_), "v"(a) : "m0");
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dq_ + 1024), "v"(a + 16 * p.ldq) : "m0");
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dd_), "v"(c) : "m0");
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dd_ + 1024), "v"(c + 16 * p.lddo) : "m0");
+        const unsigned ds_ = __builtin_amdgcn_readfirstlane(lds_st + buf * KT * 4);
+        const float* e = gst + tl * KT;
+        if (lane < 16) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(ds_), "v"(e) : "m0");
+    };
+    const unsigned o_rows0 = img_off(r, h), o_rows1 = img_off(r, 2 + h);
+    unsigned o_trl, o_trh;
+    {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, h2 = g >> 1;
+        const int ch = 2 * (g & 1) + (pp >> 1), inner = 8 * (pp & 1);
+        o_trl = img_off(4 * h2 + q, ch) + inner;
+        o_trh = img_off(4 * h2 + q + 8, ch) + inner;
+    }
+    const unsigned o_st = 16 * h;
+    // one k-step (s) of a transposed A operand: two ds_read_b64_tr_b16
+    auto tr_one = [&](uint4& a, const char* img, int s) {
+        const h16x4 lo = SVOL_DS_READ_TR16_H16((lds_bf16x4_ptr)(img + o_trl + 1024 * s));
+        const h16x4 hi = SVOL_DS_READ_TR16_H16((lds_bf16x4_ptr)(img + o_trh + 1024 * s));
+        a = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    // halves (two 16-byte reads) of a step's row constants; c = the constant vector's base for this step
+    auto load_c2 = [&](f32x16& C, const char* c, int part) {
+#pragma unroll
+        for (int g = 2 * part; g < 2 * part + 2; ++g) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(c + o_st + 32 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) C[4 * g + e] = a[e];
+        }
+    };
+    unsigned o_w[4], o_rl, o_rh;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) o_w[g] = ds_off(r, g, h);
+    {
+        const int gg = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3, h2 = gg >> 1;
+        o_rl = ds_off(8 * h2 + qq, 2 * (gg & 1) + (pp >> 1), pp & 1);
+        o_rh = ds_off(8 * h2 + qq + 4, 2 * (gg & 1) + (pp >> 1), pp & 1);
+    }
+    auto ds_tr_one = [&](uint4& a, const char* img, int s) {   // k-step s of dS^T from a [32 keys][32 q] image
+        const h16x4 lo = SVOL_DS_READ_TR16_H16((lds_bf16x4_ptr)(img + o_rl + 1024 * s));
+        const h16x4 hi = SVOL_DS_READ_TR16_H16((lds_bf16x4_ptr)(img + o_rh + 1024 * s));
+        a = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    float* dq_base = p.ws_dq + ((int64_t)b * p.Lq + (int64_t)t_begin * KT) * dqw + hh * 32;   // (uniform)
+    const int dq_lane = (8 * wave + 4 * h) * dqw + r;
+    const char* pr_base = sPart + (wave * 64 + lane) * 16;
+    const int last_step = 4 * ntl - 1;
+
+    sp_barrier();                          // every wave is done with its staging quarter; zeros / -inf are in place
+    dma_tile_at(0, 0);
+    if (ntl > 1) dma_tile_at(1, 1);
+    dma_wait_all();
+    sp_barrier();
+
+    // operands of the step whose score / dP products are issued next, the transposed operands of the current step
+    uint4 qa[2], doa[2], qt[2], dot[2];
+    f32x16 Cl, Cd;
+    f32x16 S, dP;              // score - lse / dP - delta of the block that is processed next
+    {
+        const char* qi = sQ;
+        qa[0] = *reinterpret_cast<const uint4*>(qi + o_rows0);
+        qa[1] = *reinterpret_cast<const uint4*>(qi + o_rows1);
+        doa[0] = *reinterpret_cast<const uint4*>(qi + 2 * IMG + o_rows0);
+        doa[1] = *reinterpret_cast<const uint4*>(qi + 2 * IMG + o_rows1);
+        load_c2(Cl, reinterpret_cast<const char*>(sL), 0);
+        load_c2(Cl, reinterpret_cast<const char*>(sL), 1);
+        load_c2(Cd, reinterpret_cast<const char*>(sD), 0);
+        load_c2(Cd, reinterpret_cast<const char*>(sD), 1);
+        tr_one(qt[0], qi, 0);
+        tr_one(qt[1], qi, 1);
+        tr_one(dot[0], qi + 2 * IMG, 0);
+        tr_one(dot[1], qi + 2 * IMG, 1);
+    }
+    sp_mfma_c(S, qa[0], kbk[0][0], Cl);
+    sp_mfma_v(S, qa[1], kbk[0][1]);
+    sp_mfma_c(dP, doa[0], vbk[0][0], Cd);
+    sp_mfma_v(dP, doa[1], vbk[0][1]);
+    SP_FENCE();
+    uint4 dsa[2];                          // dS^T fragments of the previous block
+#pragma unroll
+    for (int s = 0; s < 2; ++s) dsa[s] = make_uint4(0, 0, 0, 0);
+    f32x16 dQp = zero16();
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(S), "+v"(dP), "+v"(dQp));   // the four products above are complete
+#define SP4_E(X, i) do { if (!(ABL & 1)) asm volatile("v_exp_f32 %0, %0" : "+v"(X[i])); } while (0)
+#define SP4_M(i) do { if (!(ABL & 1)) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(dP[i]) : "v"(S[i])); } while (0)
+#define SP4_CP(j) do { if (!(ABL & 1)) asm volatile("v_cvt_pk_" SVOL_H16_ASM "_f32 %0, %1, %2" : "=v"(((j) < 4 ? pw0 : pw1)[(j) & 3]) : "v"(S[2 * (j)]), "v"(S[2 * (j) + 1])); } while (0)
+#define SP4_CD(j) do { if (!(ABL & 1)) asm volatile("v_cvt_pk_" SVOL_H16_ASM "_f32 %0, %1, %2" : "=v"(((j) < 4 ? dw0 : dw1)[(j) & 3]) : "v"(dP[2 * (j)]), "v"(dP[2 * (j) + 1])); } while (0)
+#define SP4_W(g) do { if (!(ABL & 8)) *reinterpret_cast<uint2*>(img + o_w[g]) = (g) < 2 ? make_uint2(dw0[2 * ((g) & 1)], dw0[2 * ((g) & 1) + 1]) \
+                                                                             : make_uint2(dw1[2 * ((g) & 1)], dw1[2 * ((g) & 1) + 1]); } while (0)
+#define SP4_MF(stmt) do { SP_FENCE(); if (!(ABL & 2)) { stmt; } SP_FENCE(); } while (0)
+#ifdef SP_ABLATE   // lab only: plain stores in place of the atomics — same instruction and vmcnt counts
+#define SP4_ATOM(ptr, val) __builtin_nontemporal_store(val, ptr)
+#else
+#define SP4_ATOM(ptr, val) unsafeAtomicAdd(ptr, val)
+#endif
+#define SP4_ADD(d, x, y) do { _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { float o_; asm volatile("v_add_f32 %0, %1, %2" : "=v"(o_) : "v"((x)[e_]), "v"((y)[e_])); (d)[e_] = o_; } } while (0)
+    SP4_E(S, 0); SP4_E(S, 1); SP4_E(S, 2); SP4_E(S, 3); SP4_E(S, 4);   // (the loop does these five in the last two gaps of the block before)
+    f32x4 red[4], rsum;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) red[w2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    rsum = red[0];
+    u32x4 pw0, pw1, dw0, dw1;              // P / dS of the current block, packed: the B operands of the dV / dK products
+
+    // one iteration = one 128-query tile = four steps with a compile-time sub-tile; iteration ntl is the DRAIN tile
+    for (int tl = 0; tl <= ntl; ++tl) {
+        const bool drain = tl == ntl;
+        const char* qtile = sQ + ((drain ? ntl - 1 : tl) & 1) * IMG;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+        const int st = 4 * tl + sub;
+        if (!(ABL & 16) && sub == 0 && tl >= 1 && tl + 1 < ntl) {   // the other tile buffers were last read in the step before, behind its barrier
+            dma_tile_at(tl + 1, (tl + 1) & 1);
+            asm volatile("" ::: "memory");   // the atomics below stay BEHIND these five transfers (the counted vmcnt below relies on it)
+        }
+        // the NEXT step: its operands are fetched during this one (tiles past the end are DRAIN tiles: any resident rows, -inf)
+        const int subn = (sub + 1) & 3, tn = tl + (sub + 1 >= 4 ? 1 : 0);
+        const bool drain_n = tn >= ntl;
+        const int cur_n = (drain_n ? ntl - 1 : tn) & 1;
+        const char* qn = sQ + cur_n * IMG + subn * 2048;                      // Q rows of the next step (dO: + 2 IMG)
+        const char* cln = drain_n ? reinterpret_cast<const char*>(sNeg) : reinterpret_cast<const char*>(sL) + cur_n * KT * 4 + subn * 128;
+        const char* cdn = reinterpret_cast<const char*>(sD) + cur_n * KT * 4 + subn * 128;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const int kn = (kb + 1) & 3;         // key block of the NEXT block in the stream
+            const int ks = (kb + 3) & 3;         // key block whose dQ product runs here (the previous block of the stream)
+            f32x16 Sn, dPn;
+            char* img = sT + kb * 2048;
+            const char* img_prev = sT + ks * 2048;
+            // ---- gap 1
+            SP4_MF(sp_mfma_c(Sn, qa[0], kbk[kn][0], Cl));
+            if (!(ABL & 8)) ds_tr_one(dsa[1], img_prev, 1);
+            if (kb == 1) *reinterpret_cast<f32x4*>(sPart + ((sub - 1) & 1) * SP_PART + ((wave * 4 + 0) * 64 + lane) * 16) = f32x4{dQp[0], dQp[1], dQp[2], dQp[3]};
+            if (kb == 2) load_c2(Cl, cln, 0);
+            SP_FENCE();
+            SP4_E(S, 5); SP4_E(S, 6); SP4_CP(0); SP4_CP(1); SP4_M(0);
+            // ---- gap 2
+            SP4_MF(sp_mfma_v(Sn, qa[1], kbk[kn][1]));
+            if (kb == 0) tr_one(qt[1], qtile + sub * 2048, 1);
+            if (kb == 1) *reinterpret_cast<f32x4*>(sPart + ((sub - 1) & 1) * SP_PART + ((wave * 4 + 1) * 64 + lane) * 16) = f32x4{dQp[4], dQp[5], dQp[6], dQp[7]};
+            if (kb == 2) load_c2(Cl, cln, 1);
+            if (kb == 3) {   // the sum of the partial published by the last barrier -> fp32 image (rows of this workgroup only: see the template)
+                float* dst = dq_base + (int64_t)min(max(st - 2, 0), last_step) * 32 * dqw + dq_lane;
+                SP4_ATOM(dst, rsum[0]);
+                SP4_ATOM(dst + dqw, rsum[1]);
+            }
+            SP_FENCE();
+            SP4_E(S, 7); SP4_M(1); SP4_M(2); SP4_M(3); SP4_CD(0); SP4_CP(2);
+            // ---- gap 3
+            SP4_MF(sp_mfma_c(dPn, doa[0], vbk[kn][0], Cd));
+            if (kb == 1) *reinterpret_cast<f32x4*>(sPart + ((sub - 1) & 1) * SP_PART + ((wave * 4 + 2) * 64 + lane) * 16) = f32x4{dQp[8], dQp[9], dQp[10], dQp[11]};
+            if (kb == 2) {
+                qa[0] = *reinterpret_cast<const uint4*>(qn + o_rows0);
+                qa[1] = *reinterpret_cast<const uint4*>(qn + o_rows1);
+            }
+            if (kb == 3) {
+                float* dst = dq_base + (int64_t)min(max(st - 2, 0), last_step) * 32 * dqw + dq_lane;
+                SP4_ATOM(dst + 2 * dqw, rsum[2]);
+                SP4_ATOM(dst + 3 * dqw, rsum[3]);
+            }
+            SP_FENCE();
+            SP4_E(S, 8); SP4_E(S, 9); SP4_M(4); SP4_M(5); SP4_CD(1);
+            // ---- gap 4
+            SP4_MF(sp_mfma_v(dPn, doa[1], vbk[kn][1]));
+            SP4_W(0);
+            SP_FENCE();
+            SP4_CP(3); SP4_E(S, 10); SP4_M(6); SP4_M(7); SP4_CD(2);
+            // ---- gap 5: dV^T += dO^T P, first k-step (P registers 0..7; the last conversion is five instructions back)
+            SP4_MF(sp_mfma_a(dV[kb], dot[0], pw0));
+            if (kb == 1) *reinterpret_cast<f32x4*>(sPart + ((sub - 1) & 1) * SP_PART + ((wave * 4 + 3) * 64 + lane) * 16) = f32x4{dQp[12], dQp[13], dQp[14], dQp[15]};
+            if (kb == 2) load_c2(Cd, cdn, 0);
+            if (kb == 3) tr_one(dot[0], qn + 2 * IMG, 0);
+            SP_FENCE();
+            SP4_E(S, 11); SP4_E(S, 12); SP4_CD(3); SP4_CP(4); SP4_M(8);
+            // ---- gap 6: dQ += dS K of the previous block, first k-step (the partial restarts with the step's first key block)
+            SP4_MF(if (ks == 0) sp_mfma_z(dQp, dsa[0], kd[0][0]); else sp_mfma_v(dQp, dsa[0], kd[ks][0]));
+            SP4_W(1);
+            SP_FENCE();
+            SP4_E(S, 13); SP4_M(9); SP4_M(10); SP4_M(11); SP4_CD(4); SP4_CP(5);
+            // ---- gap 7: dK^T += Q^T dS, first k-step (dS registers 0..7: the last conversion is a whole gap back)
+            SP4_MF(sp_mfma_a(dK[kb], qt[0], dw0));
+            if (kb == 1) {
+                red[0] = *reinterpret_cast<const f32x4*>(pr_base + (sub & 1) * SP_PART + 0 * 4 * 64 * 16);
+                red[1] = *reinterpret_cast<const f32x4*>(pr_base + (sub & 1) * SP_PART + 1 * 4 * 64 * 16);
+            }
+            if (kb == 2) load_c2(Cd, cdn, 1);
+            if (kb == 3) tr_one(qt[0], qn, 0);
+            SP_FENCE();
+            SP4_E(S, 14); SP4_E(S, 15); SP4_M(12); SP4_M(13); SP4_CD(5);
+            // ---- gap 8
+            SP4_MF(sp_mfma_v(dQp, dsa[1], kd[ks][1]));
+            SP4_W(2);
+            SP_FENCE();
+            SP4_CP(6); SP4_CP(7); SP4_M(14); SP4_M(15); SP4_CD(6);
+            if (kb == 2) { SP4_ADD(rsum, red[0], red[1]); }   // (asm: hipcc packs a vector add into v_pk_add_f32, which no MFMA gap hides)
+            // ---- gap 9: dV, second k-step (P registers 8..15; the last conversion is four instructions back)
+            SP4_MF(sp_mfma_a(dV[kb], dot[1], pw1));
+            if (kb == 1) {
+                red[2] = *reinterpret_cast<const f32x4*>(pr_base + (sub & 1) * SP_PART + 2 * 4 * 64 * 16);
+                red[3] = *reinterpret_cast<const f32x4*>(pr_base + (sub & 1) * SP_PART + 3 * 4 * 64 * 16);
+            }
+            if (kb == 2) {
+                doa[0] = *reinterpret_cast<const uint4*>(qn + 2 * IMG + o_rows0);
+                doa[1] = *reinterpret_cast<const uint4*>(qn + 2 * IMG + o_rows1);
+            }
+            if (kb == 3) tr_one(dot[1], qn + 2 * IMG, 1);
+            SP_FENCE();
+            SP4_CD(7); SP4_E(Sn, 0); SP4_E(Sn, 1);
+            if (kb == 2) { SP4_ADD(rsum, rsum, red[2]); }
+            // ---- gap 10: dK, second k-step
+            SP4_MF(sp_mfma_a(dK[kb], qt[1], dw1));
+            SP4_W(3);
+            if (!(ABL & 8)) ds_tr_one(dsa[0], img, 0);
+            SP_FENCE();
+            SP4_E(Sn, 2); SP4_E(Sn, 3); SP4_E(Sn, 4);
+            if (kb == 2) { SP4_ADD(rsum, rsum, red[3]); }
+            S = Sn;
+            dP = dPn;
+        }
+        if (ABL & 16) { }
+        else if (sub == 2 && tl >= 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        // the partial written in block 1 must be in LDS before the barrier: LDS operations of a wave complete in order and more than
+        // eight follow those stores inside the step
+        if (ABL & 4) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
+        }
+    }
+#undef SP4_E
+#undef SP4_M
+#undef SP4_CP
+#undef SP4_CD
+#undef SP4_W
+#undef SP4_MF
+#undef SP4_ADD
+#undef SP4_ATOM
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the last asm MFMAs' results are read by compiler-generated code below
+    h16_t* dKo = reinterpret_cast<h16_t*>(p.dk) + (int64_t)b * p.Lk * p.lddk + hh * 32;
+    h16_t* dVo = reinterpret_cast<h16_t*>(p.dv) + (int64_t)b * p.Lk * p.lddv + hh * 32;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        store_acc(dK[kb], dKo, p.lddk, key0 + kb * 32 + r, true, 32, h, p.scale / p.premul);
+        store_acc(dV[kb], dVo, p.lddv, key0 + kb * 32 + r, true, 32, h, 1.f);
+    }
+}
 // workgroup id -> work.  [0, n_main): the full 512-key groups, heads dealt to the XCDs as block_coords does (nxt = full groups per
 // head).  [n_main, n_main + 4 B H): the tail groups, four query quarters each, on the same head -> XCD deal.
 struct SpWork { int hh, b, kbase, t0, t1, part; bool tail; };
@@ -2115,10 +2449,15 @@ __device__ __forceinline__ float* sp_tail_ptr(const Args& p, const SpWork& w) {
     const int tk = p.Lk % SP_KEYS;
     return p.ws_dq + (int64_t)p.B * p.Lq * p.H * 32 + ((int64_t)(w.b * p.H + w.hh) * 4 + w.part) * 2 * tk * 32;
 }
-template <int ABL>
+// V9: the round-4 body for the full workgroups too (A/B: SVOL_ATTN_SP_V9=1)
+template <int ABL, bool V9 = false>
 __device__ __forceinline__ void attn_bwd_sp_dispatch(const Args& p, char* smem) {
     const SpWork w = sp_work(p);
-    if (!w.tail) { attn_bwd_sp_body<4, ABL>(p, smem, w.hh, w.b, w.kbase, w.t0, w.t1, nullptr); return; }
+    if (!w.tail) {
+        if (V9) attn_bwd_sp_body<4, ABL>(p, smem, w.hh, w.b, w.kbase, w.t0, w.t1, nullptr);
+        else attn_bwd_sp_body4<ABL>(p, smem, w.hh, w.b, w.kbase, w.t0, w.t1);
+        return;
+    }
     float* to = sp_tail_ptr(p, w);
     const int tk = p.Lk % SP_KEYS;         // workgroup-uniform; Lk % 128 == 0
     if (w.t1 <= w.t0) {                    // fewer than four query tiles: this part is empty — its partial still has to exist
@@ -2139,6 +2478,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_sp_lab(Args p) {
 __global__ __launch_bounds__(256, 1) void attn_bwd_sp_bf16(Args p) {
     __shared__ __attribute__((aligned(1024))) char smem[SP_LDS];
     attn_bwd_sp_dispatch<0>(p, smem);
+}
+__global__ __launch_bounds__(256, 1) void attn_bwd_sp_bf16_v9(Args p) {
+    __shared__ __attribute__((aligned(1024))) char smem[SP_LDS];
+    attn_bwd_sp_dispatch<0, true>(p, smem);
 }
 // workgroups of the launch above
 // blocks of attn_dq_round_bf16: the image (8 elements per thread, rounded up to whole blocks), then the tail partials
@@ -2299,7 +2642,9 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
                 ps.nl2 = reinterpret_cast<unsigned*>(delta + n);     // here: plain fp32 -lse2
                 ps.nd2 = reinterpret_cast<unsigned*>(delta + 2 * n);  //       plain fp32 -delta
                 hipLaunchKernelGGL(attn_bwd_sp_prep_bf16, dim3((unsigned)((int64_t)B * Lq / 32)), dim3(256), 0, s, ps);
-                hipLaunchKernelGGL(attn_bwd_sp_bf16, dim3(sp_grid(B, H, Lk)), dim3(256), 0, s, ps);
+                static const bool sp_v9 = getenv("SVOL_ATTN_SP_V9") != nullptr;   // round 4's placement of the full workgroups' stream (A/B)
+                if (sp_v9) hipLaunchKernelGGL(attn_bwd_sp_bf16_v9, dim3(sp_grid(B, H, Lk)), dim3(256), 0, s, ps);
+                else hipLaunchKernelGGL(attn_bwd_sp_bf16, dim3(sp_grid(B, H, Lk)), dim3(256), 0, s, ps);
                 hipLaunchKernelGGL(attn_dq_round_bf16, dim3(sp_round_grid(B, H, Lq, Lk)), dim3(256), 0, s, ps);
                 return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
             }

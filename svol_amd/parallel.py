@@ -342,7 +342,7 @@ class FlatAdamW(torch.optim.Optimizer):
         # the loss was multiplied by this before backward (fp16 operands: gradients of ~1e-6 underflow otherwise); divided back out
         # inside the update kernel
         self.loss_scale = 1.0
-        self.scaler: Optional[DynamicLossScaler] = None   # set for fp16 training: overflow check + skip + dynamic scale (see step())
+        self._scaler: Optional[DynamicLossScaler] = None   # set for fp16 training: overflow check + skip + dynamic scale (see step())
         self.flat = []      # per bucket: flat parameters / first / second moments
         self._slot = {}     # id(param) -> (bucket index, offset, numel)
         for bi, b in enumerate(reducer.buckets):
@@ -354,6 +354,24 @@ class FlatAdamW(torch.optim.Optimizer):
                 p.data = flat_p[off:off + n].view_as(p)  # same layout as the gradient views of the bucket
                 self._slot[id(p)] = (bi, off, n)
             self.flat.append({'p': flat_p, 'm': torch.zeros_like(flat_p), 'v': torch.zeros_like(flat_p)})
+
+    # With a scaler attached the bias-correction step count is the DEVICE count of updates really taken (scaler.state[3]: an
+    # overflow-skipped step does not advance it, as apex + torch AdamW do not advance 'step').  It is what checkpoints carry
+    # (a resume used to restart it at 1 under warm moments), so attaching a scaler or loading a state dict keeps the
+    # two in step: whichever happens second pushes the loaded count to the device.
+    @property
+    def scaler(self) -> Optional['DynamicLossScaler']:
+        return self._scaler
+
+    @scaler.setter
+    def scaler(self, sc: Optional['DynamicLossScaler']):
+        self._scaler = sc
+        if sc is not None:
+            sc.state[3] = float(self.t)
+
+    def steps_taken(self) -> int:
+        """Updates really applied (what torch calls 'step'); a host read of the device count when a scaler is attached."""
+        return int(self._scaler.state[3].item()) if self._scaler is not None else self.t
 
     # the hyper-parameters live in param_groups[0] (what torch's schedulers edit); attribute access kept for callers
     lr = property(lambda self: self.param_groups[0]['lr'], lambda self, v: self.param_groups[0].__setitem__('lr', float(v)))
@@ -407,11 +425,12 @@ class FlatAdamW(torch.optim.Optimizer):
         one step was taken (torch creates the entry at the first step of a parameter that has a gradient)."""
         plist = self.param_groups[0]['params']
         state = {}
-        if self.t > 0:
+        taken = self.steps_taken()   # (not the count of step() calls: overflow-skipped steps are not steps)
+        if taken > 0:
             for i, p in enumerate(plist):
                 if id(p) in self._slot:
                     m, v = self._views(p)
-                    state[i] = {'step': torch.tensor(float(self.t)), 'exp_avg': m.clone(), 'exp_avg_sq': v.clone()}
+                    state[i] = {'step': torch.tensor(float(taken)), 'exp_avg': m.clone(), 'exp_avg_sq': v.clone()}
         group = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
         group['params'] = list(range(len(plist)))
         return {'state': state, 'param_groups': [group]}
@@ -424,6 +443,8 @@ class FlatAdamW(torch.optim.Optimizer):
             for st, m, v in zip(self.flat, sd['m'], sd['v']):
                 st['m'].copy_(m)
                 st['v'].copy_(v)
+            if self._scaler is not None:
+                self._scaler.state[3] = float(self.t)
             return
         if not self._params_given:
             # torch's schema maps state to parameters BY POSITION in the optimizer's list (train.py:72: named_parameters() order);
@@ -465,6 +486,8 @@ class FlatAdamW(torch.optim.Optimizer):
             m.copy_(ent['exp_avg'].reshape(p.shape))
             v.copy_(ent['exp_avg_sq'].reshape(p.shape))
         self.t = steps.pop() if steps else 0
+        if self._scaler is not None:
+            self._scaler.state[3] = float(self.t)
         grp = self.param_groups[0]
         for k in ('lr', 'eps', 'weight_decay', 'initial_lr'):
             if k in g0:

@@ -145,6 +145,69 @@ def test_dynamic_loss_scaler_skips_overflowed_steps_and_follows_torch_adamw():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('attach_first', [True, False])
+def test_scaled_adamw_resume_keeps_the_bias_correction_step(attach_first):
+    """with a DynamicLossScaler the bias-correction step count lives on the device (scaler.state[3]) and was neither saved
+    nor restored — a resumed fp16 run restarted it at 1 under warm moments (bc1 = 0.1, bc2 = 0.001: updates ~0.3x mis-scaled).
+    An uninterrupted run of 8 steps (step 2 overflows and is skipped) must equal 4 steps + state_dict -> fresh optimizer + scaler ->
+    load_state_dict -> 4 more steps, bit for bit, whichever of {attach the scaler, load the state} happens first; and the saved
+    'step' is the count of updates TAKEN (3 after four calls with one skip), which is what torch / apex write."""
+    import torch
+    from svol_amd import parallel
+    shapes = [(64, 33), (33,), (128, 128), (5, 3, 2), (1,)]
+    dev = torch.device('cuda')
+
+    def grads(step, scale):
+        g = torch.Generator(device='cuda').manual_seed(500 + step)
+        out = [torch.randn(s, device='cuda', generator=g) * (1.0 + step) * scale for s in shapes]
+        if step == 2:
+            out[1][5] = float('inf')
+        return out
+
+    def make(src):
+        ps = [torch.nn.Parameter(p.detach().clone()) for p in src]
+        red = parallel.BucketedGradAllReduce(ps, bucket_bytes=40000)
+        opt = parallel.FlatAdamW(red, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, params=ps)
+        return ps, red, opt
+
+    def run(ps, red, opt, steps):
+        for st in steps:
+            red.zero_grad()
+            scale = float(opt.scaler.state[0].item())
+            for p, g in zip(ps, grads(st, scale)):
+                p.grad.copy_(g)
+            opt.step()
+        torch.cuda.synchronize()
+
+    torch.manual_seed(3)
+    p0 = [torch.randn(s, device='cuda') for s in shapes]
+    pa, ra, oa = make(p0)
+    oa.scaler = parallel.DynamicLossScaler(dev, init_scale=256.0, growth_interval=1000)
+    run(pa, ra, oa, range(8))
+    assert oa.steps_taken() == 7
+
+    pb, rb, ob = make(p0)
+    ob.scaler = parallel.DynamicLossScaler(dev, init_scale=256.0, growth_interval=1000)
+    run(pb, rb, ob, range(4))
+    sd_opt, sd_amp = ob.state_dict(), ob.scaler.state_dict()
+    assert {int(float(e['step'])) for e in sd_opt['state'].values()} == {3}   # four calls, one skipped
+    pc, rc, oc = make([p.detach() for p in pb])
+    sc = parallel.DynamicLossScaler(dev)
+    sc.load_state_dict(sd_amp)
+    if attach_first:
+        oc.scaler = sc
+        oc.load_state_dict(sd_opt)
+    else:
+        oc.load_state_dict(sd_opt)
+        oc.scaler = sc
+    assert oc.steps_taken() == 3
+    run(pc, rc, oc, range(4, 8))
+    assert oc.steps_taken() == 7
+    for a, c in zip(pa, pc):
+        assert torch.equal(a.detach(), c.detach())
+
+
+@pytest.mark.gpu
 def test_flat_adamw_checkpoints_interoperate_with_torch_adamw():
     """FlatAdamW speaks torch.optim.AdamW's state-dict schema.  torch AdamW, 2 steps -> state_dict ->
     FlatAdamW.load_state_dict -> 2 more steps on both == same weights; and back: FlatAdamW.state_dict() resumes a fresh
