@@ -2101,7 +2101,8 @@ __device__ __forceinline__ void attn_bwd_sp_body(const Args& p, char* smem, int 
 //     short of vector work and none has to take more than two exps.
 //   * the dQ product runs ONE block behind (was two): the transposed read-back of dS is issued in gap 10 / gap 1 and consumed by
 //     the MFMAs behind gaps 5 / 7 — five gaps of latency cover; 8 registers less.
-// Gap k = what follows MFMA k.  MFMAs: 1, 2 score of the next block, 3, 4 its dP, 5 / 9 dV, 7 / 10 dK, 6 / 8 dQ of the previous block.
+// Gap k = what follows MFMA k.  MFMAs: 1, 3 score of the next block, 2, 4 its dP (alternating: no product waits for the accumulator of
+// the MFMA right in front of it), 5 / 9 dV, 7 / 10 dK, 6 / 8 dQ of the previous block.
 template <int ABL = 0>
 __device__ __forceinline__ void attn_bwd_sp_body4(const Args& p, char* smem, int hh, int b, int kbase, int t_begin, int t_end) {
     constexpr int NKB = 4;
@@ -2315,7 +2316,7 @@ __device__ __forceinline__ void attn_bwd_sp_body4(const Args& p, char* smem, int
             SP_FENCE();
             SP4_E(S, 5); SP4_E(S, 6); SP4_CP(0); SP4_CP(1); SP4_M(0);
             // ---- gap 2
-            SP4_MF(sp_mfma_v(Sn, qa[1], kbk[kn][1]));
+            SP4_MF(sp_mfma_c(dPn, doa[0], vbk[kn][0], Cd));
             if (kb == 0) tr_one(qt[1], qtile + sub * 2048, 1);
             if (kb == 1) *reinterpret_cast<f32x4*>(sPart + ((sub - 1) & 1) * SP_PART + ((wave * 4 + 1) * 64 + lane) * 16) = f32x4{dQp[4], dQp[5], dQp[6], dQp[7]};
             if (kb == 2) load_c2(Cl, cln, 1);
@@ -2327,7 +2328,7 @@ __device__ __forceinline__ void attn_bwd_sp_body4(const Args& p, char* smem, int
             SP_FENCE();
             SP4_E(S, 7); SP4_M(1); SP4_M(2); SP4_M(3); SP4_CD(0); SP4_CP(2);
             // ---- gap 3
-            SP4_MF(sp_mfma_c(dPn, doa[0], vbk[kn][0], Cd));
+            SP4_MF(sp_mfma_v(Sn, qa[1], kbk[kn][1]));
             if (kb == 1) *reinterpret_cast<f32x4*>(sPart + ((sub - 1) & 1) * SP_PART + ((wave * 4 + 2) * 64 + lane) * 16) = f32x4{dQp[8], dQp[9], dQp[10], dQp[11]};
             if (kb == 2) {
                 qa[0] = *reinterpret_cast<const uint4*>(qn + o_rows0);
