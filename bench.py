@@ -13,8 +13,8 @@ workload: BASELINE.json configs[1]  — B=8 videos per GPU, T=32 frames, P=196 t
           weights: module default init.  One step = zero_grad, forward, criterion (all 6 layers matched on
           device), backward (+ bucketed RCCL gradient all-reduce overlapped with backward when N > 1), and
           the AdamW step (torch.optim.AdamW's update as one kernel per gradient bucket, svol_amd.parallel.FlatAdamW; the
-          per-step fp32->bf16 weight refresh is inside the timed region too).  Launches are eager (host issue ~15 ms/step,
-          hidden behind ~23 ms of GPU work) at every N, so the N = 1 and N > 1 numbers are the same program; --graph
+          per-step fp32->bf16 weight refresh is inside the timed region too).  Launches are eager (host issue ~5-6 ms/step,
+          hidden behind ~18 ms of GPU work: `host_issue_ms_per_step` in the line) at every N, so the N = 1 and N > 1 numbers are the same program; --graph
           replays the step as one hipGraph instead.  --workload selects the other measured configurations (cfg4: ViT
           extractor online, cfg5: long video, encdec: enc/dec Transformer head, resnet: ResNet extractors online).
 Prints ONE JSON line on rank 0.
@@ -62,7 +62,7 @@ def _host_cores():
     return max(1, n), how
 
 
-def cpu_baseline(seconds_budget=30.0):
+def cpu_baseline(seconds_budget=40.0):
     """Reference CPU path timed beside the GPU number: the oracle (CPU restatement proven equal to the
     reference by the golden vectors) on a BOUNDED sample of the same workload — one of the 8 videos of
     configs[1] (B=1, T=32, P=196, d=256, 6 layers, N=100, fp32, fwd + matcher + bwd).  Videos are
@@ -79,7 +79,7 @@ def cpu_baseline(seconds_budget=30.0):
     tg = syn.synth_targets(B, T, seed=1)
     times = []
     t_start = time.time()
-    for it in range(4):
+    for it in range(6):   # one warm-up + five timed steps (~6 s each on the pool's 16 cores)
         for p in sd.values():
             p.grad = None
         t0 = time.time()
@@ -437,21 +437,28 @@ def main():
             except (OSError, ValueError, KeyError, IndexError, AttributeError):
                 pass
         # at d_h = 32 the attention core is bound by instruction ISSUE (softmax exp / VALU beside the MFMAs), not by the
-        # matrix pipe.  Forward floor per 32x32 score block from the guide's issue costs (MFMA 32x32x16: 32 cycles of pipe, 8 of issue;
-        # v_exp 8; other VALU 4 — profiles/round2_pmc_attention.md): 309 cycles.  Backward (round 4, single pass): the in-kernel
-        # ablations of profiles/round4_attention_lab.md show the costs ADDING — 32 cycles per MFMA + ~5.7 per any other instruction,
-        # no overlap — so the floor of the pass is its minimal instruction set: 10 MFMAs + 16 v_exp + 16 v_cvt_pk + 8 v_pk_mul + 8 LDS
-        # per block = 320 + 48 * 5.7 = 594 cycles.  Priced at the clock the attention kernels HOLD (2.08 GHz: s_memtime against
-        # s_memrealtime in the round-4 lab; GRBM cycles / duration in profiles/round3_pmc_attention.md say 2.0), not at the 2.4 GHz maximum.
-        CLK_GHZ, SIMDS = 2.08, 256 * 4
+        # matrix pipe.  Round 5 settled the model with a fillers-per-gap micro-benchmark (profiles/round5_mfma_fillers.md): an MFMA
+        # 32x32x16 holds the SIMD's issue for 8 of its 32 cycles and a gap runs max(32, 8 + sum of issue costs): v_exp 8, v_cvt_pk 5,
+        # v_mul / v_add 4 (measured; the guide's constants) — round 4's additive 594-cycle floor is gone.  Per 32x32 score block:
+        #   forward  : 4 MFMAs x 8 + 16 exp x 8 + 8 cvt x 5 + 16 row-sum adds x 4 + LDS reads ~ 309 issue cycles (pipe: 128)
+        #   backward : 10 MFMAs x 8 + 16 exp x 8 + 16 cvt x 5 + 16 mul x 4 = 352 issue cycles: the floor of ANY schedule of the single-pass
+        #              algorithm (pipe: 320); with ONE wave per SIMD the dS round trip through LDS cannot hide (4 ds_write_b64 x 13 +
+        #              4 transposed reads x 5, measured first-in-gap prices): 424.
+        # Priced at the clock the attention kernels HOLD under load (2.08 GHz: s_memtime against s_memrealtime, round-4 lab) and,
+        # as separate fields, at the 2.4 GHz maximum.
+        CLK_GHZ, CLK_MAX_GHZ, SIMDS = 2.08, 2.4, 256 * 4
+        FWD_ISSUE, BWD_ISSUE, BWD_ISSUE_1WAVE = 309, 352, 424
         blocks = B * args.nheads * (L / 32.0) ** 2
-        floor_fwd_ms = blocks * 309 / (SIMDS * CLK_GHZ * 1e9) * 1e3
-        floor_bwd_ms = blocks * 594 / (SIMDS * CLK_GHZ * 1e9) * 1e3
-        issue = {'model': 'per 32x32 block: fwd 309 issue cycles per SIMD (exp 8, VALU 4, MFMA issue 8 + LDS); bwd (single pass) 594 = 10 MFMAs x 32 '
-                          '+ 48 other instructions x 5.7 (costs add, measured: profiles/round4_attention_lab.md); %d SIMDs at the %.2f GHz the '
-                          'kernels hold' % (SIMDS, CLK_GHZ),
-                 'fwd_floor_ms': floor_fwd_ms, 'bwd_floor_ms': floor_bwd_ms,
-                 'fwd_frac_of_issue_floor': floor_fwd_ms / fwd[1], 'bwd_frac_of_issue_floor': floor_bwd_ms / bwd[1]}
+        floor_ms = lambda cyc, ghz: blocks * cyc / (SIMDS * ghz * 1e9) * 1e3
+        floor_fwd_ms, floor_bwd_ms = floor_ms(FWD_ISSUE, CLK_GHZ), floor_ms(BWD_ISSUE, CLK_GHZ)
+        issue = {'model': 'measured (profiles/round5_mfma_fillers.md): a gap = max(32, 8 + sum of issue costs), exp 8, cvt_pk 5, mul / add 4; per '
+                          '32x32 block: fwd %d issue cycles per SIMD, bwd (single pass) %d for any schedule, %d with one wave per SIMD (dS round '
+                          'trip through LDS not hidden); %d SIMDs at the %.2f GHz the kernels hold' % (FWD_ISSUE, BWD_ISSUE, BWD_ISSUE_1WAVE, SIMDS, CLK_GHZ),
+                 'model_version': 'round5-measured',
+                 'fwd_floor_ms': floor_fwd_ms, 'bwd_floor_ms': floor_bwd_ms, 'bwd_floor_ms_one_wave_per_simd': floor_ms(BWD_ISSUE_1WAVE, CLK_GHZ),
+                 'fwd_floor_ms_at_2p4GHz': floor_ms(FWD_ISSUE, CLK_MAX_GHZ), 'bwd_floor_ms_at_2p4GHz': floor_ms(BWD_ISSUE, CLK_MAX_GHZ),
+                 'fwd_frac_of_issue_floor': floor_fwd_ms / fwd[1], 'bwd_frac_of_issue_floor': floor_bwd_ms / bwd[1],
+                 'bwd_frac_of_one_wave_floor': floor_ms(BWD_ISSUE_1WAVE, CLK_GHZ) / bwd[1]}
         # algorithmic bytes of one launch: backward reads q, k, v, o, dO and writes dq, dk, dv once; forward reads q, k, v, writes o
         alg_bytes = (8 if bwd[1] >= fwd[1] else 4) * B * L * args.hidden_dim * 2.0
         roof = {'bound': 'mfma', 'kernel': which, 'achieved': ach, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',

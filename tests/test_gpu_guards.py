@@ -1,0 +1,221 @@
+"""Red zones around every output and scratch buffer of the kernels that write by computed offsets ("What's weak 1" /
+"Next round 5"): the single-pass attention backward shipped in round 4 with fp32 atomics of all-zero partials landing behind its rows
+and no parity test could see it.  Every buffer a kernel may write is carved out of ONE arena pre-filled with fp32 -0.0 words, with a
+guard zone in FRONT of and BEHIND it: a plain store of anything else changes the pattern, and an fp32 atomic add of +0.0 — the invisible
+kind — flips the sign.  The guards must come back bit-identical; the outputs must be finite (i.e. written).  All calls go through the
+C-ABI with raw pointers, the way the block programs call it.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NEG0 = -2147483648  # 0x80000000 as int32: fp32 -0.0
+
+
+class GuardArena:
+    """One int32 allocation of -0.0 words; take() returns tensors of it separated by guard zones (also one in front of the first and
+    one behind the last); check() verifies every word outside the taken ranges."""
+
+    def __init__(self, guard_bytes=1 << 18):
+        self.guard = guard_bytes // 4
+        self.req = []
+
+    def plan(self, name, shape, dtype):
+        self.req.append((name, tuple(shape), dtype))
+
+    def build(self):
+        off = self.guard
+        self.slots = {}
+        for name, shape, dtype in self.req:
+            n = 1
+            for s in shape:
+                n *= s
+            words = (n * torch.empty((), dtype=dtype).element_size() + 3) // 4
+            words = (words + 63) // 64 * 64          # 256-byte aligned starts
+            self.slots[name] = (off, words, shape, dtype)
+            off += words + self.guard
+        self.buf = torch.full((off,), NEG0, dtype=torch.int32, device='cuda')
+        out = {}
+        for name, (o, w, shape, dtype) in self.slots.items():
+            n = 1
+            for s in shape:
+                n *= s
+            out[name] = self.buf[o:o + w].view(dtype)[:n].view(shape)
+        return out
+
+    def check(self, what):
+        keep = torch.ones_like(self.buf, dtype=torch.bool)
+        for name, (o, w, shape, dtype) in self.slots.items():
+            n = 1
+            for s in shape:
+                n *= s
+            used = (n * torch.empty((), dtype=dtype).element_size() + 3) // 4
+            keep[o:o + used] = False
+        bad = (self.buf != NEG0) & keep
+        if bool(bad.any()):
+            idx = int(torch.nonzero(bad)[0])
+            near = [nm for nm, (o, w, _, _) in self.slots.items() if o - self.guard <= idx < o + w + self.guard]
+            raise AssertionError(f'{what}: guard word {idx} changed ({int(bad.sum())} words in all); nearest buffer(s): {near}')
+
+
+def _qkv(B, Lq, Lk, d, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    pm = 1.4426950408889634 / math.sqrt(32)
+    q = (torch.randn((B * Lq, d), generator=g) * pm).to(dtype).cuda()
+    k = torch.randn((B * Lk, d), generator=g).to(dtype).cuda()
+    v = torch.randn((B * Lk, d), generator=g).to(dtype).cuda()
+    do = torch.randn((B * Lq, d), generator=g).to(dtype).cuda()
+    return q, k, v, do, pm
+
+
+@pytest.mark.parametrize('B,Lq,Lk,ws,mask', [
+    (1, 6272, 6272, True, False),      # single pass, B = 1: the image ends the scratch's first part, a 128-key tail group behind it
+    (8, 6272, 6272, True, False),      # the bench launch itself
+    (2, 1536, 1536, True, False),      # single pass, no tail group (L % 512 == 0)
+    (2, 2048 + 384, 2048 + 384, True, False),   # single pass, 384-key tail (three blocks per wave)
+    (2, 1536, 1536, False, False),     # two-pass kernels (no scratch)
+    (2, 1000, 1000, True, False),      # ragged length: tile-classified masked kernels (scratch = tile flags)
+    (2, 1536, 1536, True, True),       # additive key mask
+    (8, 100, 6272, True, True),        # 100 queries against the video: key-split partials + dQ atomics in the scratch
+    (8, 100, 6272, True, False),
+], ids=['sp-B1-L6272', 'sp-B8-L6272', 'sp-L1536', 'sp-tail384', 'twopass', 'ragged', 'masked', 'ksplit-masked', 'ksplit'])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_attention_backward_stays_inside_its_buffers(B, Lq, Lk, ws, mask, dtype):
+    from svol_amd import _lib, ops
+    H, dh = 8, 32
+    d = H * dh
+    lib = _lib.lib()
+    q, k, v, do, pm = _qkv(B, Lq, Lk, d, dtype, 17)
+    kbias = None
+    if mask:
+        kbias = torch.zeros((B, Lk), dtype=torch.float32, device='cuda')
+        kbias[:, Lk - Lk // 5:] = float('-inf')
+        kbias[0, 7] = float('-inf')
+    o, lse2 = ops.attn_fwd(q, k, v, B, H, Lq, Lk, dh, kbias, pm)
+    need = int(lib.svol_attn_ws_bytes(B, H, Lq, Lk, dh)) if ws else 0
+    ar = GuardArena()
+    ar.plan('dq', (B * Lq, d), dtype)
+    ar.plan('dkv', (B * Lk, 2 * d), dtype)
+    ar.plan('delta', (3 * B * H * Lq,), torch.float32)
+    if need:
+        ar.plan('ws', (need // 4,), torch.float32)
+    t = ar.build()
+    dq, dkv = t['dq'], t['dkv']
+    P = ops._ptr
+    rc = lib.svol_attn_bwd(P(q), q.stride(0), P(k), k.stride(0), P(v), v.stride(0), P(o), o.stride(0), P(do), do.stride(0), P(lse2),
+                           P(t['delta']), P(kbias) if kbias is not None else None, P(dq), dq.stride(0), P(dkv[:, :d]), dkv.stride(0),
+                           P(dkv[:, d:]), dkv.stride(0), B, H, Lq, Lk, dh, 1.0 / math.sqrt(dh), pm, P(t['ws']) if need else None, need,
+                           ops._dt(q), ops._stream())
+    _lib.check(rc, 'svol_attn_bwd')
+    torch.cuda.synchronize()
+    ar.check(f'svol_attn_bwd B={B} Lq={Lq} Lk={Lk} ws={ws} mask={mask}')
+    assert bool(torch.isfinite(dq.float()).all()) and bool(torch.isfinite(dkv.float()).all()), 'an output was not (fully) written'
+    assert float(dq.float().abs().max()) > 0 and float(dkv.float().abs().max()) > 0
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_attention_forward_stays_inside_its_buffers(dtype):
+    """the forward's outputs (o, lse) and its scratch (redo flags / tile classes / key-split partials)."""
+    from svol_amd import _lib, ops
+    H, dh = 8, 32
+    d = H * dh
+    lib = _lib.lib()
+    for B, Lq, Lk, mask in ((2, 1536, 1536, False), (2, 1000, 1000, False), (8, 100, 6272, True), (1, 6272, 6272, False)):
+        q, k, v, _, pm = _qkv(B, Lq, Lk, d, dtype, 23)
+        kbias = None
+        if mask:
+            kbias = torch.zeros((B, Lk), dtype=torch.float32, device='cuda')
+            kbias[:, Lk - 1000:] = float('-inf')
+        need = int(lib.svol_attn_ws_bytes(B, H, Lq, Lk, dh))
+        ar = GuardArena()
+        ar.plan('o', (B * Lq, d), dtype)
+        ar.plan('lse', (B * H * Lq,), torch.float32)
+        ar.plan('ws', (max(need // 4, 1),), torch.float32)
+        t = ar.build()
+        P = ops._ptr
+        rc = lib.svol_attn_fwd(P(q), q.stride(0), P(k), k.stride(0), P(v), v.stride(0), P(t['o']), t['o'].stride(0), P(t['lse']),
+                               P(kbias) if kbias is not None else None, B, H, Lq, Lk, dh, 1.0 / math.sqrt(dh), pm, P(t['ws']), need,
+                               ops._dt(q), ops._stream())
+        _lib.check(rc, 'svol_attn_fwd')
+        torch.cuda.synchronize()
+        ar.check(f'svol_attn_fwd B={B} Lq={Lq} Lk={Lk}')
+        assert bool(torch.isfinite(t['o'].float()).all()) and bool(torch.isfinite(t['lse']).all())
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32], ids=['bf16', 'fp32'])
+def test_grouped_weight_gradient_gemm_stays_inside_its_sinks(dtype):
+    """svol_gemm_tn_grouped: split-M workgroups add their tiles with fp32 atomics straight into the gradient sinks, the problem of a
+    workgroup is found by a scan over prefix sums — odd sizes, several problems, column sums on and off."""
+    from svol_amd import ops
+    g = torch.Generator().manual_seed(3)
+    M = 50176 if dtype == torch.bfloat16 else 800
+    shapes = [(256, 2048, True), (2048, 256, True), (256, 256, False), (256, 512, True), (248, 104, True), (64, 8, False)]   # (N, K multiples of one 16-byte load)
+    ar = GuardArena()
+    for i, (k_, n_, cs) in enumerate(shapes):
+        ar.plan(f'out{i}', (n_, k_), torch.float32)
+        if cs:
+            ar.plan(f'cs{i}', (n_,), torch.float32)
+    t = ar.build()
+    probs = []
+    refs = []
+    for i, (k_, n_, cs) in enumerate(shapes):
+        A = (torch.randn((M, n_), generator=g) * 0.1).to(dtype).cuda()      # dY [M, N]
+        X = (torch.randn((M, k_), generator=g) * 0.1).to(dtype).cuda()      # X  [M, K]
+        out = t[f'out{i}']
+        out.zero_()
+        c = t[f'cs{i}'] if cs else None
+        if c is not None:
+            c.zero_()
+        probs.append((A, X, out, c))
+        refs.append((A, X))
+    ops.gemm_tn_grouped(probs)
+    torch.cuda.synchronize()
+    ar.check('svol_gemm_tn_grouped')
+    for (A, X), (_, _, out, c) in zip(refs, probs):
+        ref = A.double().t() @ X.double()
+        err = float((out.double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+        assert err < 2e-3, err
+        if c is not None:
+            rc = A.double().sum(0)
+            assert float((c.double() - rc).abs().max()) / max(1.0, float(rc.abs().max())) < 2e-3
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_mlp_chain_stays_inside_its_buffers(dtype):
+    """svol_mlp_chain (both directions): the [M, F] tensors leave through streaming stores with per-lane computed offsets; M not a multiple
+    of the 64-row fragments."""
+    from svol_amd import _lib, ops
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(9)
+    D, F = 256, 2048
+    for M in (6272, 1000):
+        X = (torch.randn((M, D), generator=g) * 0.5).to(dtype).cuda()
+        Wa = (torch.randn((F, D), generator=g) * 0.05).to(dtype).cuda()
+        Wb = (torch.randn((D, F), generator=g) * 0.05).to(dtype).cuda()
+        ba = torch.randn((F,), generator=g).cuda() * 0.1
+        bb = torch.randn((D,), generator=g).cuda() * 0.1
+        res = torch.randn((M, D), generator=g).cuda()
+        ar = GuardArena()
+        ar.plan('hid', (M, F), dtype)
+        ar.plan('dpre', (M, F), dtype)
+        ar.plan('Y', (M, D), torch.float32)
+        ar.plan('dT', (M, F), dtype)
+        ar.plan('dX', (M, D), dtype)
+        t = ar.build()
+        P = ops._ptr
+        rc = lib.svol_mlp_chain(P(X), X.stride(0), P(Wa), P(Wb), P(t['hid']), F, None, P(t['dpre']), F, P(t['Y']), D, P(ba), P(bb), P(res),
+                                res.stride(0), 0, M, D, F, ops._dt(X), ops._stream())
+        if rc != 0:
+            pytest.skip('svol_mlp_chain does not take this shape')
+        dY = (torch.randn((M, D), generator=g) * 0.5).to(dtype).cuda()
+        Wb_t, Wa_t = Wb.t().contiguous(), Wa.t().contiguous()
+        rc = lib.svol_mlp_chain(P(dY), dY.stride(0), P(Wb_t), P(Wa_t), P(t['dT']), F, P(t['dpre']), None, F, P(t['dX']), D, None, None, None,
+                                0, 1, M, D, F, ops._dt(dY), ops._stream())
+        _lib.check(rc, 'svol_mlp_chain bwd')
+        torch.cuda.synchronize()
+        ar.check(f'svol_mlp_chain M={M}')
+        for k_ in ('hid', 'dpre', 'Y', 'dT', 'dX'):
+            assert bool(torch.isfinite(t[k_].float()).all()), k_
