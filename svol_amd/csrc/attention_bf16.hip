@@ -2514,8 +2514,15 @@ static int plan_ksplit(int B, int H, int Lq, int Lk, int dh, int64_t ws_floats, 
 }
 // shapes the single-pass backward (attn_bwd_sp_bf16) serves: full 128-row tiles both ways, heads dealt to the XCDs, enough keys for
 // the 512-key workgroups to fill the chip (SVOL_ATTN_SP_MIN_LK lowers the bar: tests drive small shapes through it)
+// SVOL_DETERMINISTIC=1: no floating-point atomics in the attention backward — the two-pass kernels (dQ by a query-stationary pass)
+// instead of the single pass, no key split for launches with few queries (their dQ partials meet through atomics).  Gradients are
+// then bit-identical from run to run (tests/test_gpu_ops.py::test_attention_backward_is_bit_reproducible_in_deterministic_mode).
+static bool attn_deterministic() {
+    static const bool det = getenv("SVOL_DETERMINISTIC") != nullptr;
+    return det;
+}
 static bool sp_shape_ok(int B, int H, int Lq, int Lk, int dh) {
-    static const bool no_sp = getenv("SVOL_ATTN_NO_SP") != nullptr;
+    static const bool no_sp = getenv("SVOL_ATTN_NO_SP") != nullptr || attn_deterministic();
     static const int min_lk = getenv("SVOL_ATTN_SP_MIN_LK") ? atoi(getenv("SVOL_ATTN_SP_MIN_LK")) : 2 * SP_KEYS;
     return !no_sp && dh == 32 && H == 8 && (B * H) % 8 == 0 && Lq % KT == 0 && Lk % KT == 0 && Lk >= min_lk;
 }
@@ -2608,7 +2615,7 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
     const int ntk = (Lk + KT - 1) / KT;
     const bool pre = premul != 0.f && drop_p == 0.f &&
                      (!masked || (!no_pre_masked && pre_masked_ok(B, H, Lq, Lk, dh) && ws && ws_bytes >= (int64_t)B * ntk * 4));
-    p.ksplit = (ws && !pre) ? plan_ksplit(B, H, Lq, Lk, dh, ws_bytes / 4, &p.tiles_per_split) : 1;
+    p.ksplit = (ws && !pre && !attn_deterministic()) ? plan_ksplit(B, H, Lq, Lk, dh, ws_bytes / 4, &p.tiles_per_split) : 1;
     if (p.ksplit == 1) p.tiles_per_split = ntk;
     else bind_ws(p, ws);
     dim3 gd((unsigned)((total + 255) / 256));
