@@ -2210,6 +2210,11 @@ __device__ __forceinline__ void attn_bwd_sp_body4(const Args& p, char* smem, int
             for (int e = 0; e < 4; ++e) C[4 * g + e] = a[e];
         }
     };
+    auto load_c1 = [&](f32x16& C, const char* c, int g) {   // one 16-byte read: rows 8 g + 4 h .. + 3 of the step
+        const f32x4 a = *reinterpret_cast<const f32x4*>(c + o_st + 32 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) C[4 * g + e] = a[e];
+    };
     unsigned o_w[4], o_rl, o_rh;
 #pragma unroll
     for (int g = 0; g < 4; ++g) o_w[g] = ds_off(r, g, h);
@@ -2330,10 +2335,7 @@ __device__ __forceinline__ void attn_bwd_sp_body4(const Args& p, char* smem, int
             // ---- gap 3
             SP4_MF(sp_mfma_v(Sn, qa[1], kbk[kn][1]));
             if (kb == 1) *reinterpret_cast<f32x4*>(sPart + ((sub - 1) & 1) * SP_PART + ((wave * 4 + 2) * 64 + lane) * 16) = f32x4{dQp[8], dQp[9], dQp[10], dQp[11]};
-            if (kb == 2) {
-                qa[0] = *reinterpret_cast<const uint4*>(qn + o_rows0);
-                qa[1] = *reinterpret_cast<const uint4*>(qn + o_rows1);
-            }
+            if (kb == 2) load_c2(Cd, cdn, 0);   // (the dP product of gap 2 was the old constants' last reader)
             if (kb == 3) {
                 float* dst = dq_base + (int64_t)min(max(st - 2, 0), last_step) * 32 * dqw + dq_lane;
                 SP4_ATOM(dst + 2 * dqw, rsum[2]);
@@ -2344,18 +2346,23 @@ __device__ __forceinline__ void attn_bwd_sp_body4(const Args& p, char* smem, int
             // ---- gap 4
             SP4_MF(sp_mfma_v(dPn, doa[1], vbk[kn][1]));
             SP4_W(0);
+            if (kb == 2) load_c1(Cd, cdn, 2);
             SP_FENCE();
             SP4_CP(3); SP4_E(S, 10); SP4_M(6); SP4_M(7); SP4_CD(2);
             // ---- gap 5: dV^T += dO^T P, first k-step (P registers 0..7; the last conversion is five instructions back)
             SP4_MF(sp_mfma_a(dV[kb], dot[0], pw0));
             if (kb == 1) *reinterpret_cast<f32x4*>(sPart + ((sub - 1) & 1) * SP_PART + ((wave * 4 + 3) * 64 + lane) * 16) = f32x4{dQp[12], dQp[13], dQp[14], dQp[15]};
-            if (kb == 2) load_c2(Cd, cdn, 0);
+            if (kb == 2) {
+                load_c1(Cd, cdn, 3);
+                qa[0] = *reinterpret_cast<const uint4*>(qn + o_rows0);
+            }
             if (kb == 3) tr_one(dot[0], qn + 2 * IMG, 0);
             SP_FENCE();
             SP4_E(S, 11); SP4_E(S, 12); SP4_CD(3); SP4_CP(4); SP4_M(8);
             // ---- gap 6: dQ += dS K of the previous block, first k-step (the partial restarts with the step's first key block)
             SP4_MF(if (ks == 0) sp_mfma_z(dQp, dsa[0], kd[0][0]); else sp_mfma_v(dQp, dsa[0], kd[ks][0]));
             SP4_W(1);
+            if (kb == 2) qa[1] = *reinterpret_cast<const uint4*>(qn + o_rows1);
             SP_FENCE();
             SP4_E(S, 13); SP4_M(9); SP4_M(10); SP4_M(11); SP4_CD(4); SP4_CP(5);
             // ---- gap 7: dK^T += Q^T dS, first k-step (dS registers 0..7: the last conversion is a whole gap back)
@@ -2364,7 +2371,10 @@ __device__ __forceinline__ void attn_bwd_sp_body4(const Args& p, char* smem, int
                 red[0] = *reinterpret_cast<const f32x4*>(pr_base + (sub & 1) * SP_PART + 0 * 4 * 64 * 16);
                 red[1] = *reinterpret_cast<const f32x4*>(pr_base + (sub & 1) * SP_PART + 1 * 4 * 64 * 16);
             }
-            if (kb == 2) load_c2(Cd, cdn, 1);
+            if (kb == 2) {
+                doa[0] = *reinterpret_cast<const uint4*>(qn + 2 * IMG + o_rows0);
+                doa[1] = *reinterpret_cast<const uint4*>(qn + 2 * IMG + o_rows1);
+            }
             if (kb == 3) tr_one(qt[0], qn, 0);
             SP_FENCE();
             SP4_E(S, 14); SP4_E(S, 15); SP4_M(12); SP4_M(13); SP4_CD(5);
@@ -2379,10 +2389,6 @@ __device__ __forceinline__ void attn_bwd_sp_body4(const Args& p, char* smem, int
             if (kb == 1) {
                 red[2] = *reinterpret_cast<const f32x4*>(pr_base + (sub & 1) * SP_PART + 2 * 4 * 64 * 16);
                 red[3] = *reinterpret_cast<const f32x4*>(pr_base + (sub & 1) * SP_PART + 3 * 4 * 64 * 16);
-            }
-            if (kb == 2) {
-                doa[0] = *reinterpret_cast<const uint4*>(qn + 2 * IMG + o_rows0);
-                doa[1] = *reinterpret_cast<const uint4*>(qn + 2 * IMG + o_rows1);
             }
             if (kb == 3) tr_one(dot[1], qn + 2 * IMG, 1);
             SP_FENCE();

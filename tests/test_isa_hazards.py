@@ -4,7 +4,9 @@ NON-MFMA instruction reads (v_exp on the score tile, v_mul on dP, ds_write of th
 NumPasses + 4 wait states on gfx950 (LLVM GCNHazardRecognizer: 12 for an 8-pass, 20 for a 16-pass XDL op).  The kernel keeps every such
 consumer dozens of instructions behind its producer by construction; this test compiles the file to assembly (no GPU needed, ~10 s) and
 measures the distance in the code hipcc really emitted, so a compiler or source change that moves a consumer up fails here, not as a
-rare wrong gradient."""
+rare wrong gradient.  Also checked (round 5): the 2 wait states between a VALU write and the MFMA that reads the register as an
+operand.  Not checked: distances across a loop's back edge — every step of these loops ends in s_waitcnt + s_barrier, far longer than
+either window."""
 import os
 import re
 import shutil
@@ -106,6 +108,36 @@ def _check(lines, passes):
     return n_mfma, worst
 
 
+def _check_valu_to_mfma(lines):
+    """The second hand-managed hazard: a VALU-written register (v_cvt_pk of P / dS, v_exp, v_mul) read by an MFMA as its
+    A, B or C operand needs 2 wait states in between; hipcc pads this only across statement boundaries it can see.  Returns (MFMAs
+    checked, the smallest distance found to ANY in-window VALU producer, or None)."""
+    insts = [(n, _parse(l)) for n, l in enumerate(lines)]
+    insts = [(n, p) for n, p in insts if p]
+    closest = None
+    n_mfma = 0
+    for k, (n, (op, ops)) in enumerate(insts):
+        if not op.startswith('v_mfma'):
+            continue
+        n_mfma += 1
+        srcs = [r for r in (_regs(t) for t in ops[1:4]) if r]
+        states = 0
+        for n2, (op2, ops2) in reversed(insts[max(0, k - 8):k]):
+            if op2.startswith('s_cbranch') or op2 in ('s_branch', 's_barrier'):
+                break
+            if op2.startswith('v_') and not op2.startswith('v_mfma') and ops2:
+                dst = _regs(ops2[0])
+                if dst and any(s[0] == dst[0] and (s[1] & dst[1]) for s in srcs):
+                    if closest is None or states < closest[0]:
+                        closest = (states, lines[n2].strip(), lines[n].strip())
+                    assert states >= 2, f'{lines[n].strip()!r} reads {lines[n2].strip()!r} after {states} wait states (2 needed)'
+                    break
+            states += _wait_states(op2, ops2, 8) if not op2.startswith('v_mfma') else 8
+            if states >= 2:
+                break
+    return n_mfma, closest
+
+
 @pytest.mark.parametrize('flag', [[], ['-DSVOL_H16_FP16']], ids=['bf16', 'fp16'])
 def test_single_pass_backward_mfma_results_are_not_read_early(tmp_path, flag):
     hipcc = _hipcc()
@@ -123,6 +155,8 @@ def test_single_pass_backward_mfma_results_are_not_read_early(tmp_path, flag):
         n_mfma, worst = _check(lines, passes)
         assert n_mfma >= 40                  # the loop body alone holds 40
         assert worst is not None and worst[0] >= passes + 4
+    n2, closest = _check_valu_to_mfma(lines)     # VALU-written operand -> MFMA: at least 2 wait states (asserted inside)
+    assert n2 >= 40
     body = '\n'.join(lines)
     # the whole point of the asm forms: no accumulator <-> vector register copies inside the loop, nothing spilled
     meta = asm[asm.index('amdhsa.kernels'):]
