@@ -1,15 +1,15 @@
 set -e
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r4
+O=$R/gpurun_out/prof_r${RN:-5}
 rm -rf $O; mkdir -p $O
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o r4 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o r${RN:-5} -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench.json 2> $O/bench.err
 F=$(find $O/kt -name "*kernel_stats.csv" | head -1)
-cp $F $O/round4_kernel_stats.csv
-python tools/prof_summary.py $F 16 > $O/round4_kernel_stats.txt
-python tools/trace_timeline.py $(find $O/kt -name "*kernel_trace.csv" | head -1) > $O/round4_timeline.txt 2>&1 || true
-python - <<PY > $O/round4_turnaround.txt
+cp $F $O/round${RN:-5}_kernel_stats.csv
+python tools/prof_summary.py $F 16 > $O/round${RN:-5}_kernel_stats.txt
+python tools/trace_timeline.py $(find $O/kt -name "*kernel_trace.csv" | head -1) > $O/round${RN:-5}_timeline.txt 2>&1 || true
+python - <<PY > $O/round${RN:-5}_turnaround.txt
 import csv,glob
 f=glob.glob('$O/kt/**/*kernel_trace.csv', recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
@@ -35,5 +35,5 @@ for r in win[sb[-1]:]:
     print('%9.1f us +%7.1f  q%s  %s' % ((r['s']-win[sb[-1]]['s'])/1e3, (r['e']-r['s'])/1e3, r['Queue_Id'], r['n']))
 PY
 rm -rf $O/kt
-head -50 $O/round4_kernel_stats.txt
-cat $O/round4_timeline.txt | head -40
+head -50 $O/round${RN:-5}_kernel_stats.txt
+cat $O/round${RN:-5}_timeline.txt | head -40
