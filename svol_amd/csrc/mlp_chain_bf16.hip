@@ -446,8 +446,13 @@ int svol_mlp_chain_bf16(const void* X, int64_t ldx, const void* Wa, const void* 
     if (2 * ldr > ldbig) ldbig = 2 * ldr;
     if (256 * ldbig * 2 + F * 2 >= (1ll << 31) || 256 * F * 2 >= (1ll << 31)) return SVOL_E_UNSUPPORTED;   // 32-bit buffer offsets
     if (dry) return SVOL_OK;
+    // the lab's ablation mask (results INVALID) is honoured only together with SVOL_LAB=1: a stray SVOL_CHAIN_ABL alone is refused
+    // instead of silently skipping stores; both are read once
+    static const int abl = getenv("SVOL_CHAIN_ABL") ? atoi(getenv("SVOL_CHAIN_ABL")) : 0;
+    static const bool lab = getenv("SVOL_LAB") != nullptr;
+    if (abl && !lab) return SVOL_E_INVALID;
     ChainArgs p{(const h16_t*)X, (const h16_t*)Wa, (const h16_t*)Wb, (h16_t*)hid, (const h16_t*)aux_in, (h16_t*)aux_out, Y, ba, bb, res,
-                ldx, ldh, lda, ldy, ldr, (int)M, (int)F, getenv("SVOL_CHAIN_ABL") ? atoi(getenv("SVOL_CHAIN_ABL")) : 0};
+                ldx, ldh, lda, ldy, ldr, (int)M, (int)F, abl};
     const unsigned grid = (unsigned)((M + 255) / 256);
     static bool attr_done = false;
     if (!attr_done) {

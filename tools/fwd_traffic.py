@@ -18,7 +18,7 @@ def main():
     trace, table, algo, label = sys.argv[1], json.load(open(sys.argv[2])), float(sys.argv[3]), sys.argv[4]
     rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r['Start_Timestamp']))
     lsap = [i for i, r in enumerate(rows) if 'lsap_kernel' in r['Kernel_Name']]
-    opt = [i for i, r in enumerate(rows) if 'adamw_flat_kernel' in r['Kernel_Name']]
+    opt = [i for i, r in enumerate(rows) if 'adamw_flat' in r['Kernel_Name']]
     end = lsap[-1]
     start = max(i for i in opt if i < end) + 1  # first launch after the previous step's optimizer
     rd = wr = 0.0
