@@ -189,6 +189,47 @@ for base in ['EEMC', 'EMC']:
         slots = [base + extra_, base] * 5
         VARIANTS.append((f'h_{base}_{extra_}', f'alternate gaps: {slots[0]} {slots[1]}') + block(slots))
 
+# ---- round 5, second question: would the attention backward at TWO waves per SIMD (8 waves x 64 keys, no one-block lookahead:
+# registers; the dQ product over ALL the workgroup's keys with 16x16x32 MFMAs so that no 32 x 32 fp32 partial per wave crosses LDS)
+# be issue-bound where the model says?  One "step" of one wave = 2 blocks + the per-step part, as COARSE phases (what a stream
+# without lookahead looks like: loads, products, the vector phase, products, stores) and as a fine interleave for comparison.
+def sp8_step(fine):
+    b = Body()
+    def mf16():
+        b.lines.append(f'v_mfma_f32_16x16x32_bf16 v[{ACC[0]}:{ACC[0] + 3}], v[{A}:{A + 3}], v[{B}:{B + 3}], v[{ACC[0]}:{ACC[0] + 3}]')
+    n_mfma = 0
+    for blk in range(2):
+        if not fine:
+            for _ in range(8): b.filler('dsr128')          # row constants straight into the score / dP registers
+            if blk == 0:
+                for _ in range(4): b.filler('dsr128')      # Q / dO rows of the step
+                for _ in range(8): b.filler('dsr_tr')      # transposed Q / dO
+            for _ in range(4): b.mfma(); n_mfma += 1
+            for k in 'E' * 16 + 'M' * 16 + 'C' * 16: b.filler(KINDS[k])
+            for _ in range(4): b.mfma(); n_mfma += 1
+            for _ in range(4): b.filler('dsw')
+        else:
+            slots = [list(x) for x in BAL]
+            extra = list('LLLLLLLL') + (list('LLLL' 'RRRRRRRR') if blk == 0 else [])
+            for i, ch in enumerate(extra): slots[(2 * i) % 10].insert(0, ch)
+            for sl in slots:
+                b.mfma(); n_mfma += 1
+                for ch in sl:
+                    if ch in 'WR' and sl is not None and ch == 'R' and False: pass
+                    b.filler(KINDS[ch])
+    # the dQ phase of the previous step: 16 transposed reads, 8 MFMAs 16x16x32, the 2-way reduce and the atomics (as adds / nops)
+    for i in range(8):
+        b.filler('dsr_tr'); b.filler('dsr_tr')
+        mf16()
+    b.filler('dsr128')
+    for _ in range(4): b.filler('add')
+    for _ in range(4): b.filler('nop')
+    return b, 20        # "gaps" = the 20 32x32x16 MFMAs of the two blocks: cycles per gap x 10 = cycles per block (the dQ MFMAs = 4 more gaps of pipe)
+
+
+VARIANTS.append(('sp8_phase', 'two-waves-per-SIMD backward, one step, COARSE phases (per block: 10 gaps + 2 pipe-equivalents of dQ)') + sp8_step(False))
+VARIANTS.append(('sp8_fine', 'the same instructions finely interleaved') + sp8_step(True))
+
 clob = ', '.join(f'"v{i}"' for i in range(32, 180))
 
 print('// GENERATED by tools/micro/gen_mfma_fillers.py -- do not edit.  See that file for what this measures.')
