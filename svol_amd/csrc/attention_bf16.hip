@@ -2429,6 +2429,160 @@ __device__ __forceinline__ void attn_bwd_sp_body4(const Args& p, char* smem, int
         store_acc(dV[kb], dVo, p.lddv, key0 + kb * 32 + r, true, 32, h, 1.f);
     }
 }
+// ---- round 5: the fast forward as a hand-placed stream (same algorithm as attn_fwd_bf16_fast: anchored once, LDS-DMA tiles,
+// overflow flag + attn_fwd_bf16_pre behind it).  attn_fwd_bf16_fast is hipcc-scheduled: per 128-key tile it issues, beside 16 MFMAs,
+// 64 exp and 32 cvt_pk, 26 v_pk_add_f32 (row sums in register pairs), 31 v_mov (to build those pairs) and 16 s_nop — and a packed
+// fp32 instruction does not overlap an MFMA at all (profiles/round5_mfma_fillers.md): ~390 cycles per 32 x 32 block against an issue
+// floor of ~264 (4 MFMAs x 8 + 16 exp x 8 + 16 add x 4 + 8 cvt x 5).  Here every MFMA and every vector instruction is an asm statement
+// in source order: a block = [V^T fragments + the next block's K rows from LDS] E0-7 | S' k-step 0 | E8-11 A0-7 | S' k-step 1 |
+// C0-3 E12-15 | PV k-step 0 | C4-7 A8-15 | PV k-step 1, the next block's scores (S') one block ahead and ITS K rows fetched a block before that —
+// across tile boundaries too: three tile buffers, the wait + barrier for tile t + 1 stand in front of tile t's THIRD block and the transfer of tile t + 2 is
+// issued right behind that barrier (every wave is then done with tile t - 1, whose buffer it takes).  Plain v_add_f32 row sums in four
+// rotating accumulators.  Conversions stand four statements in front of the MFMA that reads them (hipcc pads closer pairs).
+__device__ __forceinline__ void fw_mfma_c(f32x16& d, const uint4& a, const uint4& b, const f32x16& c) {
+    asm volatile("v_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %1, %2, %3" : "=&v"(d) : "v"(as_u32x4(a)), "v"(as_u32x4(b)), "v"(c));
+}
+__device__ __forceinline__ void fw_mfma_v(f32x16& d, const uint4& a, const uint4& b) {
+    asm volatile("v_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %1, %2, %0" : "+v"(d) : "v"(as_u32x4(a)), "v"(as_u32x4(b)));
+}
+__device__ __forceinline__ void fw_mfma_p(f32x16& d, const uint4& a, const u32x4& b) {
+    asm volatile("v_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %1, %2, %0" : "+v"(d) : "v"(as_u32x4(a)), "v"(b));
+}
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_fast2(Args p) {
+    __shared__ __attribute__((aligned(16))) char smem[6 * IMG];   // [3] K tiles | [3] V tiles
+    char* sK = smem;
+    char* sV = smem + 3 * IMG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int xt, hh, b;
+    block_coords(p, xt, hh, b);
+    const int qrow = xt * 128 + wave * 32 + r;
+    const bool qvalid = qrow < p.Lq;
+    const h16_t* Q = reinterpret_cast<const h16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * p.dh;
+    const h16_t* K = reinterpret_cast<const h16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * p.dh;
+    const h16_t* V = reinterpret_cast<const h16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * p.dh;
+    uint4 qb[2];
+    load_lane_block(qb, Q, p.ldq, qrow, qvalid, p.dh, h);
+    const int nt = p.Lk / KT;     // launcher guarantees Lk % KT == 0 and dh == 32
+    dma_tile(sK, K, p.ldk, 0, wave, lane);
+    dma_tile(sV, V, p.ldv, 0, wave, lane);
+    if (nt > 1) {
+        dma_tile(sK + IMG, K, p.ldk, KT, wave, lane);
+        dma_tile(sV + IMG, V, p.ldv, KT, wave, lane);
+    }
+    dma_wait_all();
+    __syncthreads();
+    float m;                      // the anchor: this query's largest score in key tile 0 (log2 domain)
+    {
+        float mm = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            uint4 ka[2];
+            read_rows(ka, sK, sub * 32 + r, h);
+            const f32x16 S0 = mma_first(ka, qb);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mm = fmaxf(mm, S0[i]);
+        }
+        const HalfPair sw = swap_halves(__builtin_bit_cast(unsigned, mm));
+        m = fmaxf(__builtin_bit_cast(float, sw.lo), __builtin_bit_cast(float, sw.hi));
+    }
+    const f32x16 Cm = splat16(-m);
+    f32x16 O = zero16();
+    float lacc[4] = {0.f, 0.f, 0.f, 0.f};
+    // lane-dependent LDS offsets inside a tile image, computed ONCE (a tile / sub-tile adds uniform bytes: 32 rows = 2048)
+    const unsigned o_rows0 = img_off(r, h), o_rows1 = img_off(r, 2 + h);
+    unsigned o_trl, o_trh;
+    {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, h2 = g >> 1;
+        const int ch = 2 * (g & 1) + (pp >> 1), inner = 8 * (pp & 1);
+        o_trl = img_off(4 * h2 + q, ch) + inner;
+        o_trh = img_off(4 * h2 + q + 8, ch) + inner;
+    }
+    f32x16 S;                      // score - anchor of the block that is processed next
+    uint4 kn[2];                   // K rows of the block after it (fetched a whole block before the products that read them)
+    {
+        uint4 ka[2];
+        read_rows(ka, sK, r, h);
+        read_rows(kn, sK, 32 + r, h);
+        fw_mfma_c(S, ka[0], qb[0], Cm);
+        fw_mfma_v(S, ka[1], qb[1]);
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(S), "+v"(O));
+    }
+#define FW_E(i) asm volatile("v_exp_f32 %0, %0" : "+v"(S[i]))
+#define FW_A(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(lacc[(i) & 3]) : "v"(S[i]))
+#define FW_C(j) asm volatile("v_cvt_pk_" SVOL_H16_ASM "_f32 %0, %1, %2" : "=v"(((j) < 4 ? P0 : P1)[(j) & 3]) : "v"(S[2 * (j)]), "v"(S[2 * (j) + 1]))
+#define FW_MF(stmt) do { SP_FENCE(); stmt; SP_FENCE(); } while (0)
+    // LDS-DMA sources of this wave's two 16-row pieces of a tile (dma_piece's address arithmetic), kept as running pointers to tile t + 2
+    const int prow = 32 * wave + (lane >> 2), pch = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
+    const h16_t* gk2 = K + ((int64_t)2 * KT + prow) * p.ldk + pch;
+    const h16_t* gv2 = V + ((int64_t)2 * KT + prow) * p.ldv + pch;
+    const unsigned lds_k = (unsigned)(size_t)(lds_vptr)sK + wave * 2048, lds_v = (unsigned)(size_t)(lds_vptr)sV + wave * 2048;
+    int cur = 0;                   // buffer of tile t (t % 3, kept incrementally)
+    for (int t = 0; t < nt; ++t) {
+        const int nxt = cur == 2 ? 0 : cur + 1, nxt2 = nxt == 2 ? 0 : nxt + 1;
+        const char* kimg = sK + cur * IMG;
+        const char* vimg = sV + cur * IMG;
+        const bool more = t + 1 < nt;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            if (sub == 2 && more) {   // tile t + 1 (issued a whole tile ago) has landed: this block fetches its first K rows
+                dma_wait_all();
+                __syncthreads();      // ... and every wave is done with tile t - 1: its buffer takes tile t + 2
+                if (t + 2 < nt) {
+                    const unsigned dk_ = __builtin_amdgcn_readfirstlane(lds_k + nxt2 * IMG), dv_ = __builtin_amdgcn_readfirstlane(lds_v + nxt2 * IMG);
+                    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dk_), "v"(gk2) : "m0");
+                    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dk_ + 1024), "v"(gk2 + 16 * p.ldk) : "m0");
+                    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dv_), "v"(gv2) : "m0");
+                    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dv_ + 1024), "v"(gv2 + 16 * p.ldv) : "m0");
+                    gk2 += (int64_t)KT * p.ldk;
+                    gv2 += (int64_t)KT * p.ldv;
+                }
+            }
+            // (the last block of the last tile computes the scores of a block that does not exist, from stale rows of the next
+            // buffer: branch-free, nothing reads them)
+            const char* nrow = sub < 2 ? kimg + (sub + 2) * 2048 : sK + nxt * IMG + (sub - 2) * 2048;   // K rows of the block after next
+            uint4 va[2];
+            f32x16 Sn;
+            u32x4 P0, P1;
+            SP_FENCE();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {   // (= read_tr(va, vimg, sub, lane))
+                const h16x4 lo = SVOL_DS_READ_TR16_H16((lds_bf16x4_ptr)(vimg + sub * 2048 + o_trl + 1024 * ks));
+                const h16x4 hi = SVOL_DS_READ_TR16_H16((lds_bf16x4_ptr)(vimg + sub * 2048 + o_trh + 1024 * ks));
+                va[ks] = __builtin_bit_cast(uint4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+            SP_FENCE();
+            FW_E(0); FW_E(1); FW_E(2); FW_E(3); FW_E(4); FW_E(5); FW_E(6); FW_E(7);
+            FW_MF(fw_mfma_c(Sn, kn[0], qb[0], Cm));
+            FW_E(8); FW_E(9); FW_E(10); FW_E(11); FW_A(0); FW_A(1); FW_A(2); FW_A(3); FW_A(4); FW_A(5); FW_A(6); FW_A(7);
+            FW_MF(fw_mfma_v(Sn, kn[1], qb[1]));
+            kn[0] = *reinterpret_cast<const uint4*>(nrow + o_rows0);   // (= read_rows: the rows of the block after next, behind their
+            kn[1] = *reinterpret_cast<const uint4*>(nrow + o_rows1);   //  registers' last reader)
+            SP_FENCE();
+            FW_C(0); FW_C(1); FW_C(2); FW_C(3); FW_E(12); FW_E(13); FW_E(14); FW_E(15);
+            FW_MF(fw_mfma_p(O, va[0], P0));
+            FW_C(4); FW_C(5); FW_C(6); FW_C(7); FW_A(8); FW_A(9); FW_A(10); FW_A(11); FW_A(12); FW_A(13); FW_A(14); FW_A(15);
+            FW_MF(fw_mfma_p(O, va[1], P1));
+            S = Sn;
+        }
+        cur = nxt;
+    }
+#undef FW_E
+#undef FW_A
+#undef FW_C
+#undef FW_MF
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(O));   // the last product's result is read by compiler-generated code below
+    const float l = (lacc[0] + lacc[1]) + (lacc[2] + lacc[3]);
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const int bad = __syncthreads_or(qvalid && !(lt < SVOL_H16_PSUM_MAX));   // inf / NaN (fp16: any P near 65504): a score left the anchor's range
+    if (tid == 0) p.redo[blockIdx.x] = bad ? 1 : 0;
+    if (bad) return;              // attn_fwd_bf16_pre (next launch on the stream) recomputes this workgroup
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    h16_t* Oo = reinterpret_cast<h16_t*>(p.out_o) + (int64_t)b * p.Lq * p.ldo + hh * p.dh;
+    store_acc(O, Oo, p.ldo, qrow, qvalid, p.dh, h, inv);
+    if (qvalid && h == 0) p.lse2[((int64_t)b * p.H + hh) * p.Lq + qrow] = m + __builtin_amdgcn_logf(lt);
+}
+
 // workgroup id -> work.  [0, n_main): the full 512-key groups, heads dealt to the XCDs as block_coords does (nxt = full groups per
 // head).  [n_main, n_main + 4 B H): the tail groups, four query quarters each, on the same head -> XCD deal.
 struct SpWork { int hh, b, kbase, t0, t1, part; bool tail; };
@@ -2592,7 +2746,9 @@ int svol_attn_fwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
         const int64_t nwg = (int64_t)grid.x * grid.y * grid.z;
         if (!no_fast && p.head_xcd && dh == 32 && ws && ws_bytes >= nwg * 4) {
             p.redo = reinterpret_cast<int*>(ws);
-            hipLaunchKernelGGL(attn_fwd_bf16_fast, grid, dim3(256), 0, s, p);
+            static const bool fwd_v1 = getenv("SVOL_ATTN_FWD_V1") != nullptr;   // round 2's hipcc-scheduled fast forward (A/B)
+            if (fwd_v1) hipLaunchKernelGGL(attn_fwd_bf16_fast, grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL(attn_fwd_bf16_fast2, grid, dim3(256), 0, s, p);
         }
         hipLaunchKernelGGL(attn_fwd_bf16_pre, grid, dim3(256), 0, s, p);  // all workgroups, or (p.redo) only the flagged ones
     } else if (masked) hipLaunchKernelGGL(attn_fwd_bf16<true>, grid, dim3(256), 0, s, p);
