@@ -2504,7 +2504,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_fast2(Args p) {
         uint4 ka[2];
         read_rows(ka, sK, r, h);
         read_rows(kn, sK, 32 + r, h);
-        fw_mfma_c(S, ka[0], qb[0], Cm);
+        // (Cm was written by vector moves just above: a VALU-written operand needs 2 wait states in front of the MFMA that reads it
+        // and hipcc pads nothing in front of an asm statement — found by tests/test_isa_hazards.py; inside the loop Cm is invariant)
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_" SVOL_H16_ASM " %0, %1, %2, %3" : "=&v"(S) : "v"(as_u32x4(ka[0])), "v"(as_u32x4(qb[0])), "v"(Cm));
         fw_mfma_v(S, ka[1], qb[1]);
         asm volatile("s_nop 15\n\ts_nop 15" : "+v"(S), "+v"(O));
     }

@@ -185,3 +185,31 @@ for B, Lq, Lk, mask in ((8, 6272, 6272, False), (8, 100, 6272, True)):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('SHAPE')]
     assert len(lines) == 2 and all('identical' in ln for ln in lines), r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('L', [128, 256, 384, 512, 640, 1152])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_hand_placed_forward_at_small_tile_counts(L, dtype):
+    """attn_fwd_bf16_fast2 keeps three tile buffers and computes the next block's scores across tile boundaries: 1, 2, 3, 4, 5 and 9
+    key tiles (the ring wraps after three) against fp64, every (batch, head), output and lse."""
+    import math
+    from svol_amd import ops
+    B, H, dh = 2, 8, 32
+    d = H * dh
+    pm = 1.4426950408889634 / math.sqrt(dh)
+    g = torch.Generator().manual_seed(100 + L)
+    q32, k32, v32 = (torch.randn((B * L, d), generator=g) for _ in range(3))
+    q = (q32 * pm).to(dtype).cuda()
+    k, v = k32.to(dtype).cuda(), v32.to(dtype).cuda()
+    o, lse2 = ops.attn_fwd(q, k, v, B, H, L, L, dh, None, pm)
+    torch.cuda.synchronize()
+    qd = q.double().cpu().view(B, L, H, dh).transpose(1, 2)          # (pre-multiplied: scores are in the log2 domain)
+    kd = k.double().cpu().view(B, L, H, dh).transpose(1, 2)
+    vd = v.double().cpu().view(B, L, H, dh).transpose(1, 2)
+    s2 = qd @ kd.transpose(-1, -2)
+    ref_lse2 = torch.logsumexp(s2 * math.log(2.0), -1) / math.log(2.0)
+    ref_o = (torch.softmax(s2 * math.log(2.0), -1) @ vd).transpose(1, 2).reshape(B * L, d)
+    tol = 1.2e-2 if dtype == torch.bfloat16 else 2e-3
+    assert float((o.double().cpu() - ref_o).abs().max()) <= tol
+    assert float((lse2.double().cpu() - ref_lse2).abs().max()) <= 2e-5 * max(1.0, float(ref_lse2.abs().max()))

@@ -169,3 +169,39 @@ def test_single_pass_backward_mfma_results_are_not_read_early(tmp_path, flag):
         assert not any('v_accvgpr' in l or 'scratch_' in l for l in lines[a:b])
     assert 'cmpswap' not in body             # dQ leaves as global_atomic_add_f32, not a compare-and-swap loop
     assert body.count('global_atomic_add_f32') >= 4
+
+
+@pytest.mark.parametrize('flag', [[], ['-DSVOL_H16_FP16']], ids=['bf16', 'fp16'])
+def test_hand_placed_forward_keeps_its_hazard_distances(tmp_path, flag):
+    """The round-5 fast forward (attn_fwd_bf16_fast2) is asm statements in source order too: the scores of the next block are
+    exponentiated a whole block after their MFMAs, a conversion feeds the PV product four statements later.  Same two static checks
+    as the backward, and nothing spilled."""
+    hipcc = _hipcc()
+    if hipcc is None:
+        pytest.skip('hipcc not found')
+    from svol_amd import build
+    out = str(tmp_path / 'attention.s')
+    cmd = [hipcc] + build.COMMON + build.PER_FILE.get('attention_bf16.hip', []) + flag + ['--cuda-device-only', '-S', SRC, '-o', out]
+    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+    asm = open(out).read()
+    name = [m for m in re.findall(r'^(_Z\w*attn_fwd_\w*fast2\w*):', asm, flags=re.M)]
+    assert name, 'attn_fwd_bf16_fast2 not found in the assembly'
+    lines = _kernel_lines(asm, name[0])
+    # the prologue (anchor from key tile 0) uses the MFMA BUILTIN, which hipcc pads itself for the documented 8 passes; the hand-managed
+    # part is the tile loop: checked under both pass models
+    n_mfma, worst = _check(lines, 8)
+    assert n_mfma >= 16 and worst is not None and worst[0] >= 12
+    loops = _mfma_loops(lines)
+    assert len(loops) == 1
+    a, b = loops[0]
+    for passes in PASSES:
+        n_loop, worst = _check(lines[a:b], passes)
+        assert n_loop >= 16 and (worst is None or worst[0] >= passes + 4)
+    n2, _ = _check_valu_to_mfma(lines)
+    assert n2 >= 16
+    meta = asm[asm.index('amdhsa.kernels'):]
+    k = meta[meta.index(name[0]):]
+    assert int(re.search(r'\.private_segment_fixed_size:\s*(\d+)', k).group(1)) == 0
+    assert int(re.search(r'\.vgpr_spill_count:\s*(\d+)', k).group(1)) == 0
+    body = '\n'.join(lines)
+    assert 'v_pk_add_f32' not in body and 'v_pk_mul_f32' not in body   # a packed fp32 instruction does not overlap an MFMA
