@@ -102,6 +102,17 @@ template <> struct H16<f16_t> {
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// SVOL_DETERMINISTIC=1 (read once): every reduction that normally meets its partial sums through floating-point atomics in ARRIVAL
+// order takes a form with ONE adder per output element instead — the row-loop kernels (LayerNorm / gate backward, column sums) walk all
+// their rows in one wave, the split weight-gradient GEMMs do not split the contraction, fused bias-gradient column sums become a separate
+// single-adder pass, the attention backward uses its atomic-free kernels.  A test mode: the step is several times slower, and bit-identical
+// from run to run (tests/test_gpu_training.py::test_training_steps_are_bit_reproducible_in_deterministic_mode).
+#include <cstdlib>
+static inline bool svol_deterministic() {
+    static const bool det = getenv("SVOL_DETERMINISTIC") != nullptr;
+    return det;
+}
+
 // v_permlane32_swap of a value with itself: lo = the value held by lane (i & 31), hi = the value held by lane (i | 32), in
 // EVERY lane i.  The second operand is laundered through an empty asm: with two identical SSA operands hipcc (ROCm 7.2) folds the
 // two results of the builtin into one register (v_permlane32_swap v1, v3 ; v_add_f32 v3, v1, v1) and the partner's value is lost.

@@ -617,6 +617,7 @@ __global__ __launch_bounds__(256) void gate_vec_bwd_b_multi_kernel(const float* 
 }
 
 int rows_per_wave(int64_t rows, int64_t target_waves) {
+    if (svol_deterministic()) return (int)(rows < 1 ? 1 : rows);   // one wave walks every row (one adder per reduced element)
     int64_t r = (rows + target_waves - 1) / target_waves;
     return (int)(r < 1 ? 1 : r);
 }

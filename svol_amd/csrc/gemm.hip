@@ -624,6 +624,7 @@ static int tn_generic_plan(const void* A, int64_t lda, const void* B, int64_t ld
     static const int small_wgs = getenv("SVOL_TN_SMALL_WGS") ? atoi(getenv("SVOL_TN_SMALL_WGS")) : 64;
     const int target_wgs = force_wgs ? force_wgs : ((dtype == SVOL_F32 && Mc <= 4096) ? small_wgs : (tiles <= 8 ? 256 : 512));
     int64_t want = (target_wgs + tiles - 1) / tiles;
+    if (svol_deterministic()) want = 1;   // no contraction split: one adder per output element
     int64_t chunk = (Mc + want - 1) / want;
     chunk = ((chunk + ct - 1) / ct) * ct;
     // (fp32 with few rows — the query stream's weight gradients, Mc = 800: the 4 x CT floor would leave 28 workgroups, each
@@ -757,6 +758,10 @@ int svol_gemm_nt_dact(const void* A, int64_t lda, const void* B, int64_t ldb, vo
     if (!A || !B || !C || !aux || M < 0 || N < 0 || K <= 0) return SVOL_E_INVALID;
     if (act != SVOL_ACT_GELU && act != SVOL_ACT_RELU && act != SVOL_ACT_GELU_D) return SVOL_E_INVALID;
     if (M == 0 || N == 0) return SVOL_OK;
+    if (colsum && svol_deterministic()) {   // the fused column sums meet through atomics in arrival order: a single-adder pass instead
+        const int rc = svol_gemm_nt_dact(A, lda, B, ldb, C, ldc, aux, ldaux, act, nullptr, M, N, K, dtype, stream);
+        return rc ? rc : svol_colsum(C, ldc, colsum, M, N, dtype, stream);
+    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (svol_is16(dtype)) {
         const int rc = (dtype == SVOL_BF16 ? svol_gemm_nt_bf16_fast : svol_gemm_nt_f16_fast)(
@@ -865,6 +870,7 @@ int svol_colsum(const void* X, int64_t ldx, float* out, int64_t M, int64_t N, in
     int maxrb = 2048 / colblocks;
     if (maxrb < 1) maxrb = 1;
     if (rowblocks > maxrb) rowblocks = maxrb;
+    if (svol_deterministic()) rowblocks = 1;   // one adder per column
     const int rpb = (int)((M + rowblocks - 1) / rowblocks);
     dim3 grid(colblocks, (unsigned)((M + rpb - 1) / rpb));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

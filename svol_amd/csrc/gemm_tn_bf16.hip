@@ -225,6 +225,7 @@ bool tn_plan(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, i
     const int target_wgs = tiles <= 8 ? (force_wgs ? force_wgs : 128) : (force_wgs2 ? force_wgs2 : 128);
     int64_t want = (target_wgs + tiles - 1) / tiles;
     if (want > 8) want = want / 8 * 8;
+    if (svol_deterministic()) want = 1;   // no contraction split: one adder per output element
     int64_t chunk = (Mc + want - 1) / want;
     chunk = ((chunk + CT - 1) / CT) * CT;
     if (chunk < 4 * CT) chunk = 4 * CT;

@@ -327,6 +327,7 @@ int svol_layernorm_bwd(const float* dy32, const void* dy, const void* dy2, const
     // ~2048 waves (512 workgroups); each wave walks `rpw` consecutive rows; one set of atomics per workgroup
     int64_t rpw = (M + 2047) / 2048;
     if (rpw < 1) rpw = 1;
+    if (svol_deterministic()) rpw = M;   // one wave walks every row: one adder per column sum
     const int64_t waves = (M + rpw - 1) / rpw;
     const unsigned grid = (unsigned)((waves + 3) / 4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -232,3 +232,68 @@ def test_bare_transformer_sees_in_place_weight_updates(opt_kind):
         assert float((a - b).abs().max()) <= 0.1 * moved + 2e-2, (float((a - b).abs().max()), moved)   # ... and the plans see them
     for a, b in zip(p_blk, p_ref):                                                   # backward used the current W^T too
         assert float((a - b).abs().max()) <= 2e-2 * max(1.0, float(b.abs().max()))
+
+
+def test_training_steps_are_bit_reproducible_in_deterministic_mode():
+    """SURVEY §5 asks for a deterministic-reduction mode; VERDICT r4 ("What's missing 4") for a switch and a test that two training
+    steps are bit-identical.  SVOL_DETERMINISTIC=1 gives every floating-point reduction of the step ONE adder per output element
+    (csrc/common.h::svol_deterministic: atomic-free attention backward, unsplit weight-gradient GEMMs, single-wave LayerNorm / gate /
+    column-sum reductions).  Two fresh runs of three optimisation steps — the bench model's width (d = 256, 8 heads, so the MFMA-path
+    kernels run) at L = 1536 with the single-pass shapes in reach — must leave bit-identical parameters and losses; the same two runs
+    WITHOUT the switch are allowed to differ and are only reported.  The library reads the variable once: child processes."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import hashlib, torch
+from svol_amd import parallel
+from svol_amd import synthetic as syn
+from svol_amd.modeling.loss import build_loss
+from svol_amd.modeling.svanet import build_svanet
+args = syn.head_args(hidden_dim=256, nheads=8, num_layers=2, num_queries=100, num_frames=8, input_vid_dim=512, input_skch_dim=512,
+                     input_dropout=0.1, matcher='video_matcher')
+args.compute_dtype = 'bf16'
+B, T, P = 2, 8, 192
+def run():
+    torch.manual_seed(1)
+    model = build_svanet(args).cuda().train()
+    crit = build_loss(args).cuda().train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    red = parallel.BucketedGradAllReduce(parallel.arrival_order(model), skip=parallel.unused_parameters(model))
+    opt = parallel.FlatAdamW(red, lr=1e-3, weight_decay=1e-4, params=params)
+    inp = {k: v.cuda() for k, v in syn.synth_inputs(args, B, T, P, seed=3).items()}
+    tg = syn.synth_targets(B, T, seed=3)
+    h = hashlib.sha256()
+    for _ in range(3):
+        red.zero_grad()
+        out = model(inp['src_sketch'], inp['src_sketch_mask'], inp['src_video'], inp['src_video_mask'])
+        crit(out, tg)
+        loss = crit.weighted_total()
+        loss.backward()
+        red.finish()
+        opt.step()
+        h.update(loss.detach().cpu().numpy().tobytes())
+    torch.cuda.synchronize()
+    for p in params:
+        h.update(p.detach().cpu().numpy().tobytes())
+    return h.hexdigest(), float(loss)
+a = run()
+b = run()
+print('RUNS', a[0], b[0], a[1], b[1])
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for det in (True, False):
+        env = dict(os.environ, PYTHONPATH=root)
+        env.pop('SVOL_DETERMINISTIC', None)
+        if det:
+            env['SVOL_DETERMINISTIC'] = '1'
+        r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('RUNS')][0].split()
+        res[det] = (line[1], line[2], float(line[3]), float(line[4]))
+    print('deterministic:', res[True], ' default:', res[False])
+    assert res[True][0] == res[True][1], 'two runs under SVOL_DETERMINISTIC=1 differ'
+    assert res[True][2] == res[True][2] and abs(res[True][2]) < 1e4
+    # the mode changes summation orders, not the algorithm: same loss as the default mode to rounding
+    assert abs(res[True][2] - res[False][2]) <= 2e-2 * max(1.0, abs(res[False][2]))
