@@ -121,6 +121,24 @@ if 'gemm3' in which:  # fc1 epilogue ablation: what bounds the weight-stationary
         t = timeit(fn)
         print(f'{name:34s}: {t * 1e3:7.1f} us  {byts / t / 1e6:6.0f} GB/s')
 
+if 'gemm4' in which:  # round 5: the video half's MLP as the step runs it (fc1 saves gelu', the backward multiplies by it)
+    M = B * L
+    x = rnd(M, D)
+    W_fd = rnd(F, D, scale=0.05)
+    W_df = rnd(D, F, scale=0.05)
+    b_f = torch.zeros(F, device=DEV)
+    dpre = rnd(M, F)
+    cs = torch.zeros(F, dtype=torch.float32, device=DEV)
+    for name, fn, byts in [
+        ('fc1 gelu + gelu\' saved', lambda: ops.gemm_nt(x, W_fd, b_f, ops.ACT_GELU_D, want_pre=True), M * D * 2 + M * F * 4),
+        ('dmul (dY W2) * aux + colsum', lambda: ops.gemm_nt_dact(x, W_fd, dpre, ops.ACT_GELU_D, colsum_out=cs), M * D * 2 + M * F * 4),
+        ('fc1 none', lambda: ops.gemm_nt(x, W_fd, b_f), M * D * 2 + M * F * 2),
+        ('v proj N=256', lambda: ops.gemm_nt(x, W_df[:, :D].contiguous(), b_f[:D].contiguous()), M * D * 4),
+        ('qk proj N=512', lambda: ops.gemm_nt(x, W_fd[:2 * D].contiguous(), b_f[:2 * D].contiguous(), colscale=torch.ones(2 * D, device=DEV)), M * D * 6),
+    ]:
+        t = timeit(fn)
+        print(f'{name:34s}: {t * 1e3:7.1f} us  {byts / t / 1e6:6.0f} GB/s')
+
 if 'ln' in which:
     M = B * L
     x = torch.randn(M, D, device=DEV)
