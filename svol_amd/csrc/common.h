@@ -103,15 +103,53 @@ template <> struct H16<f16_t> {
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // SVOL_DETERMINISTIC=1 (read once): every reduction that normally meets its partial sums through floating-point atomics in ARRIVAL
-// order takes a form with ONE adder per output element instead — the row-loop kernels (LayerNorm / gate backward, column sums) walk all
-// their rows in one wave, the split weight-gradient GEMMs do not split the contraction, fused bias-gradient column sums become a separate
-// single-adder pass, the attention backward uses its atomic-free kernels.  A test mode: the step is several times slower, and bit-identical
-// from run to run (tests/test_gpu_training.py::test_training_steps_are_bit_reproducible_in_deterministic_mode).
+// order takes a form with ONE adder per output element instead — the row-loop kernels (LayerNorm / gate backward, column sums) store
+// per-workgroup partial rows that are folded in index order (DetScratch / det_fold below), the split weight-gradient GEMMs do not split the
+// contraction, fused bias-gradient column sums become a separate folded pass, the attention backward uses its atomic-free kernels.  A test
+// mode: the step is ~2 x slower (38 against 18 ms at cfg2), and bit-identical from run to run
+// (tests/test_gpu_training.py::test_training_steps_are_bit_reproducible_in_deterministic_mode).
 #include <cstdlib>
 static inline bool svol_deterministic() {
     static const bool det = getenv("SVOL_DETERMINISTIC") != nullptr;
     return det;
 }
+
+// Two-level reductions of the deterministic mode: instead of adding its partial vector to the sink with atomics, a workgroup (or wave)
+// stores it into a row of a stream-ordered scratch; det_fold then adds the rows to the sink in index order — one adder per element,
+// the same order in every run, at the parallelism of the default mode.  (hipMallocAsync / hipFreeAsync: the scratch lives between
+// the two launches on the caller's stream; the mode is a debugging aid, not for graph capture.)
+struct DetScratch {
+    float* p = nullptr;
+    hipStream_t s;
+    DetScratch(size_t floats, hipStream_t s_, bool zero = false) : s(s_) {
+        if (hipMallocAsync(reinterpret_cast<void**>(&p), floats * sizeof(float), s) != hipSuccess) p = nullptr;
+        if (p && zero && hipMemsetAsync(p, 0, floats * sizeof(float), s) != hipSuccess) { (void)hipFreeAsync(p, s); p = nullptr; }
+    }
+    ~DetScratch() { if (p) (void)hipFreeAsync(p, s); }
+    DetScratch(const DetScratch&) = delete;
+    DetScratch& operator=(const DetScratch&) = delete;
+};
+#ifdef __HIPCC__
+namespace {
+// dst[b][j] += part[b][0][j] + part[b][1][j] + ... (rows `pstride` floats apart, batches bpart / bdst floats apart)
+__global__ __launch_bounds__(256) void det_fold_kernel(const float* __restrict__ part, int parts, int64_t pstride, float* __restrict__ dst,
+                                                       int64_t n, int64_t bpart, int64_t bdst) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const float* q = part + (int64_t)blockIdx.y * bpart + j;
+    float* d = dst + (int64_t)blockIdx.y * bdst + j;
+    float acc = *d;
+    for (int i = 0; i < parts; ++i) acc += q[(int64_t)i * pstride];
+    *d = acc;
+}
+inline void det_fold(const float* part, int parts, int64_t pstride, float* dst, int64_t n, hipStream_t s, int batches = 1, int64_t bpart = 0,
+                     int64_t bdst = 0) {
+    if (!dst || n <= 0 || parts <= 0) return;
+    hipLaunchKernelGGL(det_fold_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)batches), dim3(256), 0, s, part, parts, pstride, dst, n,
+                       bpart, bdst);
+}
+}  // namespace
+#endif
 
 // v_permlane32_swap of a value with itself: lo = the value held by lane (i & 31), hi = the value held by lane (i | 32), in
 // EVERY lane i.  The second operand is laundered through an empty asm: with two identical SSA operands hipcc (ROCm 7.2) folds the

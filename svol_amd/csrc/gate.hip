@@ -221,7 +221,10 @@ __global__ __launch_bounds__(256) void gate_bwd_ln_kernel(const float* __restric
                                                           float* __restrict__ da, float* __restrict__ dgamma,
                                                           float* __restrict__ dbeta, const float* __restrict__ scores,
                                                           const float* __restrict__ mx, const float* __restrict__ sm,
-                                                          float* __restrict__ cc, int L, int H, int64_t M, int D, int rpw) {
+                                                          float* __restrict__ cc, int L, int H, int64_t M, int D, int rpw,
+                                                          float* __restrict__ det_cc, float* __restrict__ det_gb) {
+    // det_cc / det_gb: deterministic mode (common.h): this WAVE's row of [B*H] partial c sums (zero-filled scratch) and this
+    // WORKGROUP's row of [2*D] dgamma | dbeta partials, folded in index order by the launcher instead of the atomics
     const int lane = threadIdx.x & 63;
     const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw;
     const int64_t rend = (r0 + rpw < M) ? r0 + rpw : M;
@@ -302,7 +305,8 @@ __global__ __launch_bounds__(256) void gate_bwd_ln_kernel(const float* __restric
         cacc += __expf(cur.sc - mxl) * isl * dacc;
         if (bn != bcur || row + 1 == rend) {   // wave-uniform: leaving this batch element (or done)
             if (lane < H) {
-                atomicAdd(cc + bcur * H + lane, cacc / (float)H);
+                if (det_cc) det_cc[(((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (M / L) + bcur) * H + lane] = cacc / (float)H;
+                else atomicAdd(cc + bcur * H + lane, cacc / (float)H);
                 cacc = 0.f;
                 if (row + 1 < rend) { mxl = mx[bn * H + lane]; isl = 1.f / sm[bn * H + lane]; }
             }
@@ -329,6 +333,11 @@ __global__ __launch_bounds__(256) void gate_bwd_ln_kernel(const float* __restric
         }
         __syncthreads();
     }
+    if (det_gb) {
+        float* row = det_gb + (int64_t)blockIdx.x * 2 * D;
+        for (int c = threadIdx.x; c < D; c += 256) { row[c] = red[0][c]; row[D + c] = red[1][c]; }
+        return;
+    }
     for (int c = threadIdx.x; c < D; c += 256) {
         atomicAdd(dgamma + c, red[0][c]);
         atomicAdd(dbeta + c, red[1][c]);
@@ -342,7 +351,7 @@ __global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const float* __rest
                                                              const float* __restrict__ mx, const float* __restrict__ sm,
                                                              const float* __restrict__ da, const float* __restrict__ cc,
                                                              float* __restrict__ dx, float* __restrict__ du, int L, int D,
-                                                             int H, int rpw) {
+                                                             int H, int rpw, float* __restrict__ det_du) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int l0 = (blockIdx.x * 4 + wave) * rpw;
@@ -448,7 +457,11 @@ __global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const float* __rest
     }
     for (int i = threadIdx.x; i < GH * NP * 256; i += 256) {
         const int hh = i / (NP * 256), c = i % (NP * 256);
-        if (hh < H && c < D) atomicAdd(du + ((int64_t)b * H + hh) * D + c, red[i]);
+        if (hh < H && c < D) {
+            // deterministic mode: the workgroup's row [H*D] of batch element b's block of the scratch (folded by the launcher)
+            if (det_du) det_du[(((int64_t)b * gridDim.x + blockIdx.x) * H + hh) * D + c] = red[i];
+            else atomicAdd(du + ((int64_t)b * H + hh) * D + c, red[i]);
+        }
     }
 }
 
@@ -617,7 +630,6 @@ __global__ __launch_bounds__(256) void gate_vec_bwd_b_multi_kernel(const float* 
 }
 
 int rows_per_wave(int64_t rows, int64_t target_waves) {
-    if (svol_deterministic()) return (int)(rows < 1 ? 1 : rows);   // one wave walks every row (one adder per reduced element)
     int64_t r = (rows + target_waves - 1) / target_waves;
     return (int)(r < 1 ? 1 : r);
 }
@@ -692,19 +704,35 @@ int svol_gate_bwd(const float* dy32, const void* dy, const void* dy2, const floa
     const int rpw3 = rows_per_wave(L, gate_waves(2) / B + 1);
     dim3 g3((unsigned)((L + 4 * rpw3 - 1) / (4 * rpw3)), (unsigned)B);
     if (hipMemsetAsync(cc, 0, sizeof(float) * (size_t)(B * H), s) != hipSuccess) return SVOL_E_LAUNCH;
+    // deterministic mode (common.h): the three atomic reductions of the two kernels go through per-wave / per-workgroup rows of a
+    // stream-ordered scratch and are folded in index order: [waves][B*H] (zero-filled: a wave visits few batch elements) |
+    // [workgroups][2*D] | [B][workgroups per batch element][H*D]
+    const bool det_mode = svol_deterministic();
+    const size_t n_cc = (size_t)g1 * 4 * (size_t)(B * H), n_gb = (size_t)g1 * 2 * (size_t)D, n_du = (size_t)B * g3.x * (size_t)(H * D);
+    DetScratch det(det_mode ? n_cc + n_gb + n_du : 0, s, true);
+    if (det_mode && !det.p) return SVOL_E_LAUNCH;
+    float* det_cc = det_mode ? det.p : nullptr;
+    float* det_gb = det_mode ? det.p + n_cc : nullptr;
+    float* det_du = det_mode ? det.p + n_cc + n_gb : nullptr;
 #define SVOL_GATE_BWD(TT)                                                                                                   \
     do {                                                                                                                    \
-        if (np_ == 1) hipLaunchKernelGGL((gate_bwd_ln_kernel<TT, 1>), dim3(g1), dim3(256), 0, s, dy32, (const TT*)dy, (const TT*)dy2, x32, a, gamma, mean, rstd, dx32, da, dgamma, dbeta, scores, mx, sm, cc, (int)L, (int)H, M, (int)D, rpw1); \
-        else if (np_ == 2) hipLaunchKernelGGL((gate_bwd_ln_kernel<TT, 2>), dim3(g1), dim3(256), 0, s, dy32, (const TT*)dy, (const TT*)dy2, x32, a, gamma, mean, rstd, dx32, da, dgamma, dbeta, scores, mx, sm, cc, (int)L, (int)H, M, (int)D, rpw1); \
-        else hipLaunchKernelGGL((gate_bwd_ln_kernel<TT, 4>), dim3(g1), dim3(256), 0, s, dy32, (const TT*)dy, (const TT*)dy2, x32, a, gamma, mean, rstd, dx32, da, dgamma, dbeta, scores, mx, sm, cc, (int)L, (int)H, M, (int)D, rpw1); \
-        if (np_ == 1) hipLaunchKernelGGL((gate_bwd_apply_kernel<TT, 1>), g3, dim3(256), 0, s, x32, (const TT*)pos, u, scores, mx, sm, da, cc, dx32, du, (int)L, (int)D, (int)H, rpw3); \
-        else if (np_ == 2) hipLaunchKernelGGL((gate_bwd_apply_kernel<TT, 2>), g3, dim3(256), 0, s, x32, (const TT*)pos, u, scores, mx, sm, da, cc, dx32, du, (int)L, (int)D, (int)H, rpw3); \
-        else hipLaunchKernelGGL((gate_bwd_apply_kernel<TT, 4>), g3, dim3(256), 0, s, x32, (const TT*)pos, u, scores, mx, sm, da, cc, dx32, du, (int)L, (int)D, (int)H, rpw3); \
+        if (np_ == 1) hipLaunchKernelGGL((gate_bwd_ln_kernel<TT, 1>), dim3(g1), dim3(256), 0, s, dy32, (const TT*)dy, (const TT*)dy2, x32, a, gamma, mean, rstd, dx32, da, dgamma, dbeta, scores, mx, sm, cc, (int)L, (int)H, M, (int)D, rpw1, det_cc, det_gb); \
+        else if (np_ == 2) hipLaunchKernelGGL((gate_bwd_ln_kernel<TT, 2>), dim3(g1), dim3(256), 0, s, dy32, (const TT*)dy, (const TT*)dy2, x32, a, gamma, mean, rstd, dx32, da, dgamma, dbeta, scores, mx, sm, cc, (int)L, (int)H, M, (int)D, rpw1, det_cc, det_gb); \
+        else hipLaunchKernelGGL((gate_bwd_ln_kernel<TT, 4>), dim3(g1), dim3(256), 0, s, dy32, (const TT*)dy, (const TT*)dy2, x32, a, gamma, mean, rstd, dx32, da, dgamma, dbeta, scores, mx, sm, cc, (int)L, (int)H, M, (int)D, rpw1, det_cc, det_gb); \
+        if (det_mode) {                                                                                                     \
+            det_fold(det_cc, (int)(g1 * 4), B * H, cc, B * H, s);                                                           \
+            det_fold(det_gb, (int)g1, 2 * D, dgamma, D, s);                                                                 \
+            det_fold(det_gb + D, (int)g1, 2 * D, dbeta, D, s);                                                              \
+        }                                                                                                                   \
+        if (np_ == 1) hipLaunchKernelGGL((gate_bwd_apply_kernel<TT, 1>), g3, dim3(256), 0, s, x32, (const TT*)pos, u, scores, mx, sm, da, cc, dx32, du, (int)L, (int)D, (int)H, rpw3, det_du); \
+        else if (np_ == 2) hipLaunchKernelGGL((gate_bwd_apply_kernel<TT, 2>), g3, dim3(256), 0, s, x32, (const TT*)pos, u, scores, mx, sm, da, cc, dx32, du, (int)L, (int)D, (int)H, rpw3, det_du); \
+        else hipLaunchKernelGGL((gate_bwd_apply_kernel<TT, 4>), g3, dim3(256), 0, s, x32, (const TT*)pos, u, scores, mx, sm, da, cc, dx32, du, (int)L, (int)D, (int)H, rpw3, det_du); \
     } while (0)
     if (dtype == SVOL_BF16) SVOL_GATE_BWD(bf16_t);
     else if (dtype == SVOL_F16) SVOL_GATE_BWD(f16_t);
     else SVOL_GATE_BWD(float);
 #undef SVOL_GATE_BWD
+    if (det_mode) det_fold(det_du, (int)g3.x, H * D, du, H * D, s, (int)B, (int64_t)g3.x * H * D, H * D);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }

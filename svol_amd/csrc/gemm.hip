@@ -328,14 +328,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(TnGroupArgsG g)
 
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* X, int64_t ldx, float* out, int M, int N, int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* X, int64_t ldx, float* out, int M, int N, int rows_per_block, float* det_part) {
     // thread t owns column blockIdx.x*256 + t; rows [blockIdx.y*rpb, ...)
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
     float s = 0.f;
     for (int m = m0; m < m1; ++m) s += to_f32(X[(int64_t)m * ldx + n]);
-    atomicAdd(out + n, s);
+    if (det_part) det_part[(int64_t)blockIdx.y * N + n] = s;   // deterministic mode: row block's partial, folded in index order (common.h)
+    else atomicAdd(out + n, s);
 }
 
 template <typename TS, typename TD>
@@ -870,17 +871,20 @@ int svol_colsum(const void* X, int64_t ldx, float* out, int64_t M, int64_t N, in
     int maxrb = 2048 / colblocks;
     if (maxrb < 1) maxrb = 1;
     if (rowblocks > maxrb) rowblocks = maxrb;
-    if (svol_deterministic()) rowblocks = 1;   // one adder per column
     const int rpb = (int)((M + rowblocks - 1) / rowblocks);
     dim3 grid(colblocks, (unsigned)((M + rpb - 1) / rpb));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool det_mode = svol_deterministic();
+    DetScratch det(det_mode ? (size_t)grid.y * (size_t)N : 0, s);
+    if (det_mode && !det.p) return SVOL_E_LAUNCH;
     if (dtype == SVOL_BF16)
-        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, ldx, out, (int)M, (int)N, rpb);
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, ldx, out, (int)M, (int)N, rpb, det.p);
     else if (dtype == SVOL_F16)
-        hipLaunchKernelGGL(colsum_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)X, ldx, out, (int)M, (int)N, rpb);
+        hipLaunchKernelGGL(colsum_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)X, ldx, out, (int)M, (int)N, rpb, det.p);
     else if (dtype == SVOL_F32)
-        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)X, ldx, out, (int)M, (int)N, rpb);
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)X, ldx, out, (int)M, (int)N, rpb, det.p);
     else return SVOL_E_INVALID;
+    if (det_mode) det_fold(det.p, (int)grid.y, N, out, N, s);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ rstd, float* __restrict__ dx32,
                                                      T* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, float* __restrict__ dxsum, int64_t M, int D,
-                                                     float p, float inv_keep, uint64_t seed0, const int64_t* __restrict__ soff, int rows_per_wave) {
+                                                     float p, float inv_keep, uint64_t seed0, const int64_t* __restrict__ soff, int rows_per_wave,
+                                                     float* __restrict__ det_part) {
     const uint64_t seed = seed0 + (soff ? ((uint64_t)soff[0] << 8) : 0ull);
     const int lane = threadIdx.x & 63;
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -185,6 +186,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             }
         }
         __syncthreads();
+    }
+    if (det_part) {   // deterministic mode: this workgroup's row of the scratch, folded in index order by det_fold
+        float* row = det_part + (int64_t)blockIdx.x * 3 * D;
+        for (int c = threadIdx.x; c < D; c += 256) { row[c] = red[0][c]; row[D + c] = red[1][c]; row[2 * D + c] = red[2][c]; }
+        return;
     }
     for (int c = threadIdx.x; c < D; c += 256) {
         atomicAdd(dgamma + c, red[0][c]);
@@ -327,17 +333,19 @@ int svol_layernorm_bwd(const float* dy32, const void* dy, const void* dy2, const
     // ~2048 waves (512 workgroups); each wave walks `rpw` consecutive rows; one set of atomics per workgroup
     int64_t rpw = (M + 2047) / 2048;
     if (rpw < 1) rpw = 1;
-    if (svol_deterministic()) rpw = M;   // one wave walks every row: one adder per column sum
     const int64_t waves = (M + rpw - 1) / rpw;
     const unsigned grid = (unsigned)((waves + 3) / 4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool det_mode = svol_deterministic();
+    DetScratch det(det_mode ? (size_t)grid * 3 * (size_t)D : 0, s);   // deterministic mode: per-workgroup rows, folded below
+    if (det_mode && !det.p) return SVOL_E_LAUNCH;
     // NP = passes of 256 columns per row: the accumulator / operand arrays are sized by it (NP = 1 at d = 256: 76 VGPRs
     // instead of the 166 of the 4-pass instantiation; 46 us instead of 50 at [50176, 256] = 5.0 TB/s.  More waves or a next-row
     // prefetch do not help further: the end-of-workgroup atomics, then HBM, bound it)
 #define SVOL_LNB(TT, TXX, NPP)                                                                                                      \
     hipLaunchKernelGGL((ln_bwd_kernel<TT, TXX, NPP>), dim3(grid), dim3(256), 0, s, dy32, (const TT*)dy, (const TT*)dy2, (const TXX*)x, \
                        gamma, mean, rstd, dx32, (TT*)dx, dgamma, dbeta, dx_colsum, M, (int)D, dropout_p, inv_keep, seed,              \
-                       seed_offset_dev, (int)rpw)
+                       seed_offset_dev, (int)rpw, det.p)
 #define SVOL_LNB_NP(TT, TXX)                  \
     do {                                      \
         if (D <= 256) SVOL_LNB(TT, TXX, 1);   \
@@ -351,6 +359,11 @@ int svol_layernorm_bwd(const float* dy32, const void* dy, const void* dy2, const
     else SVOL_LNB_NP(float, float);
 #undef SVOL_LNB_NP
 #undef SVOL_LNB
+    if (det_mode) {
+        det_fold(det.p, (int)grid, 3 * D, dgamma, D, s);
+        det_fold(det.p + D, (int)grid, 3 * D, dbeta, D, s);
+        det_fold(det.p + 2 * D, (int)grid, 3 * D, dx_colsum, D, s);
+    }
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }

@@ -219,3 +219,104 @@ def test_mlp_chain_stays_inside_its_buffers(dtype):
         ar.check(f'svol_mlp_chain M={M}')
         for k_ in ('hid', 'dpre', 'Y', 'dT', 'dX'):
             assert bool(torch.isfinite(t[k_].float()).all()), k_
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_gemm_families_stay_inside_their_outputs(dtype):
+    """svol_gemm_nt / svol_gemm_nt_dact through every 16-bit kernel family the step uses — weight-stationary K = 256 (bf16 and fp32 +
+    residual outputs, the gelu' copy), the deep-K N = 256 kernel, the 800-row skinny kernels, the fused (dY W2) * aux with its column
+    sums — at row counts that are NOT multiples of the 16 / 128-row tiles, with outputs that are column slices of a wider buffer (the
+    q | k | v layout): rows past M and columns past the slice must stay untouched."""
+    from svol_amd import _lib, ops
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(31)
+    P = ops._ptr
+    D, F = 256, 2048
+    for M in (50176 // 8 + 5, 4133, 800):
+        x = (torch.randn((M, D), generator=g) * 0.5).to(dtype).cuda()
+        hid = (torch.randn((M, F), generator=g) * 0.5).to(dtype).cuda()
+        res = torch.randn((M, D), generator=g).cuda()
+        W_qk = (torch.randn((2 * D, D), generator=g) * 0.05).to(dtype).cuda()
+        W_dd = (torch.randn((D, D), generator=g) * 0.05).to(dtype).cuda()
+        W_fd = (torch.randn((F, D), generator=g) * 0.05).to(dtype).cuda()
+        W_df = (torch.randn((D, F), generator=g) * 0.05).to(dtype).cuda()
+        b = (torch.randn((F,), generator=g) * 0.1).cuda()
+        ar = GuardArena()
+        ar.plan('qkv', (M, 3 * D), dtype)        # q | k written as a 512-column slice, v as the last 256 columns
+        ar.plan('o32', (M, D), torch.float32)
+        ar.plan('hid', (M, F), dtype)
+        ar.plan('pre', (M, F), dtype)
+        ar.plan('y32', (M, D), torch.float32)
+        ar.plan('dx', (M, D), dtype)
+        ar.plan('dpre', (M, F), dtype)
+        ar.plan('cs', (F,), torch.float32)
+        t = ar.build()
+        t['cs'].zero_()
+        qkv = t['qkv']
+        dt, s = ops._dt(x), ops._stream()
+        calls = [
+            ('q|k', lambda: lib.svol_gemm_nt(P(x), D, None, 0, P(W_qk), D, P(qkv), 3 * D, P(b), None, 0, None, 0, None, 0, 0, M, 2 * D, D, dt, s)),
+            ('v', lambda: lib.svol_gemm_nt(P(x), D, None, 0, P(W_dd), D, P(qkv[:, 2 * D:]), 3 * D, P(b), None, 0, None, 0, None, 0, 0, M, D, D, dt, s)),
+            ('out-proj + residual (fp32)', lambda: lib.svol_gemm_nt(P(x), D, None, 0, P(W_dd), D, P(t['o32']), D, P(b), None, 0, None, 0, P(res), D, 1, M, D, D, dt, s)),
+            ("fc1 + gelu'", lambda: lib.svol_gemm_nt(P(x), D, None, 0, P(W_fd), D, P(t['hid']), F, P(b), None, ops.ACT_GELU_D, P(t['pre']), F, None, 0, 0, M, F, D, dt, s)),
+            ('fc2 + residual (fp32)', lambda: lib.svol_gemm_nt(P(hid), F, None, 0, P(W_df), F, P(t['y32']), D, P(b), None, 0, None, 0, P(res), D, 1, M, D, F, dt, s)),
+            ('dX of the MLP', lambda: lib.svol_gemm_nt(P(hid), F, None, 0, P(W_df), F, P(t['dx']), D, None, None, 0, None, 0, None, 0, 0, M, D, F, dt, s)),
+            ("(dY W2) * gelu' + column sums", lambda: lib.svol_gemm_nt_dact(P(x), D, P(W_fd), D, P(t['dpre']), F, P(hid), F, ops.ACT_GELU_D, P(t['cs']), M, F, D, dt, s)),
+        ]
+        for name, fn in calls:
+            _lib.check(fn(), name)
+        torch.cuda.synchronize()
+        ar.check(f'GEMM families, M = {M}')
+        for k_ in ('qkv', 'o32', 'hid', 'pre', 'y32', 'dx', 'dpre', 'cs'):
+            assert bool(torch.isfinite(t[k_].float()).all()), k_
+        ref = x.double() @ W_dd.double().t() + b[:D].double() + res.double()
+        assert float((t['o32'].double() - ref).abs().max()) < 0.05
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_layernorm_and_gate_stay_inside_their_buffers(dtype):
+    """svol_layernorm_fwd / _bwd and svol_gate_fwd / _bwd: per-wave row loops with computed row offsets, end-of-workgroup atomics into
+    [D]-sized gradient sinks; row counts that do not divide by the rows-per-wave split."""
+    from svol_amd import _lib, ops
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(37)
+    P = ops._ptr
+    D, H = 256, 8
+    for B, L in ((2, 3001), (8, 100)):
+        M = B * L
+        x32 = torch.randn((M, D), generator=g).cuda()
+        pos = torch.randn((M, D), generator=g).to(dtype).cuda()
+        gamma = (1.0 + 0.1 * torch.randn((D,), generator=g)).cuda()
+        beta = (0.1 * torch.randn((D,), generator=g)).cuda()
+        u = (torch.randn((B, H, D), generator=g) * 0.1).cuda()
+        dy32 = torch.randn((M, D), generator=g).cuda()
+        dy = torch.randn((M, D), generator=g).to(dtype).cuda()
+        ar = GuardArena()
+        for nm in ('y32', 'dx32', 'gy32', 'gdx32'):
+            ar.plan(nm, (M, D), torch.float32)
+        for nm in ('y', 'ypos', 'dx', 'gy', 'gypos'):
+            ar.plan(nm, (M, D), dtype)
+        for nm in ('mean', 'rstd', 'gmean', 'grstd'):
+            ar.plan(nm, (M,), torch.float32)
+        for nm in ('dgamma', 'dbeta', 'colsum', 'gdgamma', 'gdbeta'):
+            ar.plan(nm, (D,), torch.float32)
+        ar.plan('a', (B * L,), torch.float32)
+        ar.plan('gws', (B * H * (L + 2),), torch.float32)      # exactly what include/svol_hip.h asks for
+        ar.plan('gws2', (B * L + B * H,), torch.float32)
+        ar.plan('du', (B, H, D), torch.float32)
+        t = ar.build()
+        for nm in ('dgamma', 'dbeta', 'colsum', 'gdgamma', 'gdbeta', 'du'):
+            t[nm].zero_()
+        dt, s = ops._dt(pos), ops._stream()
+        _lib.check(lib.svol_layernorm_fwd(P(x32), 1, P(gamma), P(beta), P(t['y32']), P(t['y']), P(t['ypos']), P(pos), M, P(t['mean']), P(t['rstd']),
+                                          M, D, 0.0, 0, None, dt, s), 'svol_layernorm_fwd')
+        _lib.check(lib.svol_layernorm_bwd(P(dy32), P(dy), None, P(x32), 1, P(gamma), P(t['mean']), P(t['rstd']), P(t['dx32']), P(t['dx']),
+                                          P(t['dgamma']), P(t['dbeta']), P(t['colsum']), M, D, 0.0, 0, None, dt, s), 'svol_layernorm_bwd')
+        _lib.check(lib.svol_gate_fwd(P(x32), P(pos), P(u), P(gamma), P(beta), P(t['gy32']), P(t['gy']), P(t['gypos']), P(t['a']), P(t['gmean']),
+                                     P(t['grstd']), P(t['gws']), B, L, D, H, dt, s), 'svol_gate_fwd')
+        _lib.check(lib.svol_gate_bwd(P(dy32), P(dy), None, P(x32), P(pos), P(u), P(gamma), P(t['a']), P(t['gmean']), P(t['grstd']), P(t['gws']),
+                                     P(t['gws2']), P(t['gdx32']), P(t['du']), P(t['gdgamma']), P(t['gdbeta']), B, L, D, H, dt, s), 'svol_gate_bwd')
+        torch.cuda.synchronize()
+        ar.check(f'LayerNorm / gate, B = {B}, L = {L}')
+        for k_ in ('y32', 'y', 'ypos', 'mean', 'rstd', 'dx32', 'dx', 'dgamma', 'dbeta', 'colsum', 'gy32', 'gy', 'gypos', 'gdx32', 'du', 'gdgamma', 'gdbeta'):
+            assert bool(torch.isfinite(t[k_].float()).all()), k_

@@ -213,3 +213,43 @@ def test_hand_placed_forward_at_small_tile_counts(L, dtype):
     tol = 1.2e-2 if dtype == torch.bfloat16 else 2e-3
     assert float((o.double().cpu() - ref_o).abs().max()) <= tol
     assert float((lse2.double().cpu() - ref_lse2).abs().max()) <= 2e-5 * max(1.0, float(ref_lse2.abs().max()))
+
+
+def test_reductions_keep_their_parity_in_deterministic_mode():
+    """SVOL_DETERMINISTIC=1 re-routes every atomic reduction (LayerNorm / gate parameter gradients, the gate's du and softmax
+    constants, column sums, the weight-gradient GEMMs' contraction split) through per-workgroup partial rows folded in index order
+    (csrc/common.h::det_fold).  The same fp64 parity checks as the default mode, in a child process (the switch is read once), and the
+    gradients of two calls must be bit-identical."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import torch
+from tests import gpu_checks as G
+bad = {}
+for fn in (G.check_layernorm, G.check_gate, G.check_gemm_gelu_d, G.check_gemm_tn, G.check_gemm_tn_grouped, G.check_small_ops):
+    for k, (e, t) in fn().items():
+        if not e <= t:
+            bad[k] = (e, t)
+print('BAD', bad)
+from svol_amd import ops
+g = torch.Generator().manual_seed(5)
+M, D = 8 * 3001, 256
+x = torch.randn((M, D), generator=g).cuda()
+dy = torch.randn((M, D), generator=g).cuda()
+gamma = torch.ones(D).cuda()
+y32, y, _, mean, rstd = ops.layernorm_fwd(x, gamma, torch.zeros(D).cuda(), torch.bfloat16, None, want32=True)
+outs = []
+for rep in range(3):
+    r = ops.layernorm_bwd(dy, None, None, x, gamma, mean, rstd, torch.bfloat16, want32=True, want_colsum=True)
+    torch.cuda.synchronize()
+    outs.append([t.clone() for t in r if torch.is_tensor(t)])
+same = all(torch.equal(a, b) for o in outs[1:] for a, b in zip(outs[0], o))
+print('LN', 'identical' if same else 'DIFFERENT', len(outs[0]))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SVOL_DETERMINISTIC='1', PYTHONPATH=root)
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'BAD {}' in r.stdout, r.stdout[-3000:]
+    assert 'LN identical' in r.stdout, r.stdout[-2000:]

@@ -237,8 +237,8 @@ def test_bare_transformer_sees_in_place_weight_updates(opt_kind):
 def test_training_steps_are_bit_reproducible_in_deterministic_mode():
     """SURVEY §5 asks for a deterministic-reduction mode; VERDICT r4 ("What's missing 4") for a switch and a test that two training
     steps are bit-identical.  SVOL_DETERMINISTIC=1 gives every floating-point reduction of the step ONE adder per output element
-    (csrc/common.h::svol_deterministic: atomic-free attention backward, unsplit weight-gradient GEMMs, single-wave LayerNorm / gate /
-    column-sum reductions).  Two fresh runs of three optimisation steps — the bench model's width (d = 256, 8 heads, so the MFMA-path
+    (csrc/common.h::svol_deterministic: atomic-free attention backward, unsplit weight-gradient GEMMs, LayerNorm / gate / column-sum
+    partials folded in index order).  Two fresh runs of three optimisation steps — the bench model's width (d = 256, 8 heads, so the MFMA-path
     kernels run) at L = 1536 with the single-pass shapes in reach — must leave bit-identical parameters and losses; the same two runs
     WITHOUT the switch are allowed to differ and are only reported.  The library reads the variable once: child processes."""
     import os
