@@ -376,6 +376,32 @@ int svol_maxpool_nhwc(const void* x, void* y, int64_t N, int64_t H, int64_t W, i
                       int64_t pad, int dtype, void* stream);
 /* nn.AdaptiveAvgPool2d(1) on NHWC activations: y[n, c] (fp32) = mean over the HW positions. */
 int svol_avgpool_nhwc(const void* x, float* y, int64_t N, int64_t HW, int64_t C, int dtype, void* stream);
+/* ---- the backbone in TRAINING mode (the reference optimises every parameter of build_model(args), train.py:72; its backbone is
+ * torchvision's ResNet-34 / ResNet-18 with train-mode BatchNorm, backbone.py:133-152).  Activations NHWC [M = n*h*w, C], 16-bit; C a
+ * multiple of 8 (the column reductions: C / 8 a divisor of 256).  The convolutions stay GEMMs: forward svol_conv_nhwc / svol_im2col +
+ * svol_gemm_nt without bias; weight gradient svol_gemm_tn(dz, svol_im2col(x)); data gradient svol_gemm_nt(dz, W^T) -> svol_col2im_nhwc.
+ *   svol_bn_colstats    sum[c] += sum_m (z[m,c] - shift[c]), sumsq[c] += sum_m (z[m,c] - shift[c])^2   (shift may be NULL; caller zeroes)
+ *   svol_bn_apply       y = z * scale[c] + shift[c] (+ residual) (relu != 0: max(., 0))  — nn.BatchNorm2d in train mode with
+ *                       scale = gamma * rstd, shift = beta - mean * scale from the BATCH statistics
+ *   svol_bn_bwd_reduce  g = dy * [y > 0] (y NULL: g = dy); sum_g[c] += sum g, sum_gx[c] += sum g * (z - mean[c]) * rstd[c]  (caller zeroes)
+ *                       = the gradients of beta and gamma
+ *   svol_bn_bwd_apply   dz = gamma * rstd * (g - sum_g / M - xhat * sum_gx / M); dres (may be NULL) = g (the identity branch's gradient)
+ *   svol_col2im_nhwc    dx[n,iy,ix,c] = sum of dcols[(n,oy,ox), (ky,kx,c)] over the windows that hold (iy,ix): the transpose of svol_im2col
+ *   svol_maxpool_idx_nhwc / svol_maxpool_bwd_nhwc   nn.MaxPool2d with the window position (ky*k + kx, one byte per output element) of the
+ *                       first maximum of the (ky, kx) scan, and the backward that routes dy to it */
+int svol_bn_colstats(const void* z, const float* shift, float* sum, float* sumsq, int64_t M, int64_t C, int dtype, void* stream);
+int svol_bn_apply(const void* z, const float* scale, const float* shift, const void* residual, int relu, void* y, int64_t M, int64_t C,
+                  int dtype, void* stream);
+int svol_bn_bwd_reduce(const void* dy, const void* y, const void* z, const float* mean, const float* rstd, float* sum_g, float* sum_gx,
+                       int64_t M, int64_t C, int dtype, void* stream);
+int svol_bn_bwd_apply(const void* dy, const void* y, const void* z, const float* mean, const float* rstd, const float* gamma,
+                      const float* sum_g, const float* sum_gx, void* dz, void* dres, int64_t M, int64_t C, int dtype, void* stream);
+int svol_col2im_nhwc(const void* dcols, int64_t ldcols, void* dx, int64_t N, int64_t H, int64_t W, int64_t C, int64_t kh, int64_t kw,
+                     int64_t stride, int64_t pad, int dtype, void* stream);
+int svol_maxpool_idx_nhwc(const void* x, void* y, uint8_t* idx, int64_t N, int64_t H, int64_t W, int64_t C, int64_t k, int64_t stride,
+                          int64_t pad, int dtype, void* stream);
+int svol_maxpool_bwd_nhwc(const void* dy, const uint8_t* idx, void* dx, int64_t N, int64_t H, int64_t W, int64_t C, int64_t k,
+                          int64_t stride, int64_t pad, int dtype, void* stream);
 /* att[B,Lq,Lk] (fp32) = 1/H * sum_h softmax_l(q_h k_h^T * scale + kbias): the head-averaged attention weights that
  * nn.MultiheadAttention returns with need_weights=True and the reference's TransformerDecoder stacks per layer
  * (transformer.py:139-152, 258-262).  Recomputed from q, k (layouts as svol_attn_fwd, q_premul as there) and the

@@ -37,6 +37,41 @@ def resnet_features(sd, depths, pixel_values, avgpool=False):
     return F.adaptive_avg_pool2d(x, 1) if avgpool else x
 
 
+# ---- TRAINING mode (the reference's train.py:72 optimises every parameter of build_model(args); model.train() puts torchvision's
+# BatchNorm2d into batch-statistics mode, backbone.py:133-152).  Same network, F.batch_norm(training=True) on CLONES of the running
+# statistics (returned updated), gradients by torch autograd; pinned against transformers.ResNetModel.train() by
+# tests/golden/make_golden_resnet.py (the *_train fixtures).
+def _bn_train(x, sd, p, stats, eps=1e-5, momentum=0.1):
+    rm, rv = sd[p + '.running_mean'].clone(), sd[p + '.running_var'].clone()
+    y = F.batch_norm(x, rm, rv, sd[p + '.weight'], sd[p + '.bias'], True, momentum, eps)
+    stats[p + '.running_mean'], stats[p + '.running_var'] = rm, rv
+    return y
+
+
+def resnet_features_train(sd, depths, pixel_values, avgpool=False):
+    """-> (feature map [n,C,h,w] or pooled [n,C,1,1], {key: updated running statistic}); differentiable w.r.t. the tensors of sd."""
+    stats = {}
+    x = F.relu(_bn_train(F.conv2d(pixel_values, sd['0.weight'], None, 2, 3), sd, '1', stats))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li, n in enumerate(depths):
+        for bi in range(n):
+            p, stride = f'{4 + li}.{bi}', (1 if li == 0 else 2) if bi == 0 else 1
+            out = F.relu(_bn_train(F.conv2d(x, sd[p + '.conv1.weight'], None, stride, 1), sd, p + '.bn1', stats))
+            out = _bn_train(F.conv2d(out, sd[p + '.conv2.weight'], None, 1, 1), sd, p + '.bn2', stats)
+            if (p + '.downsample.0.weight') in sd:
+                x = _bn_train(F.conv2d(x, sd[p + '.downsample.0.weight'], None, stride, 0), sd, p + '.downsample.1', stats)
+            x = F.relu(out + x)
+    return (F.adaptive_avg_pool2d(x, 1) if avgpool else x), stats
+
+
+def resnet_train_grads(sd, depths, pixel_values, probe, avgpool=False, dtype=torch.float64):
+    """loss = sum(features * probe) in `dtype`: -> (features, {parameter key: gradient}, updated running statistics)."""
+    sdd = {k: (v.to(dtype).requires_grad_(v.is_floating_point() and 'running' not in k) if v.is_floating_point() else v) for k, v in sd.items()}
+    f, stats = resnet_features_train(sdd, depths, pixel_values.to(dtype), avgpool)
+    (f * probe.to(dtype)).sum().backward()
+    return f.detach(), {k: v.grad for k, v in sdd.items() if torch.is_tensor(v) and v.requires_grad}, stats
+
+
 def resnet_backbone_forward(sd_video, depths_video, sd_sketch, depths_sketch, sketch_batch, video_batch):
     """ResNetBackbone.forward, backbone.py:72-89 -> (src_sketch [N,1,C], src_video [N,T*h*w,C])."""
     src_sketch = resnet_features(sd_sketch, depths_sketch, sketch_batch.squeeze(1), avgpool=True).squeeze(-1).squeeze(-1).unsqueeze(1)

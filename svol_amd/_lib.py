@@ -51,6 +51,13 @@ SIGNATURES = {
     'svol_im2col': [_p, _i64, _i64, _i64, _i64, _int, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p],
     'svol_maxpool_nhwc': [_p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p],
     'svol_avgpool_nhwc': [_p, _p, _i64, _i64, _i64, _int, _p],
+    'svol_bn_colstats': [_p, _p, _p, _p, _i64, _i64, _int, _p],
+    'svol_bn_apply': [_p, _p, _p, _p, _int, _p, _i64, _i64, _int, _p],
+    'svol_bn_bwd_reduce': [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _int, _p],
+    'svol_bn_bwd_apply': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _int, _p],
+    'svol_col2im_nhwc': [_p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p],
+    'svol_maxpool_idx_nhwc': [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p],
+    'svol_maxpool_bwd_nhwc': [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p],
     'svol_attn_weights_mean': [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _int, _p],
     'svol_attn_small_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _f32, _int, _p],
     'svol_posenc_sine': [_p, _p, _i64, _i64, _i64, _int, _p],

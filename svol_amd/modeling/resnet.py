@@ -12,8 +12,18 @@ layer1-4 — so the ``backbone.{video,sketch}_backbone.*`` keys of a reference c
   convolution the ReLU AFTER the identity add (SVOL_ACT_RELU_RES) — in the GEMM epilogue; 3x3 s2 max pooling and the sketch
   branch's global average pooling are their own kernels; activations are NHWC from the stem to the tokens.
 
-Inference / frozen only (BatchNorm uses its running statistics, no backward): the pretrained torchvision weights cannot be
-downloaded here and a trainable backbone needs batch-statistics BatchNorm and convolution gradients, neither of which is built.
+Two modes.  Frozen / eval (the default; BatchNorm uses its running statistics, folded into the weights as above, no backward).
+``trainable=True`` and ``.train()``: what the reference's training step runs (train.py:72 puts EVERY parameter of build_model(args)
+into the optimiser, and ``model.train()`` puts torchvision's BatchNorm into batch-statistics mode): every conv -> BatchNorm (-> +identity)
+(-> ReLU) unit is one autograd Function (``_ConvBnFn``) over csrc/resnet_train.hip —
+
+  forward   z = conv(x) (svol_conv_nhwc / im2col + GEMM, no bias) ; batch mean / biased variance per channel (two column passes) ;
+            y = relu?(z * gamma * rstd + (beta - mean * gamma * rstd) + identity) ; running statistics updated with the UNBIASED variance
+  backward  g = dy * [y > 0] ; dbeta = sum g, dgamma = sum g * xhat ; dz = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)) ; d identity = g ;
+            dW = dz^T im2col(x) (svol_gemm_tn) ; dx = col2im(dz W) (svol_gemm_nt + svol_col2im_nhwc)
+
+— plus max pooling with its argmax and the sketch branch's average pooling as Functions.  Activations bf16 / fp16 NHWC, statistics,
+parameters and parameter gradients fp32.
 """
 from __future__ import annotations
 
@@ -54,8 +64,122 @@ def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d, dtype):
     return w.to(dtype).contiguous(), shift.contiguous()
 
 
+def _w16(weight, dtype):
+    """[Cout, Cin, kh, kw] fp32 -> [Cout, Kp] compute dtype, (ky, kx, c) order, K padded to a multiple of 32 (the GEMMs' layout)."""
+    w = weight.detach().permute(0, 2, 3, 1).reshape(weight.shape[0], -1)
+    K = w.shape[1]
+    Kp = (K + 31) // 32 * 32
+    if Kp != K:
+        w = torch.cat([w, torch.zeros((w.shape[0], Kp - K), dtype=w.dtype, device=w.device)], dim=1)
+    return w.to(dtype).contiguous()
+
+
+def _bn_forward(z, bn, gamma, beta, residual, relu):
+    """train-mode BatchNorm of the conv output z [M, C] (+ identity) (+ ReLU); updates bn's running statistics as nn.BatchNorm2d does."""
+    M = z.shape[0]
+    mean, var, rstd = ops.bn_batch_stats(z, bn.eps)
+    with torch.no_grad():
+        if bn.track_running_stats and bn.running_mean is not None:
+            bn.num_batches_tracked += 1
+            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
+            bn.running_var.mul_(1.0 - m).add_(var * (M / max(M - 1, 1)), alpha=m)
+    scale = gamma.detach().float() * rstd
+    shift = beta.detach().float() - mean * scale
+    return ops.bn_apply(z, scale.contiguous(), shift.contiguous(), residual, relu), mean, rstd
+
+
+class _ConvBnFn(torch.autograd.Function):
+    """y [n*ho*wo, Cout] = relu?(BatchNorm_train(conv(x)) + identity) on NHWC activations; see the module docstring."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, identity, geom, relu, bn, dt):
+        n, H, W, C, kh, kw, stride, pad = geom
+        w16 = _w16(weight, dt)
+        z, Ho, Wo = ops.conv_nhwc(x, w16, None, ops.ACT_NONE, n, H, W, C, kh, kw, stride, pad)
+        y, mean, rstd = _bn_forward(z, bn, gamma, beta, identity, relu)
+        ctx.geom, ctx.relu, ctx.has_id, ctx.wshape = geom, relu, identity is not None, tuple(weight.shape)
+        ctx.save_for_backward(x, w16, z, y if relu else None, mean, rstd, gamma.detach().float().contiguous())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w16, z, y, mean, rstd, gamma = ctx.saved_tensors
+        n, H, W, C, kh, kw, stride, pad = ctx.geom
+        dy = dy.contiguous()
+        dz, did, dgamma, dbeta = ops.bn_bwd(dy, y, z, mean, rstd, gamma, ctx.has_id and ctx.needs_input_grad[4])
+        Cout, Cin = ctx.wshape[0], ctx.wshape[1]
+        K, Kp = kh * kw * Cin, w16.shape[1]
+        dW = None
+        if ctx.needs_input_grad[1]:
+            cols, _, _ = ops.im2col(x, n, H, W, C, kh, kw, stride, pad, x.dtype, ldcols=Kp)
+            dW = ops.gemm_tn(dz, cols)[:, :K].reshape(Cout, kh, kw, Cin).permute(0, 3, 1, 2).contiguous()
+            del cols
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dcols = ops.gemm_nt(dz, w16.t().contiguous())
+            dx = ops.col2im_nhwc(dcols, n, H, W, C, kh, kw, stride, pad)
+        return dx, dW, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, did, None, None, None, None
+
+
+class _StemFn(torch.autograd.Function):
+    """pixels [n,3,H,W] fp32 -> relu(BatchNorm_train(conv7x7 s2 p3)) as NHWC [n*ho*wo, C]; no gradient for the pixels."""
+
+    @staticmethod
+    def forward(ctx, pix, weight, gamma, beta, bn, dt):
+        n, c, H, W = pix.shape
+        w16 = _w16(weight, dt)
+        kh, kw = weight.shape[2], weight.shape[3]
+        cols, Ho, Wo = ops.im2col(pix, n, H, W, c, kh, kw, 2, 3, dt, strides=(c * H * W, W, 1, H * W), ldcols=w16.shape[1])
+        z = ops.gemm_nt(cols, w16)
+        del cols
+        y, mean, rstd = _bn_forward(z, bn, gamma, beta, None, True)
+        ctx.wshape, ctx.dt = tuple(weight.shape), dt
+        ctx.save_for_backward(pix, z, y, mean, rstd, gamma.detach().float().contiguous())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        pix, z, y, mean, rstd, gamma = ctx.saved_tensors
+        n, c, H, W = pix.shape
+        Cout, Cin, kh, kw = ctx.wshape
+        dz, _, dgamma, dbeta = ops.bn_bwd(dy.contiguous(), y, z, mean, rstd, gamma, False)
+        K = kh * kw * Cin
+        Kp = (K + 31) // 32 * 32
+        cols, _, _ = ops.im2col(pix, n, H, W, c, kh, kw, 2, 3, ctx.dt, strides=(c * H * W, W, 1, H * W), ldcols=Kp)   # (recomputed: 1 GB at 256 frames)
+        dW = ops.gemm_tn(dz, cols)[:, :K].reshape(Cout, kh, kw, Cin).permute(0, 3, 1, 2).contiguous()
+        return None, dW, dgamma, dbeta, None, None
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, geom):
+        n, H, W, C, k, stride, pad = geom
+        y, idx, Ho, Wo = ops.maxpool_idx_nhwc(x, n, H, W, C, k, stride, pad)
+        ctx.geom = geom
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, H, W, C, k, stride, pad = ctx.geom
+        return ops.maxpool_bwd_nhwc(dy.contiguous(), ctx.saved_tensors[0], n, H, W, C, k, stride, pad), None
+
+
+class _AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n, HW, C):
+        ctx.shape, ctx.dt = (n, HW, C), x.dtype
+        return ops.avgpool_nhwc(x, n, HW, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, HW, C = ctx.shape
+        return (dy.float() / HW).to(ctx.dt).view(n, 1, C).expand(n, HW, C).reshape(n * HW, C).contiguous(), None, None, None
+
+
 class ResNetExtractor(nn.Module):
-    def __init__(self, depths=(2, 2, 2, 2), widths=(64, 128, 256, 512), stem=64, avgpool=False, compute_dtype='bf16'):
+    def __init__(self, depths=(2, 2, 2, 2), widths=(64, 128, 256, 512), stem=64, avgpool=False, compute_dtype='bf16', trainable=False):
         super().__init__()
         self.add_module('0', nn.Conv2d(3, stem, 7, 2, 3, bias=False))
         self.add_module('1', nn.BatchNorm2d(stem))
@@ -72,8 +196,9 @@ class ResNetExtractor(nn.Module):
         self.compute_dtype = _DTYPES[compute_dtype]
         self._folded = None
         self.register_load_state_dict_post_hook(lambda m, _k: setattr(m, '_folded', None))
+        self.trainable = bool(trainable)
         for p in self.parameters():
-            p.requires_grad_(False)
+            p.requires_grad_(self.trainable)
 
     def _apply(self, fn, *a, **kw):  # .to() / .cuda() move the parameters: fold again on the new device
         self._folded = None
@@ -90,14 +215,48 @@ class ResNetExtractor(nn.Module):
         self._folded = f
         return f
 
-    @torch.no_grad()
     def forward(self, pixel_values):
         """pixel_values [n,3,H,W] fp32 (normalised as for torchvision's ImageNet weights) -> tokens [n, h*w, C] in the compute
         dtype (row-major over (h, w): the order backbone.py:85-87 flattens to), or [n, C] fp32 with ``avgpool``."""
         if not pixel_values.is_cuda:
             raise RuntimeError('svol_amd ResNetExtractor runs on the MI355X HIP kernels only (no CPU path)')
+        if self.training and self.trainable:
+            return self._forward_train(pixel_values)
         if self.training and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError('the ResNet extractor is inference / frozen only (no BatchNorm batch statistics, no backward)')
+            raise NotImplementedError('parameters that require gradients need ResNetExtractor(trainable=True): the frozen path folds '
+                                      'the running statistics into the weights and has no backward')
+        with torch.no_grad():
+            return self._forward_frozen(pixel_values)
+
+    def _forward_train(self, pixel_values):
+        """batch-statistics BatchNorm, autograd through every unit (module docstring); folded weights are invalidated."""
+        dt = self.compute_dtype
+        if dt != torch.bfloat16:
+            raise NotImplementedError('the training path of the ResNet extractor keeps its activations in bf16 (compute_dtype="bf16")')
+        self._folded = None
+        x = pixel_values.float().contiguous()
+        n, c, H, W = x.shape
+        conv0, bn0 = getattr(self, '0'), getattr(self, '1')
+        y = _StemFn.apply(x, conv0.weight, bn0.weight, bn0.bias, bn0, dt)
+        H, W, C = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1, conv0.out_channels
+        y = _MaxPoolFn.apply(y, (n, H, W, C, 3, 2, 1))
+        H, W = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        for li in range(self.n_layers):
+            for blk in getattr(self, str(4 + li)):
+                s_, planes = blk.stride, blk.conv1.out_channels
+                Ho, Wo = (H + 2 - 3) // s_ + 1, (W + 2 - 3) // s_ + 1
+                t = _ConvBnFn.apply(y, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, None, (n, H, W, C, 3, 3, s_, 1), True, blk.bn1, dt)
+                idt = y
+                if blk.downsample is not None:
+                    idt = _ConvBnFn.apply(y, blk.downsample[0].weight, blk.downsample[1].weight, blk.downsample[1].bias, None,
+                                          (n, H, W, C, 1, 1, s_, 0), False, blk.downsample[1], dt)
+                y = _ConvBnFn.apply(t, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias, idt, (n, Ho, Wo, planes, 3, 3, 1, 1), True, blk.bn2, dt)
+                H, W, C = Ho, Wo, planes
+        if self.avgpool:
+            return _AvgPoolFn.apply(y, n, H * W, C)
+        return y.view(n, H * W, C)
+
+    def _forward_frozen(self, pixel_values):
         dt = self.compute_dtype
         f = self._folded or self.refold()
         x = pixel_values.float().contiguous()
@@ -118,12 +277,12 @@ class ResNetExtractor(nn.Module):
         return y.view(n, H * W, C)
 
 
-def resnet18(avgpool=False, compute_dtype='bf16'):
-    return ResNetExtractor((2, 2, 2, 2), avgpool=avgpool, compute_dtype=compute_dtype)
+def resnet18(avgpool=False, compute_dtype='bf16', trainable=False):
+    return ResNetExtractor((2, 2, 2, 2), avgpool=avgpool, compute_dtype=compute_dtype, trainable=trainable)
 
 
-def resnet34(avgpool=False, compute_dtype='bf16'):
-    return ResNetExtractor((3, 4, 6, 3), avgpool=avgpool, compute_dtype=compute_dtype)
+def resnet34(avgpool=False, compute_dtype='bf16', trainable=False):
+    return ResNetExtractor((3, 4, 6, 3), avgpool=avgpool, compute_dtype=compute_dtype, trainable=trainable)
 
 
 class ResNetBackbone(nn.Module):

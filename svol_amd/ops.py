@@ -559,6 +559,65 @@ def avgpool_nhwc(x, N, HW, C):
     return y
 
 
+# ---- the backbone in training mode (csrc/resnet_train.hip) --------------------------------------------------------------
+def bn_batch_stats(z, eps):
+    """train-mode nn.BatchNorm2d statistics of an NHWC activation z [M, C] (16-bit): (mean, biased var, rstd) fp32 [C] — the batch
+    mean first, then the second moment about it (two passes over z: no cancellation)."""
+    M, C = z.shape
+    buf = torch.zeros((4, C), dtype=torch.float32, device=z.device)
+    L_ = _lib.lib()
+    _lib.check(L_.svol_bn_colstats(_ptr(z), None, _ptr(buf[0]), _ptr(buf[1]), M, C, _dt(z), _stream()), 'svol_bn_colstats')
+    mean = buf[0] / M
+    _lib.check(L_.svol_bn_colstats(_ptr(z), _ptr(mean), _ptr(buf[2]), _ptr(buf[3]), M, C, _dt(z), _stream()), 'svol_bn_colstats')
+    var = buf[3] / M
+    return mean, var, torch.rsqrt(var + eps)
+
+
+def bn_apply(z, scale, shift, residual=None, relu=False):
+    M, C = z.shape
+    y = torch.empty_like(z)
+    _lib.check(_lib.lib().svol_bn_apply(_ptr(z), _ptr(scale), _ptr(shift), _ptr(residual), 1 if relu else 0, _ptr(y), M, C, _dt(z),
+                                        _stream()), 'svol_bn_apply')
+    return y
+
+
+def bn_bwd(dy, y, z, mean, rstd, gamma, want_dres):
+    """(dz, dres | None, dgamma, dbeta) of y = relu?(BN_train(z) + res): y = the saved output when a ReLU follows, else None."""
+    M, C = z.shape
+    sums = torch.zeros((2, C), dtype=torch.float32, device=z.device)
+    L_ = _lib.lib()
+    _lib.check(L_.svol_bn_bwd_reduce(_ptr(dy), _ptr(y), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(sums[0]), _ptr(sums[1]), M, C, _dt(z),
+                                     _stream()), 'svol_bn_bwd_reduce')
+    dz = torch.empty_like(z)
+    dres = torch.empty_like(z) if want_dres else None
+    _lib.check(L_.svol_bn_bwd_apply(_ptr(dy), _ptr(y), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(sums[0]), _ptr(sums[1]), _ptr(dz),
+                                    _ptr(dres), M, C, _dt(z), _stream()), 'svol_bn_bwd_apply')
+    return dz, dres, sums[1], sums[0]
+
+
+def col2im_nhwc(dcols, N, H, W, C, kh, kw, stride, pad):
+    dx = torch.empty((N * H * W, C), dtype=dcols.dtype, device=dcols.device)
+    _lib.check(_lib.lib().svol_col2im_nhwc(_ptr(dcols), dcols.stride(0), _ptr(dx), N, H, W, C, kh, kw, stride, pad, _dt(dcols), _stream()),
+               'svol_col2im_nhwc')
+    return dx
+
+
+def maxpool_idx_nhwc(x, N, H, W, C, k, stride, pad):
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y = torch.empty((N * Ho * Wo, C), dtype=x.dtype, device=x.device)
+    idx = torch.empty((N * Ho * Wo, C), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.lib().svol_maxpool_idx_nhwc(_ptr(x), _ptr(y), _ptr(idx), N, H, W, C, k, stride, pad, _dt(x), _stream()),
+               'svol_maxpool_idx_nhwc')
+    return y, idx, Ho, Wo
+
+
+def maxpool_bwd_nhwc(dy, idx, N, H, W, C, k, stride, pad):
+    dx = torch.empty((N * H * W, C), dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.lib().svol_maxpool_bwd_nhwc(_ptr(dy), _ptr(idx), _ptr(dx), N, H, W, C, k, stride, pad, _dt(dy), _stream()),
+               'svol_maxpool_bwd_nhwc')
+    return dx
+
+
 def attn_weights_mean(q, k, lse2, B, H, Lq, Lk, dh, kbias=None, premul=0.0):
     """head-averaged softmax probabilities [B,Lq,Lk] fp32 (nn.MultiheadAttention's second return value), recomputed
     from q, k and the lse2 of attn_fwd."""

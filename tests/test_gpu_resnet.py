@@ -130,3 +130,197 @@ def test_implicit_conv_matches_im2col_path():
         got = y.float().cpu().view(N, Ho, Wo, Cout).permute(0, 3, 1, 2).double()
         err = float((got - ref).abs().max()) / float(ref.abs().max())
         assert err < 1.2e-2, (N, H, W, C, Cout, k, s, p, act, err)
+
+
+class _RoundBf16(torch.autograd.Function):
+    """x -> bf16(x) in the forward AND the backward: marks the places where the HIP path keeps an activation / its gradient in bf16."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+def _emulated_bf16_reference(sd, depths, x, probe_fmap, avg):
+    """the same network in torch fp32 on the GPU with the HIP path's roundings (conv output, unit output, their gradients; bf16 conv
+    weights): a reference whose ReLU masks and BatchNorm cancellations see bf16 activations like the product does."""
+    import torch.nn.functional as F
+    r = _RoundBf16.apply
+    P = {k: (v.to(DEV).float().requires_grad_('running' not in k) if v.is_floating_point() else v) for k, v in sd.items()}
+    w = lambda k: r(P[k])
+
+    def bn(z, p):
+        return F.batch_norm(z, None, None, P[p + '.weight'], P[p + '.bias'], True, 0.1, 1e-5)
+    h = r(F.relu(bn(r(F.conv2d(r(x.to(DEV).float()), w('0.weight'), None, 2, 3)), '1')))
+    h = F.max_pool2d(h, 3, 2, 1)
+    for li, nb in enumerate(depths):
+        for bi in range(nb):
+            p, stride = f'{4 + li}.{bi}', (1 if li == 0 else 2) if bi == 0 else 1
+            t = r(F.relu(bn(r(F.conv2d(h, w(p + '.conv1.weight'), None, stride, 1)), p + '.bn1')))
+            idt = h
+            if (p + '.downsample.0.weight') in P:
+                idt = r(bn(r(F.conv2d(h, w(p + '.downsample.0.weight'), None, stride, 0)), p + '.downsample.1'))
+            h = r(F.relu(bn(r(F.conv2d(t, w(p + '.conv2.weight'), None, 1, 1)), p + '.bn2') + idt))
+    f = F.adaptive_avg_pool2d(h, 1) if avg else h
+    (f * probe_fmap.to(DEV).float()).sum().backward()
+    return f.detach(), {k: v.grad for k, v in P.items() if torch.is_tensor(v) and v.requires_grad}
+
+
+@pytest.mark.parametrize('name', ['resnet_tiny_train', 'resnet_tiny3_train'])
+@pytest.mark.parametrize('avg', [False, True], ids=['tokens', 'pooled'])
+def test_resnet_training_mode_gradients(name, avg):
+    """ResNetExtractor(trainable=True).train(): batch-statistics BatchNorm forward, every parameter gradient and the running statistics
+    — VERDICT r4 "Next round 8" (the reference optimises the backbone too: train.py:72, backbone.py:133-152).  Two references on the
+    same weights, pixels and probe: (a) the fp64 oracle, itself pinned to transformers.ResNetModel.train() by the *_train fixtures:
+    features and running statistics tightly, gradients loosely — these nets normalise over 32 ... 768 samples, where ONE ReLU mask
+    that flips under bf16 rounding moves a bias gradient by several per cent; (b) the same network in torch fp32 with the product's
+    bf16 roundings (activations, their gradients, conv weights): gradients per tensor to a few per cent.  The kernels themselves are
+    checked one by one against fp64 in test_resnet_training_kernels."""
+    from oracle import resnet_oracle as R
+    from svol_amd.modeling.resnet import ResNetExtractor
+    from tests.test_oracle_resnet import resnet_case
+    z, meta, sd, x = resnet_case(name)
+    depths = tuple(meta['depths'])
+    g = torch.Generator().manual_seed(11)
+    m = ResNetExtractor(depths, tuple(meta['widths']), meta['stem'], avgpool=avg, compute_dtype='bf16', trainable=True)
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV).train()
+    out = m(x.to(DEV))
+    probe = torch.randn(out.shape, generator=g)
+    (out.float() * probe.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    side = int(round(out.shape[1] ** 0.5))
+    # the oracle's features are [n, C, h, w]; tokens are (h, w)-major rows of C
+    probe_fmap = probe.view(out.shape[0], -1, 1, 1) if avg else probe.transpose(1, 2).reshape(out.shape[0], -1, side, side)
+    f, grads, stats = R.resnet_train_grads(sd, depths, x, probe_fmap, avgpool=avg)
+    ref_out = f.flatten(1) if avg else f.flatten(2).transpose(1, 2)
+    got = out.detach().float().cpu().double()
+    l2 = float((got - ref_out).norm() / ref_out.norm())
+    assert l2 <= 2.5e-2, f'features vs fp64: L2 {l2:.3e}'
+    for k, v in stats.items():
+        have = dict(m.named_buffers())[k].double().cpu()
+        assert float((have - v.double()).abs().max()) <= 1e-2 * max(1.0, float(v.abs().max())), k
+    assert int(dict(m.named_buffers())['1.num_batches_tracked']) == 1
+    fe, ge = _emulated_bf16_reference(sd, depths, x, probe_fmap, avg)
+    e64, eem = {}, {}
+    for k, p in m.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+        e64[k] = float((p.grad.double().cpu() - grads[k]).norm() / max(float(grads[k].norm()), 1e-12))
+        eem[k] = float((p.grad.double().cpu() - ge[k].double().cpu()).norm() / max(float(ge[k].norm()), 1e-12))
+    print(f'{name} avg={avg}: feature L2 {l2:.2e}; gradient L2 vs fp64 max {max(e64.values()):.2e} median {sorted(e64.values())[len(e64) // 2]:.2e}; '
+          f'vs the bf16-rounding reference max {max(eem.values()):.2e} median {sorted(eem.values())[len(eem) // 2]:.2e}')
+    # measured (round 5): vs fp64 max 0.17 - 0.33, median 0.06 - 0.24; vs the bf16-rounding reference tiny (48 samples in the last
+    # stage) max 0.06 - 0.12, median 0.04 - 0.08, tiny3 (64 x 64 pixels) max 0.016, median 0.007
+    assert max(e64.values()) <= 0.6, {k: round(v, 3) for k, v in e64.items() if v > 0.6}
+    med = sorted(eem.values())[len(eem) // 2]
+    bad = {k: round(v, 4) for k, v in eem.items() if not v <= 0.2}
+    assert not bad and med <= (0.03 if name == 'resnet_tiny3_train' else 0.12), (bad, med)
+
+
+def test_resnet_training_kernels():
+    """csrc/resnet_train.hip one kernel at a time against torch fp64 on the same bf16 values: conv forward, batch statistics, the BatchNorm
+    apply, its backward (with the kernel's own ReLU mask), the weight gradient (svol_gemm_tn of im2col), the data gradient (svol_gemm_nt +
+    col2im), max pooling with ties (post-ReLU zeros) and its backward — 3x3 s1 / s2, 1x1 s2, C = 16 ... 64 (both convolution paths)."""
+    import torch.nn.functional as F
+    from svol_amd import ops
+    from svol_amd.modeling.resnet import _w16
+
+    def rel(a, b):
+        a, b = a.double().cpu(), b.double().cpu()
+        return float((a - b).norm() / max(float(b.norm()), 1e-30))
+    g = torch.Generator().manual_seed(0)
+    dt = torch.bfloat16
+    res = {}
+    for (n, H, W, C, Cout, k, s, p) in [(3, 8, 8, 16, 32, 3, 2, 1), (2, 16, 16, 32, 32, 3, 1, 1), (2, 8, 8, 64, 128, 1, 2, 0), (2, 14, 14, 64, 64, 3, 1, 1)]:
+        tag = f'{n}x{H}x{W}x{C}->{Cout} k{k}s{s}'
+        x = torch.randn(n, C, H, W, generator=g)
+        w = torch.randn(Cout, C, k, k, generator=g) * 0.1
+        x16 = x.permute(0, 2, 3, 1).reshape(n * H * W, C).to(dt).to(DEV).contiguous()
+        xr = x16.double().cpu().view(n, H, W, C).permute(0, 3, 1, 2).requires_grad_(True)
+        w16 = _w16(w.to(DEV), dt)
+        wr = w16[:, :k * k * C].double().cpu().view(Cout, k, k, C).permute(0, 3, 1, 2).requires_grad_(True)
+        z, Ho, Wo = ops.conv_nhwc(x16, w16, None, ops.ACT_NONE, n, H, W, C, k, k, s, p)
+        zr = F.conv2d(xr, wr, None, s, p)
+        res[tag + ' conv'] = (rel(z, zr.detach().permute(0, 2, 3, 1).reshape(-1, Cout)), 4e-3)
+        M = z.shape[0]
+        mean, var, rstd = ops.bn_batch_stats(z, 1e-5)
+        zd = z.double().cpu()
+        res[tag + ' mean'] = (rel(mean, zd.mean(0)), 1e-5)
+        res[tag + ' var'] = (rel(var, zd.var(0, unbiased=False)), 1e-5)
+        gamma = (1 + 0.1 * torch.randn(Cout, generator=g)).to(DEV)
+        beta = (0.1 * torch.randn(Cout, generator=g)).to(DEV)
+        idt = torch.randn(M, Cout, generator=g).to(dt).to(DEV)
+        scale = gamma * rstd
+        y = ops.bn_apply(z, scale.contiguous(), (beta - mean * scale).contiguous(), idt, True)
+        zz, gr, br, rr = zd.clone().requires_grad_(True), gamma.double().cpu().requires_grad_(True), beta.double().cpu().requires_grad_(True), idt.double().cpu().requires_grad_(True)
+        pre = F.batch_norm(zz, None, None, gr, br, True, 0.1, 1e-5) + rr
+        res[tag + ' bn_apply'] = (rel(y, torch.relu(pre).detach()), 4e-3)
+        dy = torch.randn(M, Cout, generator=g).to(dt).to(DEV)
+        dz, dres, dgm, dbt = ops.bn_bwd(dy, y, z, mean, rstd, gamma, True)
+        (pre * (dy.double().cpu() * (y.double().cpu() > 0).double())).sum().backward()
+        res[tag + ' dz'] = (rel(dz, zz.grad), 4e-3)
+        res[tag + ' didentity'] = (rel(dres, rr.grad), 1e-6)
+        res[tag + ' dgamma'] = (rel(dgm, gr.grad), 1e-5)
+        res[tag + ' dbeta'] = (rel(dbt, br.grad), 1e-5)
+        zr.backward(dz.double().cpu().view(n, Ho, Wo, Cout).permute(0, 3, 1, 2))
+        cols, _, _ = ops.im2col(x16, n, H, W, C, k, k, s, p, dt, ldcols=w16.shape[1])
+        dW = ops.gemm_tn(dz, cols)[:, :k * k * C].reshape(Cout, k, k, C).permute(0, 3, 1, 2)
+        res[tag + ' dW'] = (rel(dW, wr.grad), 1e-5)
+        dx = ops.col2im_nhwc(ops.gemm_nt(dz, w16.t().contiguous()), n, H, W, C, k, k, s, p)
+        res[tag + ' dx'] = (rel(dx.view(n, H, W, C).permute(0, 3, 1, 2), xr.grad), 5e-3)
+    n, H, W, C = 2, 9, 9, 16
+    x16 = torch.relu(torch.randn(n, C, H, W, generator=g)).permute(0, 2, 3, 1).reshape(-1, C).to(dt).to(DEV).contiguous()
+    xr = x16.double().cpu().view(n, H, W, C).permute(0, 3, 1, 2).requires_grad_(True)
+    y, idx, Ho, Wo = ops.maxpool_idx_nhwc(x16, n, H, W, C, 3, 2, 1)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    dy = torch.randn(n * Ho * Wo, C, generator=g).to(dt).to(DEV)
+    yr.backward(dy.double().cpu().view(n, Ho, Wo, C).permute(0, 3, 1, 2))
+    res['maxpool fwd'] = (rel(y, yr.detach().permute(0, 2, 3, 1).reshape(-1, C)), 0.0)
+    res['maxpool bwd (ties)'] = (rel(ops.maxpool_bwd_nhwc(dy, idx, n, H, W, C, 3, 2, 1).view(n, H, W, C).permute(0, 3, 1, 2), xr.grad), 3e-3)
+    bad = {k_: v for k_, v in res.items() if not v[0] <= v[1]}
+    assert not bad, bad
+
+
+def test_resnet_trainable_backbone_in_the_training_step():
+    """--backbone resnet with the extractors in the optimiser: one step of the whole model (frames -> ResNet-34 -> SVANet head ->
+    criterion -> backward -> AdamW) moves backbone weights, and eval() afterwards runs the frozen path on the UPDATED running statistics."""
+    from svol_amd import parallel
+    from svol_amd import synthetic as syn
+    from svol_amd.modeling.loss import build_loss
+    from svol_amd.modeling.resnet import ResNetBackbone, ResNetExtractor
+    from svol_amd.modeling.svanet import build_svanet
+    args = syn.head_args(hidden_dim=64, nheads=8, num_layers=1, num_queries=10, num_frames=2, input_vid_dim=32, input_skch_dim=32,
+                         input_dropout=0.0)
+    args.compute_dtype = 'bf16'
+    torch.manual_seed(0)
+    vb = ResNetExtractor((1, 1), (16, 32), 16, compute_dtype='bf16', trainable=True)
+    sb = ResNetExtractor((1, 1), (16, 32), 16, avgpool=True, compute_dtype='bf16', trainable=True)
+    vb.load_state_dict(syn.synth_resnet_state_dict(syn.resnet_param_shapes((1, 1), (16, 32), 16), seed=1))
+    sb.load_state_dict(syn.synth_resnet_state_dict(syn.resnet_param_shapes((1, 1), (16, 32), 16), seed=2))
+    backbone = ResNetBackbone(vb, sb).to(DEV).train()
+    head = build_svanet(args).to(DEV).train()
+    crit = build_loss(args).to(DEV).train()
+    B, T = 2, 2
+    vid = syn.synth_images(B * T, syn.vit_config(image_size=64), seed=3).view(B, T, 3, 64, 64).to(DEV)
+    sk = syn.synth_images(B, syn.vit_config(image_size=64), seed=4).view(B, 1, 3, 64, 64).to(DEV)
+    params = [p for p in list(backbone.parameters()) + list(head.parameters()) if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-3)
+    before = {k: v.detach().clone() for k, v in backbone.named_parameters()}
+    s, v = backbone(sk, vid)
+    P = v.shape[1] // T
+    out = head(s, torch.ones(B, 1, device=DEV), v, torch.ones(B, T * P, device=DEV))
+    crit(out, syn.synth_targets(B, T, seed=1))
+    loss = crit.weighted_total()
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(loss))
+    moved = [k for k, p in backbone.named_parameters() if not torch.equal(p.detach(), before[k])]
+    assert len(moved) == len(before), f'{len(before) - len(moved)} backbone parameters did not move'
+    backbone.eval()
+    with torch.no_grad():
+        s2, v2 = backbone(sk, vid)
+    assert bool(torch.isfinite(v2.float()).all()) and bool(torch.isfinite(s2.float()).all())

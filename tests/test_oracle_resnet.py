@@ -53,3 +53,26 @@ def test_backbone_token_order():
     f = R.resnet_features(sd, (1,), vid.flatten(0, 1))  # [4, 8, 8, 8]
     assert s.shape == (2, 1, 8) and v.shape == (2, 2 * 64, 8)
     assert torch.equal(v[1, 64 + 8 * 3 + 5], f[3, :, 3, 5])
+
+
+TRAIN_CASES = ['resnet_tiny_train', 'resnet_tiny3_train']
+
+
+@pytest.mark.parametrize('name', TRAIN_CASES)
+def test_oracle_training_mode_vs_hf_resnet(name):
+    """The TRAINING-mode restatement (batch-statistics BatchNorm, autograd) against transformers.ResNetModel.train() in fp64: features,
+    every parameter gradient of loss = sum(features * probe), and the updated running statistics (tests/golden/make_golden_resnet.py)."""
+    z, meta, sd, x = resnet_case(name)
+    probe = torch.from_numpy(z['probe'])
+    f, grads, stats = R.resnet_train_grads(sd, meta['depths'], x, probe)
+    assert float((f - torch.from_numpy(z['features'])).abs().max()) <= 1e-9 * float(np.abs(z['features']).max())
+    keys = [k[5:] for k in z.files if k.startswith('grad/')]
+    assert sorted(keys) == sorted(grads.keys())
+    for k in keys:
+        ref = torch.from_numpy(z['grad/' + k])
+        assert float((grads[k] - ref).abs().max()) <= 1e-8 * max(1.0, float(ref.abs().max())), k
+    skeys = [k[5:] for k in z.files if k.startswith('stat/')]
+    assert len(skeys) > 0 and sorted(skeys) == sorted(stats.keys())
+    for k in skeys:
+        ref = torch.from_numpy(z['stat/' + k])
+        assert float((stats[k].double() - ref).abs().max()) <= 1e-9 * max(1.0, float(ref.abs().max())), k
