@@ -116,6 +116,9 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='videos per GPU (default: 8, cfg5: 1)')
     ap.add_argument('--dropout', type=float, default=None,
                     help="--workload encdec: the Transformer's dropout (reference default 0.1; the bench default stays 0 = round 3's line)")
+    ap.add_argument('--train-backbone', action='store_true',
+                    help='--workload resnet: the ResNet-34 / ResNet-18 extractors in TRAINING mode (batch-statistics BatchNorm, convolution '
+                         'gradients) and in the optimiser, as the reference\'s train.py:72 has them; default: frozen extractors')
     ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg4', 'cfg5', 'encdec', 'resnet'],
                     help='cfg2 = the BASELINE metric workload (default); cfg4 = cfg2 with the ViT-B/16 frame + sketch feature '
                          'extractor run online in front of the head (BASELINE configs[3], end-to-end frames/s); '
@@ -213,8 +216,24 @@ def main():
     model = build_svanet(args).to(dev).train()
     crit = build_loss(args).to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]   # the optimizer's list, reference order (train.py:72)
-    # gradient buckets in the order backward produces them (heads, layers 5..0, query embedding + input projections last)
-    reducer = parallel.BucketedGradAllReduce(parallel.arrival_order(model), skip=parallel.unused_parameters(model), ordered=True)
+    backbone = None
+    bb_params = []
+    if a.workload == 'resnet':
+        # randomly initialised torchvision-layout ResNets (IMAGENET1K_V1 cannot be downloaded here), synthetic pixels; the extractors run
+        # inside the timed step (backbone.py:133-152: ResNet-34 frames, ResNet-18 + avgpool sketch); frozen unless --train-backbone
+        from svol_amd.modeling.resnet import ResNetBackbone, resnet18, resnet34
+        backbone = ResNetBackbone(resnet34(compute_dtype=a.dtype, trainable=a.train_backbone),
+                                  resnet18(avgpool=True, compute_dtype=a.dtype, trainable=a.train_backbone))
+        backbone.video_backbone.load_state_dict(syn.synth_resnet_state_dict(syn.resnet_param_shapes((3, 4, 6, 3)), seed=1))
+        backbone.sketch_backbone.load_state_dict(syn.synth_resnet_state_dict(syn.resnet_param_shapes((2, 2, 2, 2)), seed=2))
+        backbone = backbone.to(dev)
+        backbone = backbone.train() if a.train_backbone else backbone.eval()
+        bb_params = [p for p in backbone.parameters() if p.requires_grad]
+        params = bb_params + params   # (backbone first: model.py:14 registers it before the head)
+    # gradient buckets in the order backward produces them (heads, layers 5..0, query embedding + input projections, then the
+    # backbone from its last stage to the stem)
+    reducer = parallel.BucketedGradAllReduce(parallel.arrival_order(model) + list(reversed(bb_params)), skip=parallel.unused_parameters(model),
+                                             ordered=True)
     use_graph = world == 1 and a.graph and not a.no_graph
     if use_graph:  # (the captured step keeps torch's capturable optimizer: its step counter lives on the device)
         opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, fused=True, capturable=True)  # train.py:98-99
@@ -225,7 +244,6 @@ def main():
     tg = syn.synth_targets(B, T, seed=1 + rank)
     wd = crit.weight_dict
     n_dec = args.dec_layers if a.workload == 'encdec' else args.num_layers  # decoder layers whose outputs the criterion matches
-    backbone = None
     if a.workload == 'cfg4':
         # frozen, randomly initialised ViT-B/16 extractors (the pretrained weights cannot be downloaded here); synthetic
         # normalised pixel values; the extractor runs inside the timed step
@@ -235,13 +253,6 @@ def main():
         pix_video = torch.randn((B, T, 3, 224, 224), device=dev, generator=g)
         pix_sketch = torch.randn((B, 1, 3, 224, 224), device=dev, generator=g)
     if a.workload == 'resnet':
-        # frozen, randomly initialised torchvision-layout ResNets (IMAGENET1K_V1 cannot be downloaded here), synthetic pixels;
-        # the extractors run inside the timed step (backbone.py:133-152: ResNet-34 frames, ResNet-18 + avgpool sketch)
-        from svol_amd.modeling.resnet import ResNetBackbone, resnet18, resnet34
-        backbone = ResNetBackbone(resnet34(compute_dtype=a.dtype), resnet18(avgpool=True, compute_dtype=a.dtype))
-        backbone.video_backbone.load_state_dict(syn.synth_resnet_state_dict(syn.resnet_param_shapes((3, 4, 6, 3)), seed=1))
-        backbone.sketch_backbone.load_state_dict(syn.synth_resnet_state_dict(syn.resnet_param_shapes((2, 2, 2, 2)), seed=2))
-        backbone = backbone.to(dev).eval()
         g = torch.Generator(device=dev).manual_seed(1 + rank)
         pix_video = torch.randn((B, T, 3, 224, 224), device=dev, generator=g)
         pix_sketch = torch.randn((B, 1, 3, 224, 224), device=dev, generator=g)
@@ -496,7 +507,7 @@ def main():
                                    'd=256, h=8, 6 layers, N=100, video_matcher, Din=%d, train mode; step = fwd + '
                                    'criterion + bwd (+RCCL grad all-reduce) + AdamW' % (B, T, P, args.input_vid_dim)) + (
                                        '; ViT-B/16 extractor (random init, frozen) on all %d frames + %d sketches inside the step' % (B * T, B)
-                                       if a.workload == 'cfg4' else ('; frozen ResNet-34 (frames, 7x7 tokens) + ResNet-18 (sketch) extractors inside the step' if a.workload == 'resnet' else '')),
+                                       if a.workload == 'cfg4' else (('; ResNet-34 (frames, 7x7 tokens) + ResNet-18 (sketch) extractors inside the step, ' + ('TRAINED (batch-statistics BatchNorm, in the optimiser)' if a.train_backbone else 'frozen')) if a.workload == 'resnet' else '')),
                        'global_batch': B * world, 'parallelism': f'dp{world}'},
             'n_ranks_seen': n_ranks_seen, 'dist_backend': backend if world > 1 else None,
             'final_loss': final_loss,

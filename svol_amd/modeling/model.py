@@ -4,7 +4,8 @@
 src_video_mask)`` keep the reference's signatures and the ``backbone.`` / ``head.`` state-dict
 prefixes.  ``--backbone features`` plugs pre-extracted features in at the measured boundary (SURVEY.md D3);
 ``--backbone vit`` runs the ViT-B/16 extractor of ``backbone.py`` on the device for every frame and the sketch
-(SURVEY.md §8 f1); ``--backbone resnet`` the ResNet-34 / ResNet-18 extractors of ``resnet.py`` (f4), both frozen.
+(frozen); ``--backbone resnet`` the ResNet-34 / ResNet-18 extractors of ``resnet.py`` (f4), frozen by default,
+trained with the head when ``args.train_backbone`` is set (what the reference's train.py does).
 """
 from __future__ import annotations
 
@@ -42,9 +43,12 @@ def build_backbone(args):
         args.input_vid_dim = 512
         args.input_skch_dim = 512
         cd = getattr(args, 'compute_dtype', 'bf16')
-        # frozen / inference only; the torchvision IMAGENET1K_V1 weights are loaded by the caller (load_state_dict with the
-        # reference's backbone.* keys) — nothing is downloaded here
-        return ResNetBackbone(resnet34(compute_dtype=cd), resnet18(avgpool=True, compute_dtype=cd))
+        # the torchvision IMAGENET1K_V1 weights are loaded by the caller (load_state_dict with the reference's backbone.* keys) —
+        # nothing is downloaded here.  args.train_backbone (default False = frozen extractors, eval-mode BatchNorm): True is what the
+        # reference's training step does (train.py:72 optimises every parameter, model.train() puts BatchNorm into batch-statistics
+        # mode; its --freeze_backbone flag is dead): convolution / BatchNorm gradients through csrc/resnet_train.hip
+        tb = bool(getattr(args, 'train_backbone', False))
+        return ResNetBackbone(resnet34(compute_dtype=cd, trainable=tb), resnet18(avgpool=True, compute_dtype=cd, trainable=tb))
     raise NotImplementedError(f"backbone '{args.backbone}' is not part of the MI355X build (the reference has it commented out)")
 
 
