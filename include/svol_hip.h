@@ -380,7 +380,8 @@ int svol_avgpool_nhwc(const void* x, float* y, int64_t N, int64_t HW, int64_t C,
  * torchvision's ResNet-34 / ResNet-18 with train-mode BatchNorm, backbone.py:133-152).  Activations NHWC [M = n*h*w, C], 16-bit; C a
  * multiple of 8 (the column reductions: C / 8 a divisor of 256).  The convolutions stay GEMMs: forward svol_conv_nhwc / svol_im2col +
  * svol_gemm_nt without bias; weight gradient svol_gemm_tn(dz, svol_im2col(x)); data gradient svol_gemm_nt(dz, W^T) -> svol_col2im_nhwc.
- *   svol_bn_colstats    sum[c] += sum_m (z[m,c] - shift[c]), sumsq[c] += sum_m (z[m,c] - shift[c])^2   (shift may be NULL; caller zeroes)
+ *   svol_bn_colstats    sum[c] += sum_m (z[m,c] - s_c), sumsq[c] += sum_m (z[m,c] - s_c)^2, s_c = shift[c] * shift_scale (shift may be NULL;
+ *                       caller zeroes): pass 1 with NULL gives the sums, pass 2 with (sums, 1 / M) the second moment about the mean
  *   svol_bn_apply       y = z * scale[c] + shift[c] (+ residual) (relu != 0: max(., 0))  — nn.BatchNorm2d in train mode with
  *                       scale = gamma * rstd, shift = beta - mean * scale from the BATCH statistics
  *   svol_bn_bwd_reduce  g = dy * [y > 0] (y NULL: g = dy); sum_g[c] += sum g, sum_gx[c] += sum g * (z - mean[c]) * rstd[c]  (caller zeroes)
@@ -389,7 +390,21 @@ int svol_avgpool_nhwc(const void* x, float* y, int64_t N, int64_t HW, int64_t C,
  *   svol_col2im_nhwc    dx[n,iy,ix,c] = sum of dcols[(n,oy,ox), (ky,kx,c)] over the windows that hold (iy,ix): the transpose of svol_im2col
  *   svol_maxpool_idx_nhwc / svol_maxpool_bwd_nhwc   nn.MaxPool2d with the window position (ky*k + kx, one byte per output element) of the
  *                       first maximum of the (ky, kx) scan, and the backward that routes dy to it */
-int svol_bn_colstats(const void* z, const float* shift, float* sum, float* sumsq, int64_t M, int64_t C, int dtype, void* stream);
+int svol_bn_colstats(const void* z, const float* shift, float shift_scale, float* sum, float* sumsq, int64_t M, int64_t C, int dtype,
+                     void* stream);
+/* the [C]-sized step between the two column passes and svol_bn_apply, one launch: mean = sum / M, rstd = (sumsq_centered / M + eps)^-1/2,
+ * scale = gamma * rstd, shift = beta - mean * scale, and nn.BatchNorm2d's running update (running_* may be NULL):
+ * running_mean = (1 - momentum) running_mean + momentum mean, running_var likewise with the UNBIASED batch variance. */
+int svol_bn_finalize(const float* sum, const float* sumsq_centered, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, float momentum, float eps, int64_t M, int64_t C, float* mean, float* rstd, float* scale, float* shift,
+                     void* stream);
+/* nn.Conv2d weights fp32 [Cout, Cin, kh, kw] -> the GEMMs' 16-bit layout: flip = 0: out [Cout, Kp], column (ky*kw + kx)*Cin + c, zero
+ * beyond kh*kw*Cin; flip = 1 (the data gradient of a stride-1 convolution as a convolution of dz): out [Cin, Kp], column
+ * (ky*kw + kx)*Cout + co = w[co, ci, kh-1-ky, kw-1-kx].  svol_conv_weight_unpack_add: grad [Cout, Cin, kh, kw] (fp32) += dWp [Cout, Kp]
+ * (fp32, the flip = 0 layout): the weight gradient of svol_gemm_tn(dz, im2col(x)) back into the parameter's layout. */
+int svol_conv_weight_pack(const float* w, void* out, int64_t Cout, int64_t Cin, int64_t kh, int64_t kw, int64_t Kp, int flip, int dtype,
+                          void* stream);
+int svol_conv_weight_unpack_add(const float* dwp, float* grad, int64_t Cout, int64_t Cin, int64_t kh, int64_t kw, int64_t Kp, void* stream);
 int svol_bn_apply(const void* z, const float* scale, const float* shift, const void* residual, int relu, void* y, int64_t M, int64_t C,
                   int dtype, void* stream);
 int svol_bn_bwd_reduce(const void* dy, const void* y, const void* z, const float* mean, const float* rstd, float* sum_g, float* sum_gx,

@@ -59,12 +59,12 @@ __device__ __forceinline__ void col_reduce_finish(float (&acc)[K][8], int G, int
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ z, const float* __restrict__ shift, float* sum, float* sumsq,
-                                                          int64_t M, int C, int64_t rows_per_wg, float* det_part) {
+__global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ z, const float* __restrict__ shift, float shift_scale, float* sum,
+                                                          float* sumsq, int64_t M, int C, int64_t rows_per_wg, float* det_part) {
     const int G = C / 8, tid = threadIdx.x, g = tid % G, rl = tid / G, RL = 256 / G;
     float sh[8], acc[2][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sh[e] = shift ? shift[g * 8 + e] : 0.f; acc[0][e] = 0.f; acc[1][e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { sh[e] = shift ? shift[g * 8 + e] * shift_scale : 0.f; acc[0][e] = 0.f; acc[1][e] = 0.f; }
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg, r1 = min(M, r0 + rows_per_wg);
     for (int64_t r = r0 + rl; r < r1; r += RL) {
         float v[8];
@@ -245,6 +245,64 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
     store8(dx + i * 8, acc);
 }
 
+// everything [C]-sized between the two column passes and the apply, in one launch: batch mean / rstd, the affine pair of svol_bn_apply,
+// nn.BatchNorm2d's running-statistics update (momentum m, UNBIASED variance)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq_c,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                                                          float* running_var, float momentum, float eps, float inv_m, float unbias, int C,
+                                                          float* mean, float* rstd, float* scale, float* shift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float mu = sum[c] * inv_m, var = sumsq_c[c] * inv_m;
+    const float rs = 1.0f / sqrtf(var + eps);
+    const float sc = gamma[c] * rs;
+    mean[c] = mu;
+    rstd[c] = rs;
+    scale[c] = sc;
+    shift[c] = beta[c] - mu * sc;
+    if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mu;
+    if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * var * unbias;
+}
+
+// fp32 [Cout, Cin, kh, kw] (nn.Conv2d) -> 16-bit [Cout, Kp], (ky, kx, c) order, columns K .. Kp-1 zero (the GEMMs' layout)
+template <typename T>
+__global__ __launch_bounds__(256) void conv_weight_pack_kernel(const float* __restrict__ w, T* __restrict__ out, int Cin, int khw, int K, int Kp,
+                                                               int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t co = i / Kp;
+    const int k = (int)(i - co * Kp);
+    float v = 0.f;
+    if (k < K) { const int c = k % Cin, t = k / Cin; v = w[(co * Cin + c) * khw + t]; }
+    out[i] = (T)v;
+}
+// the weight gradient back: grad[Cout, Cin, kh, kw] (fp32) += dWp[Cout, Kp] (fp32, (ky, kx, c) order)
+__global__ __launch_bounds__(256) void conv_weight_unpack_add_kernel(const float* __restrict__ dwp, float* __restrict__ grad, int Cin, int khw,
+                                                                     int K, int Kp, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over grad elements
+    if (i >= n) return;
+    const int t = (int)(i % khw);
+    const int64_t r = i / khw;
+    const int c = (int)(r % Cin);
+    const int64_t co = r / Cin;
+    grad[i] += dwp[co * Kp + (int64_t)t * Cin + c];
+}
+// the data gradient's weights for stride-1 convolutions: out[ci, (ky, kx, co)] = w[co, ci, kh-1-ky, kw-1-kx] (16-bit, Kp2 = pad32(kh*kw*Cout))
+template <typename T>
+__global__ __launch_bounds__(256) void conv_weight_flip_kernel(const float* __restrict__ w, T* __restrict__ out, int Cin, int Cout, int kh, int kw,
+                                                               int Kp2, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t ci = i / Kp2;
+    const int k = (int)(i - ci * Kp2);
+    float v = 0.f;
+    if (k < kh * kw * Cout) {
+        const int co = k % Cout, t = k / Cout, ky = t / kw, kx = t % kw;
+        v = w[(((int64_t)co * Cin + ci) * kh + (kh - 1 - ky)) * kw + (kw - 1 - kx)];
+    }
+    out[i] = (T)v;
+}
+
 bool chan_ok(int64_t C) { return C >= 8 && C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0; }
 int64_t reduce_wgs(int64_t M, int64_t C, int64_t& rows_per_wg) {
     const int64_t RL = 256 / (C / 8);
@@ -259,7 +317,8 @@ int64_t reduce_wgs(int64_t M, int64_t C, int64_t& rows_per_wg) {
 
 extern "C" {
 
-int svol_bn_colstats(const void* z, const float* shift, float* sum, float* sumsq, int64_t M, int64_t C, int dtype, void* stream) {
+int svol_bn_colstats(const void* z, const float* shift, float shift_scale, float* sum, float* sumsq, int64_t M, int64_t C, int dtype,
+                     void* stream) {
     if (!z || !sum || !sumsq || M <= 0) return SVOL_E_INVALID;
     if (!chan_ok(C) || !svol_is16(dtype) || M > (1ll << 40)) return SVOL_E_UNSUPPORTED;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -269,13 +328,56 @@ int svol_bn_colstats(const void* z, const float* shift, float* sum, float* sumsq
     DetScratch det(det_mode ? (size_t)(wgs * 2 * C) : 0, s);
     if (det_mode && !det.p) return SVOL_E_LAUNCH;
     if (dtype == SVOL_BF16)
-        hipLaunchKernelGGL(bn_colstats_kernel<bf16_t>, dim3((unsigned)wgs), dim3(256), 0, s, (const bf16_t*)z, shift, sum, sumsq, M, (int)C, rpw, det.p);
+        hipLaunchKernelGGL(bn_colstats_kernel<bf16_t>, dim3((unsigned)wgs), dim3(256), 0, s, (const bf16_t*)z, shift, shift_scale, sum, sumsq, M, (int)C, rpw, det.p);
     else
-        hipLaunchKernelGGL(bn_colstats_kernel<f16_t>, dim3((unsigned)wgs), dim3(256), 0, s, (const f16_t*)z, shift, sum, sumsq, M, (int)C, rpw, det.p);
+        hipLaunchKernelGGL(bn_colstats_kernel<f16_t>, dim3((unsigned)wgs), dim3(256), 0, s, (const f16_t*)z, shift, shift_scale, sum, sumsq, M, (int)C, rpw, det.p);
     if (det_mode) {
         det_fold(det.p, (int)wgs, 2 * C, sum, C, s);
         det_fold(det.p + C, (int)wgs, 2 * C, sumsq, C, s);
     }
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_bn_finalize(const float* sum, const float* sumsq_centered, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, float momentum, float eps, int64_t M, int64_t C, float* mean, float* rstd, float* scale, float* shift,
+                     void* stream) {
+    if (!sum || !sumsq_centered || !gamma || !beta || !mean || !rstd || !scale || !shift || M <= 0 || C <= 0) return SVOL_E_INVALID;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), sum,
+                       sumsq_centered, gamma, beta, running_mean, running_var, momentum, eps, 1.0f / (float)M,
+                       M > 1 ? (float)M / (float)(M - 1) : 1.0f, (int)C, mean, rstd, scale, shift);
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_conv_weight_pack(const float* w, void* out, int64_t Cout, int64_t Cin, int64_t kh, int64_t kw, int64_t Kp, int flip, int dtype,
+                          void* stream) {
+    if (!w || !out || Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0) return SVOL_E_INVALID;
+    if (!svol_is16(dtype)) return SVOL_E_UNSUPPORTED;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!flip) {
+        const int64_t K = kh * kw * Cin;
+        if (Kp < K) return SVOL_E_INVALID;
+        const int64_t n = Cout * Kp;
+        const unsigned g = (unsigned)((n + 255) / 256);
+        if (dtype == SVOL_BF16) hipLaunchKernelGGL(conv_weight_pack_kernel<bf16_t>, dim3(g), dim3(256), 0, s, w, (bf16_t*)out, (int)Cin, (int)(kh * kw), (int)K, (int)Kp, n);
+        else hipLaunchKernelGGL(conv_weight_pack_kernel<f16_t>, dim3(g), dim3(256), 0, s, w, (f16_t*)out, (int)Cin, (int)(kh * kw), (int)K, (int)Kp, n);
+    } else {
+        if (Kp < kh * kw * Cout) return SVOL_E_INVALID;
+        const int64_t n = Cin * Kp;
+        const unsigned g = (unsigned)((n + 255) / 256);
+        if (dtype == SVOL_BF16) hipLaunchKernelGGL(conv_weight_flip_kernel<bf16_t>, dim3(g), dim3(256), 0, s, w, (bf16_t*)out, (int)Cin, (int)Cout, (int)kh, (int)kw, (int)Kp, n);
+        else hipLaunchKernelGGL(conv_weight_flip_kernel<f16_t>, dim3(g), dim3(256), 0, s, w, (f16_t*)out, (int)Cin, (int)Cout, (int)kh, (int)kw, (int)Kp, n);
+    }
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_conv_weight_unpack_add(const float* dwp, float* grad, int64_t Cout, int64_t Cin, int64_t kh, int64_t kw, int64_t Kp, void* stream) {
+    if (!dwp || !grad || Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0 || Kp < kh * kw * Cin) return SVOL_E_INVALID;
+    const int64_t n = Cout * Cin * kh * kw;
+    hipLaunchKernelGGL(conv_weight_unpack_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dwp,
+                       grad, (int)Cin, (int)(kh * kw), (int)(kh * kw * Cin), (int)Kp, n);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }

@@ -66,27 +66,27 @@ def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d, dtype):
 
 def _w16(weight, dtype):
     """[Cout, Cin, kh, kw] fp32 -> [Cout, Kp] compute dtype, (ky, kx, c) order, K padded to a multiple of 32 (the GEMMs' layout)."""
-    w = weight.detach().permute(0, 2, 3, 1).reshape(weight.shape[0], -1)
-    K = w.shape[1]
-    Kp = (K + 31) // 32 * 32
-    if Kp != K:
-        w = torch.cat([w, torch.zeros((w.shape[0], Kp - K), dtype=w.dtype, device=w.device)], dim=1)
-    return w.to(dtype).contiguous()
+    return ops.conv_weight_pack(weight, dtype)
 
 
 def _bn_forward(z, bn, gamma, beta, residual, relu):
     """train-mode BatchNorm of the conv output z [M, C] (+ identity) (+ ReLU); updates bn's running statistics as nn.BatchNorm2d does."""
-    M = z.shape[0]
-    mean, var, rstd = ops.bn_batch_stats(z, bn.eps)
-    with torch.no_grad():
-        if bn.track_running_stats and bn.running_mean is not None:
+    if bn.momentum is None:
+        raise NotImplementedError('BatchNorm2d(momentum=None) (cumulative average) is not on the reference path')
+    track = bn.track_running_stats and bn.running_mean is not None
+    mean, rstd, scale, shift = ops.bn_train_stats(z, gamma.detach(), beta.detach(), bn.running_mean if track else None,
+                                                  bn.running_var if track else None, bn.momentum, bn.eps)
+    if track:
+        with torch.no_grad():
             bn.num_batches_tracked += 1
-            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-            bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
-            bn.running_var.mul_(1.0 - m).add_(var * (M / max(M - 1, 1)), alpha=m)
-    scale = gamma.detach().float() * rstd
-    shift = beta.detach().float() - mean * scale
-    return ops.bn_apply(z, scale.contiguous(), shift.contiguous(), residual, relu), mean, rstd
+    return ops.bn_apply(z, scale, shift, residual, relu), mean, rstd
+
+
+def _weight_grad(dz, cols, weight):
+    """dW of a convolution in the parameter's own layout: svol_gemm_tn(dz, im2col(x)) -> [Cout, Kp], folded back by one kernel."""
+    dW = torch.zeros_like(weight, dtype=torch.float32, memory_format=torch.contiguous_format)
+    ops.conv_weight_unpack_add(ops.gemm_tn(dz, cols), dW)
+    return dW
 
 
 class _ConvBnFn(torch.autograd.Function):
@@ -98,27 +98,30 @@ class _ConvBnFn(torch.autograd.Function):
         w16 = _w16(weight, dt)
         z, Ho, Wo = ops.conv_nhwc(x, w16, None, ops.ACT_NONE, n, H, W, C, kh, kw, stride, pad)
         y, mean, rstd = _bn_forward(z, bn, gamma, beta, identity, relu)
-        ctx.geom, ctx.relu, ctx.has_id, ctx.wshape = geom, relu, identity is not None, tuple(weight.shape)
-        ctx.save_for_backward(x, w16, z, y if relu else None, mean, rstd, gamma.detach().float().contiguous())
+        ctx.geom, ctx.relu, ctx.has_id, ctx.out_hw = geom, relu, identity is not None, (Ho, Wo)
+        ctx.save_for_backward(x, weight, w16, z, y if relu else None, mean, rstd, gamma.detach())
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w16, z, y, mean, rstd, gamma = ctx.saved_tensors
+        x, weight, w16, z, y, mean, rstd, gamma = ctx.saved_tensors
         n, H, W, C, kh, kw, stride, pad = ctx.geom
-        dy = dy.contiguous()
-        dz, did, dgamma, dbeta = ops.bn_bwd(dy, y, z, mean, rstd, gamma, ctx.has_id and ctx.needs_input_grad[4])
-        Cout, Cin = ctx.wshape[0], ctx.wshape[1]
-        K, Kp = kh * kw * Cin, w16.shape[1]
+        Ho, Wo = ctx.out_hw
+        dz, did, dgamma, dbeta = ops.bn_bwd(dy.contiguous(), y, z, mean, rstd, gamma, ctx.has_id and ctx.needs_input_grad[4])
+        Cout = weight.shape[0]
         dW = None
         if ctx.needs_input_grad[1]:
-            cols, _, _ = ops.im2col(x, n, H, W, C, kh, kw, stride, pad, x.dtype, ldcols=Kp)
-            dW = ops.gemm_tn(dz, cols)[:, :K].reshape(Cout, kh, kw, Cin).permute(0, 3, 1, 2).contiguous()
+            cols, _, _ = ops.im2col(x, n, H, W, C, kh, kw, stride, pad, x.dtype, ldcols=w16.shape[1])
+            dW = _weight_grad(dz, cols, weight)
             del cols
         dx = None
         if ctx.needs_input_grad[0]:
-            dcols = ops.gemm_nt(dz, w16.t().contiguous())
-            dx = ops.col2im_nhwc(dcols, n, H, W, C, kh, kw, stride, pad)
+            if stride == 1 and 2 * pad == kh - 1 and kh == kw:
+                # the data gradient of a "same" stride-1 convolution is the convolution of dz with the reversed taps and swapped channels:
+                # the implicit-GEMM kernel again, no [M, 9 C] matrix
+                dx = ops.conv_nhwc(dz, ops.conv_weight_pack(weight, x.dtype, flip=True), None, ops.ACT_NONE, n, Ho, Wo, Cout, kh, kw, 1, pad)[0]
+            else:
+                dx = ops.col2im_nhwc(ops.gemm_nt(dz, w16.t().contiguous()), n, H, W, C, kh, kw, stride, pad)
         return dx, dW, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, did, None, None, None, None
 
 
@@ -134,21 +137,18 @@ class _StemFn(torch.autograd.Function):
         z = ops.gemm_nt(cols, w16)
         del cols
         y, mean, rstd = _bn_forward(z, bn, gamma, beta, None, True)
-        ctx.wshape, ctx.dt = tuple(weight.shape), dt
-        ctx.save_for_backward(pix, z, y, mean, rstd, gamma.detach().float().contiguous())
+        ctx.dt, ctx.Kp = dt, w16.shape[1]
+        ctx.save_for_backward(pix, weight, z, y, mean, rstd, gamma.detach())
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        pix, z, y, mean, rstd, gamma = ctx.saved_tensors
+        pix, weight, z, y, mean, rstd, gamma = ctx.saved_tensors
         n, c, H, W = pix.shape
-        Cout, Cin, kh, kw = ctx.wshape
+        kh, kw = weight.shape[2], weight.shape[3]
         dz, _, dgamma, dbeta = ops.bn_bwd(dy.contiguous(), y, z, mean, rstd, gamma, False)
-        K = kh * kw * Cin
-        Kp = (K + 31) // 32 * 32
-        cols, _, _ = ops.im2col(pix, n, H, W, c, kh, kw, 2, 3, ctx.dt, strides=(c * H * W, W, 1, H * W), ldcols=Kp)   # (recomputed: 1 GB at 256 frames)
-        dW = ops.gemm_tn(dz, cols)[:, :K].reshape(Cout, kh, kw, Cin).permute(0, 3, 1, 2).contiguous()
-        return None, dW, dgamma, dbeta, None, None
+        cols, _, _ = ops.im2col(pix, n, H, W, c, kh, kw, 2, 3, ctx.dt, strides=(c * H * W, W, 1, H * W), ldcols=ctx.Kp)   # (recomputed: 1 GB at 256 frames)
+        return None, _weight_grad(dz, cols, weight), dgamma, dbeta, None, None
 
 
 class _MaxPoolFn(torch.autograd.Function):

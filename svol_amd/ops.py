@@ -560,17 +560,41 @@ def avgpool_nhwc(x, N, HW, C):
 
 
 # ---- the backbone in training mode (csrc/resnet_train.hip) --------------------------------------------------------------
-def bn_batch_stats(z, eps):
-    """train-mode nn.BatchNorm2d statistics of an NHWC activation z [M, C] (16-bit): (mean, biased var, rstd) fp32 [C] — the batch
-    mean first, then the second moment about it (two passes over z: no cancellation)."""
+def bn_train_stats(z, gamma, beta, running_mean, running_var, momentum, eps):
+    """train-mode nn.BatchNorm2d statistics of an NHWC activation z [M, C] (16-bit) in four launches: the batch sums, the second moment
+    about the batch mean (two passes over z: no cancellation), then everything [C]-sized at once (svol_bn_finalize): -> fp32 [C] rows
+    (mean, rstd, scale = gamma * rstd, shift = beta - mean * scale); running_mean / running_var (may be None) are updated in place."""
     M, C = z.shape
-    buf = torch.zeros((4, C), dtype=torch.float32, device=z.device)
+    buf = torch.zeros((8, C), dtype=torch.float32, device=z.device)
     L_ = _lib.lib()
-    _lib.check(L_.svol_bn_colstats(_ptr(z), None, _ptr(buf[0]), _ptr(buf[1]), M, C, _dt(z), _stream()), 'svol_bn_colstats')
-    mean = buf[0] / M
-    _lib.check(L_.svol_bn_colstats(_ptr(z), _ptr(mean), _ptr(buf[2]), _ptr(buf[3]), M, C, _dt(z), _stream()), 'svol_bn_colstats')
-    var = buf[3] / M
-    return mean, var, torch.rsqrt(var + eps)
+    dt, s = _dt(z), _stream()
+    _lib.check(L_.svol_bn_colstats(_ptr(z), None, 0.0, _ptr(buf[0]), _ptr(buf[1]), M, C, dt, s), 'svol_bn_colstats')
+    _lib.check(L_.svol_bn_colstats(_ptr(z), _ptr(buf[0]), 1.0 / M, _ptr(buf[2]), _ptr(buf[3]), M, C, dt, s), 'svol_bn_colstats')
+    _lib.check(L_.svol_bn_finalize(_ptr(buf[0]), _ptr(buf[3]), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), float(momentum),
+                                   float(eps), M, C, _ptr(buf[4]), _ptr(buf[5]), _ptr(buf[6]), _ptr(buf[7]), s), 'svol_bn_finalize')
+    return buf[4], buf[5], buf[6], buf[7]
+
+
+def conv_weight_pack(w, dtype, flip=False):
+    """nn.Conv2d weight fp32 [Cout, Cin, kh, kw] -> the GEMMs' layout in `dtype`: [Cout, pad32(kh*kw*Cin)] in (ky, kx, c) order, or with
+    flip the stride-1 data gradient's [Cin, pad32(kh*kw*Cout)] (taps reversed, channels swapped)."""
+    Cout, Cin, kh, kw = w.shape
+    rows, K = (Cin, kh * kw * Cout) if flip else (Cout, kh * kw * Cin)
+    Kp = (K + 31) // 32 * 32
+    out = torch.empty((rows, Kp), dtype=dtype, device=w.device)
+    wc = w.detach()
+    wc = wc if wc.is_contiguous() else wc.contiguous()
+    _lib.check(_lib.lib().svol_conv_weight_pack(_ptr(wc), _ptr(out), Cout, Cin, kh, kw, Kp, 1 if flip else 0, _DT[dtype], _stream()),
+               'svol_conv_weight_pack')
+    return out
+
+
+def conv_weight_unpack_add(dwp, grad):
+    """grad [Cout, Cin, kh, kw] (fp32, contiguous) += dwp [Cout, Kp] (fp32, (ky, kx, c) order)"""
+    Cout, Cin, kh, kw = grad.shape
+    assert grad.is_contiguous() and dwp.is_contiguous() and dwp.dtype == torch.float32 and grad.dtype == torch.float32
+    _lib.check(_lib.lib().svol_conv_weight_unpack_add(_ptr(dwp), _ptr(grad), Cout, Cin, kh, kw, dwp.shape[1], _stream()),
+               'svol_conv_weight_unpack_add')
 
 
 def bn_apply(z, scale, shift, residual=None, relu=False):

@@ -246,15 +246,18 @@ def test_resnet_training_kernels():
         zr = F.conv2d(xr, wr, None, s, p)
         res[tag + ' conv'] = (rel(z, zr.detach().permute(0, 2, 3, 1).reshape(-1, Cout)), 4e-3)
         M = z.shape[0]
-        mean, var, rstd = ops.bn_batch_stats(z, 1e-5)
-        zd = z.double().cpu()
-        res[tag + ' mean'] = (rel(mean, zd.mean(0)), 1e-5)
-        res[tag + ' var'] = (rel(var, zd.var(0, unbiased=False)), 1e-5)
         gamma = (1 + 0.1 * torch.randn(Cout, generator=g)).to(DEV)
         beta = (0.1 * torch.randn(Cout, generator=g)).to(DEV)
+        rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+        mean, rstd, scale, shift = ops.bn_train_stats(z, gamma, beta, rm, rv, 0.1, 1e-5)
+        zd = z.double().cpu()
+        var_ref = zd.var(0, unbiased=False)
+        res[tag + ' mean'] = (rel(mean, zd.mean(0)), 1e-5)
+        res[tag + ' rstd'] = (rel(rstd, 1.0 / torch.sqrt(var_ref + 1e-5)), 1e-5)
+        res[tag + ' running_mean'] = (rel(rm, 0.1 * zd.mean(0)), 1e-5)
+        res[tag + ' running_var'] = (rel(rv, 0.9 + 0.1 * zd.var(0, unbiased=True)), 1e-5)
         idt = torch.randn(M, Cout, generator=g).to(dt).to(DEV)
-        scale = gamma * rstd
-        y = ops.bn_apply(z, scale.contiguous(), (beta - mean * scale).contiguous(), idt, True)
+        y = ops.bn_apply(z, scale, shift, idt, True)
         zz, gr, br, rr = zd.clone().requires_grad_(True), gamma.double().cpu().requires_grad_(True), beta.double().cpu().requires_grad_(True), idt.double().cpu().requires_grad_(True)
         pre = F.batch_norm(zz, None, None, gr, br, True, 0.1, 1e-5) + rr
         res[tag + ' bn_apply'] = (rel(y, torch.relu(pre).detach()), 4e-3)
@@ -269,8 +272,16 @@ def test_resnet_training_kernels():
         cols, _, _ = ops.im2col(x16, n, H, W, C, k, k, s, p, dt, ldcols=w16.shape[1])
         dW = ops.gemm_tn(dz, cols)[:, :k * k * C].reshape(Cout, k, k, C).permute(0, 3, 1, 2)
         res[tag + ' dW'] = (rel(dW, wr.grad), 1e-5)
+        w32 = wr.detach().float().to(DEV).contiguous()
+        res[tag + ' weight pack'] = (rel(ops.conv_weight_pack(w32, dt), w16), 0.0)
+        acc = torch.ones_like(w32)
+        ops.conv_weight_unpack_add(ops.gemm_tn(dz, cols), acc)
+        res[tag + ' weight unpack-add'] = (rel(acc - 1.0, wr.grad), 1e-5)
         dx = ops.col2im_nhwc(ops.gemm_nt(dz, w16.t().contiguous()), n, H, W, C, k, k, s, p)
         res[tag + ' dx'] = (rel(dx.view(n, H, W, C).permute(0, 3, 1, 2), xr.grad), 5e-3)
+        if s == 1:
+            dx2 = ops.conv_nhwc(dz, ops.conv_weight_pack(w32, dt, flip=True), None, ops.ACT_NONE, n, Ho, Wo, Cout, k, k, 1, p)[0]
+            res[tag + ' dx (as a convolution of dz)'] = (rel(dx2.view(n, H, W, C).permute(0, 3, 1, 2), xr.grad), 5e-3)
     n, H, W, C = 2, 9, 9, 16
     x16 = torch.relu(torch.randn(n, C, H, W, generator=g)).permute(0, 2, 3, 1).reshape(-1, C).to(dt).to(DEV).contiguous()
     xr = x16.double().cpu().view(n, H, W, C).permute(0, 3, 1, 2).requires_grad_(True)
