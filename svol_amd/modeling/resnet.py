@@ -82,10 +82,27 @@ def _bn_forward(z, bn, gamma, beta, residual, relu):
     return ops.bn_apply(z, scale, shift, residual, relu), mean, rstd
 
 
-def _weight_grad(dz, cols, weight):
-    """dW of a convolution in the parameter's own layout: svol_gemm_tn(dz, im2col(x)) -> [Cout, Kp], folded back by one kernel."""
+def _weight_grad(dz, make_cols, weight, sink, keep):
+    """dW of a convolution in the parameter's own layout: svol_gemm_tn(dz, im2col(x)) -> [Cout, Kp], folded back by one kernel.
+    With a gradient sink (the parameter's .grad is a view of a BucketedGradAllReduce bucket) the three launches go to the
+    weight-gradient stream (ops.py "weight gradients off the critical path": nobody needs dW before the optimiser; the dx chain behind
+    it is the backward's critical path) and add straight into the bucket: returns None.  `keep`: tensors the side stream reads."""
+    if sink is not None and ops.WGRAD_ASYNC and not torch.cuda.is_current_stream_capturing():
+        cur = torch.cuda.current_stream(dz.device)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        ws = ops._wgrad_stream(dz.device)
+        ws.wait_event(ev)
+        with torch.cuda.stream(ws):
+            ops.conv_weight_unpack_add(ops.gemm_tn(dz, make_cols()), sink.view.view(weight.shape))
+        for t in keep:
+            t.record_stream(ws)
+        return None
     dW = torch.zeros_like(weight, dtype=torch.float32, memory_format=torch.contiguous_format)
-    ops.conv_weight_unpack_add(ops.gemm_tn(dz, cols), dW)
+    ops.conv_weight_unpack_add(ops.gemm_tn(dz, make_cols()), dW)
+    if sink is not None:
+        sink.view.view(weight.shape).add_(dW)
+        return None
     return dW
 
 
@@ -99,6 +116,7 @@ class _ConvBnFn(torch.autograd.Function):
         z, Ho, Wo = ops.conv_nhwc(x, w16, None, ops.ACT_NONE, n, H, W, C, kh, kw, stride, pad)
         y, mean, rstd = _bn_forward(z, bn, gamma, beta, identity, relu)
         ctx.geom, ctx.relu, ctx.has_id, ctx.out_hw = geom, relu, identity is not None, (Ho, Wo)
+        ctx.sink = ops._claim(weight, ctx.needs_input_grad[1])
         ctx.save_for_backward(x, weight, w16, z, y if relu else None, mean, rstd, gamma.detach())
         return y
 
@@ -111,9 +129,8 @@ class _ConvBnFn(torch.autograd.Function):
         Cout = weight.shape[0]
         dW = None
         if ctx.needs_input_grad[1]:
-            cols, _, _ = ops.im2col(x, n, H, W, C, kh, kw, stride, pad, x.dtype, ldcols=w16.shape[1])
-            dW = _weight_grad(dz, cols, weight)
-            del cols
+            dW = _weight_grad(dz, lambda: ops.im2col(x, n, H, W, C, kh, kw, stride, pad, x.dtype, ldcols=w16.shape[1])[0], weight, ctx.sink,
+                              (x, dz))
         dx = None
         if ctx.needs_input_grad[0]:
             if stride == 1 and 2 * pad == kh - 1 and kh == kw:
@@ -138,6 +155,7 @@ class _StemFn(torch.autograd.Function):
         del cols
         y, mean, rstd = _bn_forward(z, bn, gamma, beta, None, True)
         ctx.dt, ctx.Kp = dt, w16.shape[1]
+        ctx.sink = ops._claim(weight, ctx.needs_input_grad[1])
         ctx.save_for_backward(pix, weight, z, y, mean, rstd, gamma.detach())
         return y
 
@@ -147,8 +165,8 @@ class _StemFn(torch.autograd.Function):
         n, c, H, W = pix.shape
         kh, kw = weight.shape[2], weight.shape[3]
         dz, _, dgamma, dbeta = ops.bn_bwd(dy.contiguous(), y, z, mean, rstd, gamma, False)
-        cols, _, _ = ops.im2col(pix, n, H, W, c, kh, kw, 2, 3, ctx.dt, strides=(c * H * W, W, 1, H * W), ldcols=ctx.Kp)   # (recomputed: 1 GB at 256 frames)
-        return None, _weight_grad(dz, cols, weight), dgamma, dbeta, None, None
+        make_cols = lambda: ops.im2col(pix, n, H, W, c, kh, kw, 2, 3, ctx.dt, strides=(c * H * W, W, 1, H * W), ldcols=ctx.Kp)[0]   # (recomputed: 1 GB at 256 frames)
+        return None, _weight_grad(dz, make_cols, weight, ctx.sink, (pix, dz)), dgamma, dbeta, None, None
 
 
 class _MaxPoolFn(torch.autograd.Function):

@@ -335,3 +335,35 @@ def test_resnet_trainable_backbone_in_the_training_step():
     with torch.no_grad():
         s2, v2 = backbone(sk, vid)
     assert bool(torch.isfinite(v2.float()).all()) and bool(torch.isfinite(s2.float()).all())
+
+
+def test_resnet_weight_gradients_into_gradient_sinks():
+    """With BucketedGradAllReduce owning .grad, the convolutions' weight gradients are issued on the weight-gradient stream and added
+    straight into the bucket views (resnet.py::_weight_grad): the same numbers as the plain autograd path, after finish() joined the
+    side stream."""
+    from svol_amd import parallel
+    from svol_amd import synthetic as syn
+    from svol_amd.modeling.resnet import ResNetExtractor
+    sd = syn.synth_resnet_state_dict(syn.resnet_param_shapes((1, 2), (32, 64), 32), seed=1)
+    x = syn.synth_images(4, syn.vit_config(image_size=64), seed=5).to(DEV)
+    g = torch.Generator().manual_seed(3)
+
+    def run(sinks):
+        m = ResNetExtractor((1, 2), (32, 64), 32, compute_dtype='bf16', trainable=True)
+        m.load_state_dict(sd)
+        m.to(DEV).train()
+        red = None
+        if sinks:
+            red = parallel.BucketedGradAllReduce(list(reversed([p for p in m.parameters()])), ordered=True)
+            red.zero_grad()
+        out = m(x)
+        probe = torch.randn(out.shape, generator=torch.Generator().manual_seed(3)).to(DEV)
+        (out.float() * probe).sum().backward()
+        if red is not None:
+            red.finish()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    a, b = run(False), run(True)
+    for k in a:
+        err = float((a[k] - b[k]).norm() / max(float(a[k].norm()), 1e-12))
+        assert err <= 2e-3, (k, err)

@@ -33,6 +33,7 @@ python bench.py --dtype fp32 --steps 6 --warmup 2 --no-cpu-baseline > $O/round${
 python bench.py --workload cfg4 --steps 10 --warmup 3 --no-cpu-baseline > $O/round${RN}_bench_cfg4.json 2>> $O/bench.err
 python bench.py --workload encdec --steps 10 --warmup 3 --no-cpu-baseline > $O/round${RN}_bench_encdec.json 2>> $O/bench.err
 python bench.py --workload resnet --steps 10 --warmup 3 --no-cpu-baseline > $O/round${RN}_bench_resnet.json 2>> $O/bench.err
+python bench.py --workload resnet --train-backbone --steps 10 --warmup 3 --no-cpu-baseline > $O/round${RN}_bench_resnet_trained.json 2>> $O/bench.err
 python bench.py --workload encdec --dropout 0.1 --steps 10 --warmup 3 --no-cpu-baseline > $O/round${RN}_bench_encdec_dropout.json 2>> $O/bench.err
 SVOL_DETERMINISTIC=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/round${RN}_bench_deterministic.json 2>> $O/bench.err
 ls $O
