@@ -367,3 +367,55 @@ def test_resnet_weight_gradients_into_gradient_sinks():
     for k in a:
         err = float((a[k] - b[k]).norm() / max(float(a[k].norm()), 1e-12))
         assert err <= 2e-3, (k, err)
+
+
+def test_build_model_with_a_trained_backbone_and_checkpoint_round_trip(tmp_path):
+    """args.train_backbone = True through build_model (model.py:31-44 + the reference's train.py:72): the full ResNet-34 / ResNet-18
+    extractors in the parameter list, one training step with BucketedGradAllReduce + FlatAdamW (the bench's pair), every backbone
+    parameter moves; the state dict (BatchNorm running statistics and counters included) survives a save / load round trip bit for bit."""
+    from svol_amd import parallel
+    from svol_amd.modeling.loss import build_loss
+    from svol_amd.modeling.model import build_model
+    args = syn.head_args(hidden_dim=64, nheads=8, num_layers=1, num_queries=10, num_frames=2, backbone='resnet', input_dropout=0.0)
+    args.train_backbone = True
+    torch.manual_seed(1)
+    model = build_model(args)
+    model.backbone.video_backbone.load_state_dict(syn.synth_resnet_state_dict(syn.resnet_param_shapes((3, 4, 6, 3)), seed=1))
+    model.backbone.sketch_backbone.load_state_dict(syn.synth_resnet_state_dict(syn.resnet_param_shapes((2, 2, 2, 2)), seed=2))
+    model.to(DEV).train()
+    crit = build_loss(args).to(DEV).train()
+    n_bb = sum(1 for _ in model.backbone.parameters())
+    assert n_bb == 108 + 60 and all(p.requires_grad for p in model.backbone.parameters())   # 36 + 20 convolutions, 2 BatchNorm rows each
+    params = [p for p in model.parameters() if p.requires_grad]
+    red = parallel.BucketedGradAllReduce(parallel.arrival_order(model), skip=parallel.unused_parameters(model), ordered=True)
+    opt = parallel.FlatAdamW(red, lr=1e-3, weight_decay=1e-4, params=params)
+    B, T = 1, 2
+    vid = syn.synth_images(B * T, syn.vit_config(image_size=224), seed=4).view(B, T, 3, 224, 224).to(DEV)
+    sk = syn.synth_images(B, syn.vit_config(image_size=224), seed=5).view(B, 1, 3, 224, 224).to(DEV)
+    before = {k: v.detach().clone() for k, v in model.backbone.named_parameters()}
+    red.zero_grad()
+    out = model(sk, vid, torch.ones(B, 1, device=DEV), torch.ones(B, T, device=DEV))
+    crit(out, syn.synth_targets(B, T, seed=1))
+    loss = crit.weighted_total()
+    loss.backward()
+    red.finish()
+    opt.step()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(loss))
+    still = [k for k, p in model.backbone.named_parameters() if torch.equal(p.detach(), before[k])]
+    assert not still, f'{len(still)} backbone parameters did not move: {still[:5]}'
+    assert int(model.backbone.video_backbone.state_dict()['1.num_batches_tracked']) == 1
+    path = tmp_path / 'm.pt'
+    torch.save(model.state_dict(), path)
+    args2 = syn.head_args(hidden_dim=64, nheads=8, num_layers=1, num_queries=10, num_frames=2, backbone='resnet', input_dropout=0.0)
+    args2.train_backbone = True
+    m2 = build_model(args2)
+    m2.load_state_dict(torch.load(path, map_location='cpu'), strict=True)
+    m2.to(DEV)
+    sd1, sd2 = model.state_dict(), m2.state_dict()
+    assert list(sd1.keys()) == list(sd2.keys()) and all(torch.equal(sd1[k], sd2[k]) for k in sd1)
+    model.eval(); m2.eval()
+    with torch.no_grad():
+        o1 = model(sk, vid, torch.ones(B, 1, device=DEV), torch.ones(B, T, device=DEV))
+        o2 = m2(sk, vid, torch.ones(B, 1, device=DEV), torch.ones(B, T, device=DEV))
+    assert torch.equal(o1['pred_boxes'], o2['pred_boxes'])
