@@ -405,6 +405,12 @@ int svol_bn_finalize(const float* sum, const float* sumsq_centered, const float*
 int svol_conv_weight_pack(const float* w, void* out, int64_t Cout, int64_t Cin, int64_t kh, int64_t kw, int64_t Kp, int flip, int dtype,
                           void* stream);
 int svol_conv_weight_unpack_add(const float* dwp, float* grad, int64_t Cout, int64_t Cin, int64_t kh, int64_t kw, int64_t Kp, void* stream);
+/* The weight gradient of a convolution without the im2col matrix: dwp [Cout, Kp] (fp32, caller zeroes; the flip = 0 layout) +=
+ * dz[(n,oy,ox), co]^T * x[n, oy*stride-pad+ky, ox*stride-pad+kx, c] — the split-M weight-gradient GEMM gathers its second operand from the
+ * NHWC activation inside its LDS-DMA loads (zero outside the image).  C, Cout, Kp multiples of 8; SVOL_E_UNSUPPORTED otherwise (the
+ * caller then uses svol_im2col + svol_gemm_tn). */
+int svol_conv_wgrad_nhwc(const void* dz, const void* x, float* dwp, int64_t N, int64_t H, int64_t W, int64_t C, int64_t Cout, int64_t kh, int64_t kw,
+                         int64_t stride, int64_t pad, int64_t Kp, int dtype, void* stream);
 int svol_bn_apply(const void* z, const float* scale, const float* shift, const void* residual, int relu, void* y, int64_t M, int64_t C,
                   int dtype, void* stream);
 int svol_bn_bwd_reduce(const void* dy, const void* y, const void* z, const float* mean, const float* rstd, float* sum_g, float* sum_gx,

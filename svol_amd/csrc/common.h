@@ -38,6 +38,7 @@ typedef f16x2 h16x2;
 #define svol_gemm_nt_bf16_fast svol_gemm_nt_f16_fast
 #define svol_gemm_tn_bf16_fast svol_gemm_tn_f16_fast
 #define svol_gemm_tn_bf16_grouped svol_gemm_tn_f16_grouped
+#define svol_conv_wgrad_bf16_fast svol_conv_wgrad_f16_fast
 #define svol_gemm_ws_bf16 svol_gemm_ws_f16
 #define svol_gemm_n256_bf16 svol_gemm_n256_f16
 #define svol_mlp_chain_bf16 svol_mlp_chain_f16

@@ -28,6 +28,14 @@ struct TnFastArgs {
     int Mc, N, K, m_chunk, ktiles, splits;
 };
 
+// Implicit-GEMM weight gradient of a convolution (round 5, the trainable ResNet): B is not a matrix in memory but the im2col view of an NHWC
+// activation x [n, cH, cW, cC] — row m = output pixel (n, oy, ox), column k = (ky*ckw + kx)*cC + c reads x[n, oy*s - p + ky, ox*s - p + kx, c]
+// (zero outside the image and for k >= Kreal): the B half of a slab is gathered by the LDS-DMA loads themselves, the [M, kh*kw*C] matrix
+// (0.9 GB for a layer-1 convolution at 256 frames) never exists.
+struct TnConvGeom {
+    int cH, cW, cC, cHo, cWo, ckw, cstride, cpad, Kreal, x_bytes;
+};
+
 constexpr int CT = 32;            // rows per slab
 constexpr int STG = 4;            // ring slots
 constexpr int OPB = CT * 256;     // bytes per operand slab
@@ -41,7 +49,8 @@ __device__ __forceinline__ int phys(int row, int col) {
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__device__ __forceinline__ void tn_dma_body(const TnFastArgs& p, const int bid) {
+template <bool CONV = false>
+__device__ __forceinline__ void tn_dma_body(const TnFastArgs& p, const int bid, const TnConvGeom* gp = nullptr) {
     __shared__ __attribute__((aligned(1024))) char smem[STG * 2 * OPB];  // 64 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,8 +75,10 @@ __device__ __forceinline__ void tn_dma_body(const TnFastArgs& p, const int bid) 
     const int colsA = min(128, p.N - n0), colsB = min(128, p.K - k0);
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.A + (int64_t)m_begin * p.lda + n0), 0, (int)((((int64_t)rows - 1) * p.lda + colsA) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.B + (int64_t)m_begin * p.ldb + k0), 0, (int)((((int64_t)rows - 1) * p.ldb + colsB) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = CONV
+        ? __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, gp->x_bytes, 0x00020000)   // the whole activation tensor
+        : __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)m_begin * p.ldb + k0), 0, (int)((((int64_t)rows - 1) * p.ldb + colsB) * 2),
+                                            0x00020000);
     // DMA geometry: instruction i of an operand covers slab rows 4i..4i+3 (1 KiB); wave w issues i = 2w, 2w+1.
     // lane -> (row 4i + lane/16, physical 16-byte slot lane%16); the slot holds source chunk ((slot/2) ^ (row&7))*2 + slot%2
     int voffA[2], voffB[2];
@@ -79,6 +90,39 @@ __device__ __forceinline__ void tn_dma_body(const TnFastArgs& p, const int bid) 
         voffA[j] = (int)(((int64_t)r * p.lda + c * 8) * 2);
         voffB[j] = (int)(((int64_t)r * p.ldb + c * 8) * 2);
     }
+    // CONV: this lane's chunk of 8 columns is one tap (ky, kx) and 8 channels from ch0 (cC % 8 == 0: a chunk never straddles taps) —
+    // constants of the workgroup's column tile; its two rows' output pixels (n, oy, ox) advance by CT rows per slab (issue() is called
+    // with stage = 0, 1, 2, ... in order)
+    int cv_n[2] = {0, 0}, cv_oy[2] = {0, 0}, cv_ox[2] = {0, 0}, cv_m[2] = {0, 0};
+    if constexpr (CONV) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = (wave * 2 + j) * 4 + (lane >> 4);
+            const int m = m_begin + r;
+            cv_m[j] = m;
+            const int hw = gp->cHo * gp->cWo;
+            cv_n[j] = m / hw;
+            const int rem = m - cv_n[j] * hw;
+            cv_oy[j] = rem / gp->cWo;
+            cv_ox[j] = rem - cv_oy[j] * gp->cWo;
+        }
+    }
+    int cv_kyj[2] = {0, 0}, cv_kxj[2] = {0, 0}, cv_chj[2] = {0, 0};
+    bool cv_colj[2] = {false, false};
+    if constexpr (CONV) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {   // (the source chunk depends on the row through the XOR permutation: per instruction)
+            const int r = (wave * 2 + j) * 4 + (lane >> 4);
+            const int s = lane & 15;
+            const int c = ((((s >> 1) ^ (r & 7))) << 1) | (s & 1);
+            const int k = k0 + c * 8;
+            cv_colj[j] = k < gp->Kreal;
+            const int tap = k / gp->cC;
+            cv_chj[j] = k - tap * gp->cC;
+            cv_kyj[j] = tap / gp->ckw;
+            cv_kxj[j] = tap - cv_kyj[j] * gp->ckw;
+        }
+    }
     auto issue = [&](int slot, int stage) {
         char* sa = smem + slot * (2 * OPB);
         char* sb = sa + OPB;
@@ -86,7 +130,22 @@ __device__ __forceinline__ void tn_dma_body(const TnFastArgs& p, const int bid) 
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_ptr)(sa + (wave * 2 + j) * 1024), 16, voffA[j], soA, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_ptr)(sb + (wave * 2 + j) * 1024), 16, voffB[j], soB, 0, 0);
+            if constexpr (CONV) {
+                const int iy = cv_oy[j] * gp->cstride - gp->cpad + cv_kyj[j], ix = cv_ox[j] * gp->cstride - gp->cpad + cv_kxj[j];
+                const bool ok = cv_colj[j] && cv_m[j] < m_end && (unsigned)iy < (unsigned)gp->cH && (unsigned)ix < (unsigned)gp->cW;
+                // padding, rows past the chunk, padded columns: an offset past the buffer reads as zero (hardware bounds check)
+                const int off = ok ? (((cv_n[j] * gp->cH + iy) * gp->cW + ix) * gp->cC + cv_chj[j]) * 2 : 0x7ffffff0;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_ptr)(sb + (wave * 2 + j) * 1024), 16, off, 0, 0, 0);
+                // the next slab's pixel of this row: CT rows further
+                cv_m[j] += CT;
+                cv_ox[j] += CT;
+                while (cv_ox[j] >= gp->cWo) {
+                    cv_ox[j] -= gp->cWo;
+                    if (++cv_oy[j] == gp->cHo) { cv_oy[j] = 0; ++cv_n[j]; }
+                }
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_ptr)(sb + (wave * 2 + j) * 1024), 16, voffB[j], soB, 0, 0);
+            }
         }
     };
 
@@ -192,6 +251,8 @@ __device__ __forceinline__ void tn_dma_body(const TnFastArgs& p, const int bid) 
     }
 }
 __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_dma(TnFastArgs p) { tn_dma_body(p, (int)blockIdx.x); }
+struct TnConvArgs { TnFastArgs t; TnConvGeom g; };
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_conv(TnConvArgs p) { tn_dma_body<true>(p.t, (int)blockIdx.x, &p.g); }
 
 // Several weight gradients of one backward block in ONE launch (92 weight-gradient launches per step): the
 // problems ride in the kernel arguments, a workgroup finds its problem by a scan over at most SVOL_TN_GROUP_MAX prefix sums.
@@ -257,6 +318,21 @@ int svol_gemm_tn_bf16_grouped(const svol_tn_problem* pr, int n, hipStream_t s) {
     for (int i = n; i <= SVOL_TN_GROUP_MAX; ++i) g.begin[i] = (int)tot;
     if (tot > (1ll << 30)) return SVOL_E_UNSUPPORTED;
     hipLaunchKernelGGL(gemm_tn_bf16_dma_grouped, dim3((unsigned)tot), dim3(256), 0, s, g);
+    return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
+}
+
+// dWp[Cout, Kp] (fp32, caller zeroes) += dz[M, Cout]^T * im2col(x)[M, Kp] with the im2col view gathered in the kernel (TnConvGeom)
+int svol_conv_wgrad_bf16_fast(const void* dz, const void* x, float* dwp, int64_t N, int64_t H, int64_t W, int64_t C, int64_t Cout, int64_t kh,
+                              int64_t kw, int64_t stride, int64_t pad, int64_t Kp, hipStream_t stream) {
+    const int64_t Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return SVOL_E_INVALID;
+    const int64_t M = N * Ho * Wo, K = kh * kw * C;
+    if (C % 8 || Cout % 8 || Kp % 8 || Kp < K || M > (1ll << 30) || N * H * W * C * 2 >= (1ll << 31) - 64) return SVOL_E_UNSUPPORTED;
+    TnConvArgs a{};
+    int64_t wgs = 0;
+    if (!tn_plan(dz, Cout, x, 8, dwp, Kp, nullptr, M, Cout, Kp, a.t, wgs)) return SVOL_E_UNSUPPORTED;   // (ldb is not used by the gather)
+    a.g = TnConvGeom{(int)H, (int)W, (int)C, (int)Ho, (int)Wo, (int)kw, (int)stride, (int)pad, (int)K, (int)(N * H * W * C * 2)};
+    hipLaunchKernelGGL(gemm_tn_bf16_conv, dim3((unsigned)wgs), dim3(256), 0, stream, a);
     return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
 }
 

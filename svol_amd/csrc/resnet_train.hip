@@ -315,7 +315,21 @@ int64_t reduce_wgs(int64_t M, int64_t C, int64_t& rows_per_wg) {
 
 }  // namespace
 
+// gemm_tn_bf16.hip (compiled once per 16-bit type)
+int svol_conv_wgrad_bf16_fast(const void* dz, const void* x, float* dwp, int64_t N, int64_t H, int64_t W, int64_t C, int64_t Cout, int64_t kh,
+                              int64_t kw, int64_t stride, int64_t pad, int64_t Kp, hipStream_t stream);
+int svol_conv_wgrad_f16_fast(const void* dz, const void* x, float* dwp, int64_t N, int64_t H, int64_t W, int64_t C, int64_t Cout, int64_t kh,
+                             int64_t kw, int64_t stride, int64_t pad, int64_t Kp, hipStream_t stream);
+
 extern "C" {
+
+int svol_conv_wgrad_nhwc(const void* dz, const void* x, float* dwp, int64_t N, int64_t H, int64_t W, int64_t C, int64_t Cout, int64_t kh, int64_t kw,
+                         int64_t stride, int64_t pad, int64_t Kp, int dtype, void* stream) {
+    if (!dz || !x || !dwp || N <= 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0) return SVOL_E_INVALID;
+    if (!svol_is16(dtype)) return SVOL_E_UNSUPPORTED;
+    return (dtype == SVOL_BF16 ? svol_conv_wgrad_bf16_fast : svol_conv_wgrad_f16_fast)(dz, x, dwp, N, H, W, C, Cout, kh, kw, stride, pad, Kp,
+                                                                                       reinterpret_cast<hipStream_t>(stream));
+}
 
 int svol_bn_colstats(const void* z, const float* shift, float shift_scale, float* sum, float* sumsq, int64_t M, int64_t C, int dtype,
                      void* stream) {

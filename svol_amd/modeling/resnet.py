@@ -82,8 +82,9 @@ def _bn_forward(z, bn, gamma, beta, residual, relu):
     return ops.bn_apply(z, scale, shift, residual, relu), mean, rstd
 
 
-def _weight_grad(dz, make_cols, weight, sink, keep):
-    """dW of a convolution in the parameter's own layout: svol_gemm_tn(dz, im2col(x)) -> [Cout, Kp], folded back by one kernel.
+def _weight_grad(dz, make_dwp, weight, sink, keep):
+    """dW of a convolution in the parameter's own layout: make_dwp() -> dz^T im2col(x) as [Cout, Kp] fp32 (svol_conv_wgrad_nhwc: the im2col
+    view gathered inside the weight-gradient GEMM; the stem: svol_gemm_tn on its kept im2col matrix), folded back by one kernel.
     With a gradient sink (the parameter's .grad is a view of a BucketedGradAllReduce bucket) the three launches go to the
     weight-gradient stream (ops.py "weight gradients off the critical path": nobody needs dW before the optimiser; the dx chain behind
     it is the backward's critical path) and add straight into the bucket: returns None.  `keep`: tensors the side stream reads."""
@@ -94,12 +95,12 @@ def _weight_grad(dz, make_cols, weight, sink, keep):
         ws = ops._wgrad_stream(dz.device)
         ws.wait_event(ev)
         with torch.cuda.stream(ws):
-            ops.conv_weight_unpack_add(ops.gemm_tn(dz, make_cols()), sink.view.view(weight.shape))
+            ops.conv_weight_unpack_add(make_dwp(), sink.view.view(weight.shape))
         for t in keep:
             t.record_stream(ws)
         return None
     dW = torch.zeros_like(weight, dtype=torch.float32, memory_format=torch.contiguous_format)
-    ops.conv_weight_unpack_add(ops.gemm_tn(dz, make_cols()), dW)
+    ops.conv_weight_unpack_add(make_dwp(), dW)
     if sink is not None:
         sink.view.view(weight.shape).add_(dW)
         return None
@@ -129,8 +130,12 @@ class _ConvBnFn(torch.autograd.Function):
         Cout = weight.shape[0]
         dW = None
         if ctx.needs_input_grad[1]:
-            dW = _weight_grad(dz, lambda: ops.im2col(x, n, H, W, C, kh, kw, stride, pad, x.dtype, ldcols=w16.shape[1])[0], weight, ctx.sink,
-                              (x, dz))
+            def dwp():
+                d = ops.conv_wgrad_nhwc(dz, x, n, H, W, C, kh, kw, stride, pad, w16.shape[1])
+                if d is None:   # a shape the gathering kernel does not take: the explicit matrix
+                    d = ops.gemm_tn(dz, ops.im2col(x, n, H, W, C, kh, kw, stride, pad, x.dtype, ldcols=w16.shape[1])[0])
+                return d
+            dW = _weight_grad(dz, dwp, weight, ctx.sink, (x, dz))
         dx = None
         if ctx.needs_input_grad[0]:
             if stride == 1 and 2 * pad == kh - 1 and kh == kw:
@@ -163,7 +168,7 @@ class _StemFn(torch.autograd.Function):
     def backward(ctx, dy):
         cols, weight, z, y, mean, rstd, gamma = ctx.saved_tensors
         dz, _, dgamma, dbeta = ops.bn_bwd(dy.contiguous(), y, z, mean, rstd, gamma, False)
-        return None, _weight_grad(dz, lambda: cols, weight, ctx.sink, (cols, dz)), dgamma, dbeta, None, None
+        return None, _weight_grad(dz, lambda: ops.gemm_tn(dz, cols), weight, ctx.sink, (cols, dz)), dgamma, dbeta, None, None
 
 
 class _MaxPoolFn(torch.autograd.Function):

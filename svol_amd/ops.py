@@ -589,6 +589,17 @@ def conv_weight_pack(w, dtype, flip=False):
     return out
 
 
+def conv_wgrad_nhwc(dz, x, N, H, W, C, kh, kw, stride, pad, Kp):
+    """[Cout, Kp] fp32 = dz^T im2col(x) without the im2col matrix (svol_conv_wgrad_nhwc); None when the kernel does not take the shape."""
+    Cout = dz.shape[1]
+    dwp = torch.zeros((Cout, Kp), dtype=torch.float32, device=dz.device)
+    rc = _lib.lib().svol_conv_wgrad_nhwc(_ptr(dz), _ptr(x), _ptr(dwp), N, H, W, C, Cout, kh, kw, stride, pad, Kp, _dt(dz), _stream())
+    if rc == -2:
+        return None
+    _lib.check(rc, 'svol_conv_wgrad_nhwc')
+    return dwp
+
+
 def conv_weight_unpack_add(dwp, grad):
     """grad [Cout, Cin, kh, kw] (fp32, contiguous) += dwp [Cout, Kp] (fp32, (ky, kx, c) order)"""
     Cout, Cin, kh, kw = grad.shape

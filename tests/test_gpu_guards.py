@@ -320,3 +320,54 @@ def test_layernorm_and_gate_stay_inside_their_buffers(dtype):
         ar.check(f'LayerNorm / gate, B = {B}, L = {L}')
         for k_ in ('y32', 'y', 'ypos', 'mean', 'rstd', 'dx32', 'dx', 'dgamma', 'dbeta', 'colsum', 'gy32', 'gy', 'gypos', 'gdx32', 'du', 'gdgamma', 'gdbeta'):
             assert bool(torch.isfinite(t[k_].float()).all()), k_
+
+
+def test_resnet_training_kernels_stay_inside_their_buffers():
+    """csrc/resnet_train.hip + the gathering weight-gradient GEMM: column reductions with end-of-workgroup atomics, gather kernels with
+    computed pixel offsets, odd image sizes and row counts that do not divide by the workgroups' row chunks."""
+    from svol_amd import _lib, ops
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(41)
+    P = ops._ptr
+    dt = torch.bfloat16
+    for (n, H, W, C, Cout, k, s, p) in [(3, 9, 11, 16, 32, 3, 2, 1), (2, 15, 15, 64, 64, 3, 1, 1), (5, 7, 7, 128, 256, 1, 2, 0)]:
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        M, Mi = n * Ho * Wo, n * H * W
+        K = k * k * C
+        Kp = (K + 31) // 32 * 32
+        x = torch.randn((Mi, C), generator=g).to(dt).cuda()
+        z = torch.randn((M, Cout), generator=g).to(dt).cuda()
+        dy = torch.randn((M, Cout), generator=g).to(dt).cuda()
+        dcols = torch.randn((M, Kp), generator=g).to(dt).cuda()
+        gamma = torch.ones(Cout).cuda()
+        ar = GuardArena()
+        ar.plan('stats', (8, Cout), torch.float32)
+        ar.plan('y', (M, Cout), dt)
+        ar.plan('sums', (2, Cout), torch.float32)
+        ar.plan('dz', (M, Cout), dt)
+        ar.plan('dres', (M, Cout), dt)
+        ar.plan('dx', (Mi, C), dt)
+        ar.plan('dwp', (Cout, Kp), torch.float32)
+        ar.plan('pool', (M, C), dt)
+        ar.plan('idx', (M, C), torch.uint8)
+        ar.plan('dpool', (Mi, C), dt)
+        t = ar.build()
+        for nm in ('stats', 'sums', 'dwp'):
+            t[nm].zero_()
+        st, d_, s_ = t['stats'], ops._dt(x), ops._stream()
+        _lib.check(lib.svol_bn_colstats(P(z), None, 0.0, P(st[0]), P(st[1]), M, Cout, d_, s_), 'colstats')
+        _lib.check(lib.svol_bn_colstats(P(z), P(st[0]), 1.0 / M, P(st[2]), P(st[3]), M, Cout, d_, s_), 'colstats')
+        _lib.check(lib.svol_bn_finalize(P(st[0]), P(st[3]), P(gamma), P(gamma), None, None, 0.1, 1e-5, M, Cout, P(st[4]), P(st[5]), P(st[6]), P(st[7]), s_), 'finalize')
+        _lib.check(lib.svol_bn_apply(P(z), P(st[6]), P(st[7]), P(dy), 1, P(t['y']), M, Cout, d_, s_), 'apply')
+        _lib.check(lib.svol_bn_bwd_reduce(P(dy), P(t['y']), P(z), P(st[4]), P(st[5]), P(t['sums'][0]), P(t['sums'][1]), M, Cout, d_, s_), 'bwd_reduce')
+        _lib.check(lib.svol_bn_bwd_apply(P(dy), P(t['y']), P(z), P(st[4]), P(st[5]), P(gamma), P(t['sums'][0]), P(t['sums'][1]), P(t['dz']), P(t['dres']), M,
+                                         Cout, d_, s_), 'bwd_apply')
+        _lib.check(lib.svol_col2im_nhwc(P(dcols), Kp, P(t['dx']), n, H, W, C, k, k, s, p, d_, s_), 'col2im')
+        _lib.check(lib.svol_conv_wgrad_nhwc(P(t['dz']), P(x), P(t['dwp']), n, H, W, C, Cout, k, k, s, p, Kp, d_, s_), 'conv_wgrad')
+        if k == 3:
+            _lib.check(lib.svol_maxpool_idx_nhwc(P(x), P(t['pool']), P(t['idx']), n, H, W, C, k, s, p, d_, s_), 'maxpool')
+            _lib.check(lib.svol_maxpool_bwd_nhwc(P(t['pool']), P(t['idx']), P(t['dpool']), n, H, W, C, k, s, p, d_, s_), 'maxpool_bwd')
+        torch.cuda.synchronize()
+        ar.check(f'resnet training kernels {(n, H, W, C, Cout, k, s, p)}')
+        for nm in ('y', 'dz', 'dres', 'dx', 'dwp') + (('pool', 'dpool') if k == 3 else ()):
+            assert bool(torch.isfinite(t[nm].float()).all()), nm

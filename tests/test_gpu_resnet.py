@@ -234,7 +234,8 @@ def test_resnet_training_kernels():
     g = torch.Generator().manual_seed(0)
     dt = torch.bfloat16
     res = {}
-    for (n, H, W, C, Cout, k, s, p) in [(3, 8, 8, 16, 32, 3, 2, 1), (2, 16, 16, 32, 32, 3, 1, 1), (2, 8, 8, 64, 128, 1, 2, 0), (2, 14, 14, 64, 64, 3, 1, 1)]:
+    for (n, H, W, C, Cout, k, s, p) in [(3, 8, 8, 16, 32, 3, 2, 1), (2, 16, 16, 32, 32, 3, 1, 1), (2, 8, 8, 64, 128, 1, 2, 0), (2, 14, 14, 64, 64, 3, 1, 1),
+                                       (5, 28, 28, 128, 256, 3, 2, 1), (3, 7, 7, 512, 512, 3, 1, 1), (9, 56, 56, 64, 64, 3, 1, 1)]:
         tag = f'{n}x{H}x{W}x{C}->{Cout} k{k}s{s}'
         x = torch.randn(n, C, H, W, generator=g)
         w = torch.randn(Cout, C, k, k, generator=g) * 0.1
@@ -272,6 +273,10 @@ def test_resnet_training_kernels():
         cols, _, _ = ops.im2col(x16, n, H, W, C, k, k, s, p, dt, ldcols=w16.shape[1])
         dW = ops.gemm_tn(dz, cols)[:, :k * k * C].reshape(Cout, k, k, C).permute(0, 3, 1, 2)
         res[tag + ' dW'] = (rel(dW, wr.grad), 1e-5)
+        dwg = ops.conv_wgrad_nhwc(dz, x16, n, H, W, C, k, k, s, p, w16.shape[1])
+        assert dwg is not None
+        res[tag + ' dW (gathered in the GEMM)'] = (rel(dwg[:, :k * k * C].reshape(Cout, k, k, C).permute(0, 3, 1, 2), wr.grad), 1e-5)
+        assert float(dwg[:, k * k * C:].abs().max()) == 0.0 if w16.shape[1] > k * k * C else True
         w32 = wr.detach().float().to(DEV).contiguous()
         res[tag + ' weight pack'] = (rel(ops.conv_weight_pack(w32, dt), w16), 0.0)
         acc = torch.ones_like(w32)
