@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_dma_grouped(TnGroupArgs g
 
 // split plan of one problem (shared by the single and the grouped launcher); false = the shape does not qualify
 bool tn_plan(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum, int64_t Mc, int64_t N,
-             int64_t K, TnFastArgs& out, int64_t& wgs) {
+             int64_t K, TnFastArgs& out, int64_t& wgs, int wgs_override = 0) {
     if (N % 8 || K % 8 || lda % 8 || ldb % 8 || !aligned16(A) || !aligned16(B)) return false;
     if (Mc < 1 || Mc > (1 << 30) || N > (1 << 30) || K > (1 << 30)) return false;
     const int64_t tiles = ((N + 127) / 128) * ((K + 127) / 128);
@@ -283,7 +283,7 @@ bool tn_plan(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, i
     // than 8 output tiles) override.
     static const int force_wgs = getenv("SVOL_TN_WGS") ? atoi(getenv("SVOL_TN_WGS")) : 0;
     static const int force_wgs2 = getenv("SVOL_TN_WGS2") ? atoi(getenv("SVOL_TN_WGS2")) : force_wgs;
-    const int target_wgs = tiles <= 8 ? (force_wgs ? force_wgs : 128) : (force_wgs2 ? force_wgs2 : 128);
+    const int target_wgs = wgs_override ? wgs_override : (tiles <= 8 ? (force_wgs ? force_wgs : 128) : (force_wgs2 ? force_wgs2 : 128));
     int64_t want = (target_wgs + tiles - 1) / tiles;
     if (want > 8) want = want / 8 * 8;
     if (svol_deterministic()) want = 1;   // no contraction split: one adder per output element
@@ -330,7 +330,10 @@ int svol_conv_wgrad_bf16_fast(const void* dz, const void* x, float* dwp, int64_t
     if (C % 8 || Cout % 8 || Kp % 8 || Kp < K || M > (1ll << 30) || N * H * W * C * 2 >= (1ll << 31) - 64) return SVOL_E_UNSUPPORTED;
     TnConvArgs a{};
     int64_t wgs = 0;
-    if (!tn_plan(dz, Cout, x, 8, dwp, Kp, nullptr, M, Cout, Kp, a.t, wgs)) return SVOL_E_UNSUPPORTED;   // (ldb is not used by the gather)
+    // the convolutions' weight gradients are most of the backbone's backward, not a side dish beside an attention kernel: fill the chip
+    // (SVOL_CONV_WGRAD_WGS: lab override; measured in profiles/round5_resnet_train_kernel_stats.txt)
+    static const int conv_wgs = getenv("SVOL_CONV_WGRAD_WGS") ? atoi(getenv("SVOL_CONV_WGRAD_WGS")) : 256;   // 128 -> 34.2, 256 -> 29.6, 512 -> 29.9, 1024 -> 30.6 ms per step
+    if (!tn_plan(dz, Cout, x, 8, dwp, Kp, nullptr, M, Cout, Kp, a.t, wgs, conv_wgs)) return SVOL_E_UNSUPPORTED;   // (ldb is not used by the gather)
     a.g = TnConvGeom{(int)H, (int)W, (int)C, (int)Ho, (int)Wo, (int)kw, (int)stride, (int)pad, (int)K, (int)(N * H * W * C * 2)};
     hipLaunchKernelGGL(gemm_tn_bf16_conv, dim3((unsigned)wgs), dim3(256), 0, stream, a);
     return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
