@@ -36,4 +36,7 @@ python bench.py --workload resnet --steps 10 --warmup 3 --no-cpu-baseline > $O/r
 python bench.py --workload resnet --train-backbone --steps 10 --warmup 3 --no-cpu-baseline > $O/round${RN}_bench_resnet_trained.json 2>> $O/bench.err
 python bench.py --workload encdec --dropout 0.1 --steps 10 --warmup 3 --no-cpu-baseline > $O/round${RN}_bench_encdec_dropout.json 2>> $O/bench.err
 SVOL_DETERMINISTIC=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/round${RN}_bench_deterministic.json 2>> $O/bench.err
+echo "== trained-backbone step: kernel statistics"
+bash tools/prof_resnet_train.sh > $O/prof_resnet_train.log 2>&1
+cp gpurun_out/prof_rn/kernel_stats.txt $O/round${RN}_resnet_train_kernel_stats.txt
 ls $O
