@@ -205,3 +205,29 @@ def test_hand_placed_forward_keeps_its_hazard_distances(tmp_path, flag):
     assert int(re.search(r'\.vgpr_spill_count:\s*(\d+)', k).group(1)) == 0
     body = '\n'.join(lines)
     assert 'v_pk_add_f32' not in body and 'v_pk_mul_f32' not in body   # a packed fp32 instruction does not overlap an MFMA
+
+
+@pytest.mark.parametrize('flag', [[], ['-DSVOL_H16_FP16']], ids=['bf16', 'fp16'])
+def test_no_attention_kernel_spills(tmp_path, flag):
+    """VERDICT r4 "What's weak 8": attn_bwd_dq_bf16_rot / _pre_masked compiled to 256 VGPRs with 12 - 16 bytes of scratch per lane (the
+    64-bit row indices of the epilogue and a block coordinate left in a vector register by block_coords' divisions, carried across the
+    key loop).  Every kernel of attention_bf16.hip, both 16-bit types: no scratch, no spilled VGPRs."""
+    hipcc = _hipcc()
+    if hipcc is None:
+        pytest.skip('hipcc not found')
+    from svol_amd import build
+    out = str(tmp_path / 'attention.s')
+    cmd = [hipcc] + build.COMMON + build.PER_FILE.get('attention_bf16.hip', []) + flag + ['--cuda-device-only', '-S', SRC, '-o', out]
+    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+    meta = open(out).read()
+    meta = meta[meta.index('amdhsa.kernels'):]
+    kernels = meta.split('  - .agpr_count:')[1:]
+    assert len(kernels) >= 20
+    bad = {}
+    for k in kernels:
+        name = re.search(r'\.name:\s*(\S+)', k).group(1)
+        spill = int(re.search(r'\.vgpr_spill_count:\s*(\d+)', k).group(1))
+        scratch = int(re.search(r'\.private_segment_fixed_size:\s*(\d+)', k).group(1))
+        if spill or scratch:
+            bad[name] = (spill, scratch)
+    assert not bad, bad
