@@ -124,18 +124,6 @@ int svol_gemm_nt_dact(const void* A, int64_t lda, const void* B, int64_t ldb, vo
                       const void* aux, int64_t ldaux, int act, float* colsum, int64_t M, int64_t N, int64_t K,
                       int dtype, void* stream);
 
-/* Two chained svol_gemm_nt products through the MLP's hidden layer in ONE launch; the [M, F] intermediate is written once and never read
- * back (the reference's MLP is nn.Linear -> GELU -> nn.Linear, cross_modal_transformer.py:142-143 via lib/modeling/model.py MLP):
- *   T = X Wa^T           X [M, D] (ldx), Wa [F, D] and Wb [D, F] dense, 16-bit dtype
- *   mode 0 (forward):    hid = gelu(T + ba), aux_out = gelu'(T + ba) (both [M, F] 16-bit, ldh / ldaux),
- *                        Y (fp32, ldy) = hid Wb^T + bb + res32 (ldr)            == svol_gemm_nt(SVOL_ACT_GELU_D) + svol_gemm_nt(res)
- *   mode 1 (backward):   hid = T * aux_in ([M, F], ldaux), Y (16-bit, ldy) = hid Wb^T   == svol_gemm_nt_dact(SVOL_ACT_GELU_D) + svol_gemm_nt
- *                        (WITHOUT the column sums of hid: take the bias gradient from svol_gemm_tn's colsum)
- * SVOL_E_UNSUPPORTED for D != 256, F % 32, F > 12288 (mode 0 keeps ba in LDS), fp32, unaligned operands: the caller then issues the two
- * products. */
-int svol_mlp_chain(const void* X, int64_t ldx, const void* Wa, const void* Wb, void* hid, int64_t ldh, const void* aux_in, void* aux_out,
-                   int64_t ldaux, void* Y, int64_t ldy, const float* ba, const float* bb, const float* res32, int64_t ldr, int mode,
-                   int64_t M, int64_t D, int64_t F, int dtype, void* stream);
 /* dW[N,K] (fp32, ld = ldc) (+)= A[Mc,N]^T * B[Mc,K]   (contraction over the Mc rows; weight gradient).
  * The output is accumulated with fp32 atomics: the caller zeroes C first unless it wants accumulation.
  * colsum (fp32 [N], may be NULL, caller zeroes) += column sums of A — the bias gradient, computed on the

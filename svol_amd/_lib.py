@@ -30,7 +30,6 @@ SIGNATURES = {
                      _int, _p],
     'svol_gemm_nt_dgelu': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p],
     'svol_gemm_nt_dact': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _int, _p, _i64, _i64, _i64, _int, _p],
-    'svol_mlp_chain': [_p, _i64, _p, _p, _p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i32, _i64, _i64, _i64, _i32, _p],
     'svol_gemm_tn': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _int, _p],
     'svol_gemm_tn_grouped': [_p, _i32, _int, _p],
     'svol_colsum': [_p, _i64, _p, _i64, _i64, _int, _p],

@@ -97,7 +97,6 @@ const char* const kQcNames = SVOL_QC_SLOTS(SLOT_NAME);
 
 // the video half's MLP saves gelu' instead of the pre-activation (SVOL_VH_GELU_PRE=1: round 2's form, for A/B runs)
 const int kVhGelu = getenv("SVOL_VH_GELU_PRE") ? SVOL_ACT_GELU : SVOL_ACT_GELU_D;
-constexpr int kChainFwdDefault = 0, kChainBwdDefault = 0;   // (same-box A/B, profiles/round4_mlp_chain_lab.md: 19.0-19.07 against 19.08-19.13 ms with the backward chain, 19.3 with both)
 
 inline void record(void* ev, void* stream) {
     if (ev) (void)hipEventRecord(static_cast<hipEvent_t>(ev), static_cast<hipStream_t>(stream));
@@ -105,26 +104,6 @@ inline void record(void* ev, void* stream) {
 
 }  // namespace
 
-// The video half's MLP as ONE launch per direction (svol_mlp_chain) where the kernel takes the shape.  mode 0: forward, 1: backward.
-// The backward program and the weight-gradient program ask the same question with the same operands: with the chain, b_fc1's
-// gradient is the column sum of DPRE taken by the weight-gradient launch instead of the dact epilogue.
-int svol_mlp_chain_ok(const void* X, int64_t ldx, const void* Wa, const void* Wb, void* hid, int64_t ldh, const void* aux_in, void* aux_out,
-                      int64_t ldaux, void* Y, int64_t ldy, const float* ba, const float* bb, const float* res32, int64_t ldr, int mode,
-                      int64_t M, int64_t D, int64_t F, int dtype);
-#define P(n) p[SVOL_VH_##n]
-static bool vh_chain(int mode, const Dims& d, void* const* p) {
-    static const int fwd = getenv("SVOL_MLP_CHAIN_FWD") ? atoi(getenv("SVOL_MLP_CHAIN_FWD")) : kChainFwdDefault;
-    static const int bwd = getenv("SVOL_MLP_CHAIN_BWD") ? atoi(getenv("SVOL_MLP_CHAIN_BWD")) : kChainBwdDefault;
-    if (!(mode ? bwd : fwd) || kVhGelu != SVOL_ACT_GELU_D) return false;
-    const int64_t M = d.B * d.L, D = d.D, F = d.F;
-    if (M < 4096) return false;   // (a workgroup takes 256 rows: small problems do not fill the chip)
-    if (mode == 0)
-        return svol_mlp_chain_ok(P(Y2), D, P(W_FC1), P(W_FC2), P(HID), F, nullptr, P(PRE), F, P(S3), D, f32(P(B_FC1)), f32(P(B_FC2)),
-                                 f32(P(Y2_32)), D, 0, M, D, F, d.dt) == SVOL_OK;
-    return svol_mlp_chain_ok(P(DS3), D, P(W_FC2_T), P(W_FC1_T), P(DPRE), F, P(PRE), nullptr, F, P(DY2), D, nullptr, nullptr, nullptr, 0, 1, M,
-                             D, F, d.dt) == SVOL_OK;
-}
-#undef P
 
 extern "C" {
 
@@ -224,14 +203,10 @@ int svol_video_half_fwd(const int64_t* dims, void* const* p, void* s) {
                            D, 0.f, 0, nullptr, dt, s));
     // MLP1 + residual -> LN3 (+pos) (:142-143)
     // (PRE holds gelu'(pre-activation): SVOL_ACT_GELU_D — the backward's epilogue is then a multiply)
-    if (vh_chain(0, d, p)) {   // both products in one launch, HID / PRE written once and not read back
-        RUN(svol_mlp_chain(P(Y2), D, P(W_FC1), P(W_FC2), P(HID), F, nullptr, P(PRE), F, P(S3), D, f32(P(B_FC1)), f32(P(B_FC2)),
-                           f32(P(Y2_32)), D, 0, M, D, F, dt, s));
-    } else {
-        RUN(svol_gemm_nt(P(Y2), D, nullptr, 0, P(W_FC1), D, P(HID), F, f32(P(B_FC1)), nullptr, kVhGelu, P(PRE), F, nullptr, 0, 0, M, F,
-                         D, dt, s));
-        RUN(nt_res(P(HID), F, P(W_FC2), F, P(S3), P(B_FC2), P(Y2_32), M, D, F, dt, s));
-    }
+    // (the MLP as ONE launch per direction — round 4's svol_mlp_chain — measured +-0.05 ms in the step in two rounds and left the
+    // library in round 5: tools/micro/mlp_chain_bf16.hip, profiles/round4_mlp_chain_lab.md)
+    RUN(svol_gemm_nt(P(Y2), D, nullptr, 0, P(W_FC1), D, P(HID), F, f32(P(B_FC1)), nullptr, kVhGelu, P(PRE), F, nullptr, 0, 0, M, F, D, dt, s));
+    RUN(nt_res(P(HID), F, P(W_FC2), F, P(S3), P(B_FC2), P(Y2_32), M, D, F, dt, s));
     RUN(svol_layernorm_fwd(P(S3), xf, f32(P(G3)), f32(P(BT3)), f32(P(M32)), P(M), P(MPOS), P(POS), M, f32(P(MEAN3)), f32(P(RSTD3)), M, D,
                            0.f, 0, nullptr, dt, s));
     return SVOL_OK;
@@ -248,13 +223,8 @@ int svol_video_half_bwd(const int64_t* dims, void* const* p, int phase, void* s)
         // LN3' -> (ds32, ds), b_fc2' ; (ds W2) * gelu'(pre), b_fc1' ; dpre W1 -> dy2
         RUN(svol_layernorm_bwd(f32(P(DM32)), P(DM), P(DMPOS), P(S3), xf, f32(P(G3)), f32(P(MEAN3)), f32(P(RSTD3)), f32(P(DS32_3)), P(DS3),
                                f32(P(DG3)), f32(P(DBT3)), f32(P(DB_FC2)), M, D, 0.f, 0, nullptr, dt, s));
-        if (vh_chain(1, d, p)) {   // (b_fc1' then comes from the weight-gradient launch: column sums of DPRE)
-            RUN(svol_mlp_chain(P(DS3), D, P(W_FC2_T), P(W_FC1_T), P(DPRE), F, P(PRE), nullptr, F, P(DY2), D, nullptr, nullptr, nullptr, 0, 1,
-                               M, D, F, dt, s));
-        } else {
-            RUN(svol_gemm_nt_dact(P(DS3), D, P(W_FC2_T), D, P(DPRE), F, P(PRE), F, kVhGelu, f32(P(DB_FC1)), M, F, D, dt, s));
-            RUN(nt(P(DPRE), F, P(W_FC1_T), F, P(DY2), D, nullptr, nullptr, M, D, F, dt, s));
-        }
+        RUN(svol_gemm_nt_dact(P(DS3), D, P(W_FC2_T), D, P(DPRE), F, P(PRE), F, kVhGelu, f32(P(DB_FC1)), M, F, D, dt, s));
+        RUN(nt(P(DPRE), F, P(W_FC1_T), F, P(DY2), D, nullptr, nullptr, M, D, F, dt, s));
         // LN2' -> (ds32_2, g), b_o' ; do = g Wo
         RUN(svol_layernorm_bwd(f32(P(DS32_3)), P(DY2), nullptr, P(S2), xf, f32(P(G2)), f32(P(MEAN2)), f32(P(RSTD2)), f32(P(DS32_2)), P(G2D),
                                f32(P(DG2)), f32(P(DBT2)), f32(P(DB_O)), M, D, 0.f, 0, nullptr, dt, s));
@@ -287,7 +257,7 @@ int svol_video_half_wgrad_part(const int64_t* dims, void* const* p, int part, vo
     // phase 1 of the backward (part 1: they can run beside THIS layer's attention backward), the in_proj ones after phase 2 (part 2)
     const svol_tn_problem pr[5] = {
         {P(DS3), D, P(HID), F, f32(P(DW_FC2)), F, nullptr, M, D, F},
-        {P(DPRE), F, P(Y2), D, f32(P(DW_FC1)), D, vh_chain(1, d, p) ? f32(P(DB_FC1)) : nullptr, M, F, D},
+        {P(DPRE), F, P(Y2), D, f32(P(DW_FC1)), D, nullptr, M, F, D},
         {P(G2D), D, P(O), D, f32(P(DW_O)), D, nullptr, M, D, D},
         {P(DQKV), 3 * D, P(Y1POS), D, f32(P(DW_IN)), D, f32(P(DB_IN)), M, 2 * D, D},
         {at(P(DQKV), 2 * D, dt), 3 * D, P(Y1), D, f32(P(DW_IN)) + 2 * D * D, D, f32(P(DB_IN)) + 2 * D, M, D, D}};

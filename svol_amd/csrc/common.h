@@ -41,7 +41,6 @@ typedef f16x2 h16x2;
 #define svol_conv_wgrad_bf16_fast svol_conv_wgrad_f16_fast
 #define svol_gemm_ws_bf16 svol_gemm_ws_f16
 #define svol_gemm_n256_bf16 svol_gemm_n256_f16
-#define svol_mlp_chain_bf16 svol_mlp_chain_f16
 #define svol_attn_fwd_bf16_launch svol_attn_fwd_f16_launch
 #define svol_attn_bwd_bf16_launch svol_attn_bwd_f16_launch
 #define svol_attn_ws_floats_bf16 svol_attn_ws_floats_f16

@@ -646,32 +646,6 @@ static int tn_generic_plan(const void* A, int64_t lda, const void* B, int64_t ld
     return SVOL_OK;
 }
 
-int svol_mlp_chain_bf16(const void* X, int64_t ldx, const void* Wa, const void* Wb, void* hid, int64_t ldh, const void* aux_in,
-                        void* aux_out, int64_t lda, void* Y, int64_t ldy, const float* ba, const float* bb, const float* res, int64_t ldr,
-                        int mode, int64_t M, int64_t F, hipStream_t s, int dry);
-int svol_mlp_chain_f16(const void* X, int64_t ldx, const void* Wa, const void* Wb, void* hid, int64_t ldh, const void* aux_in,
-                       void* aux_out, int64_t lda, void* Y, int64_t ldy, const float* ba, const float* bb, const float* res, int64_t ldr,
-                       int mode, int64_t M, int64_t F, hipStream_t s, int dry);
-
-static int mlp_chain_impl(const void* X, int64_t ldx, const void* Wa, const void* Wb, void* hid, int64_t ldh, const void* aux_in,
-                          void* aux_out, int64_t ldaux, void* Y, int64_t ldy, const float* ba, const float* bb, const float* res32,
-                          int64_t ldr, int mode, int64_t M, int64_t D, int64_t F, int dtype, void* stream, int dry) {
-    if (!X || !Wa || !Wb || !hid || !Y || M < 0 || D <= 0 || F <= 0 || (mode != 0 && mode != 1)) return SVOL_E_INVALID;
-    if (mode == 0 ? (!aux_out || !ba || !bb || !res32) : !aux_in) return SVOL_E_INVALID;
-    if (!svol_is16(dtype) || D != 256) return SVOL_E_UNSUPPORTED;
-    if (M == 0) return SVOL_OK;
-    return (dtype == SVOL_BF16 ? svol_mlp_chain_bf16 : svol_mlp_chain_f16)(X, ldx, Wa, Wb, hid, ldh, aux_in, aux_out, ldaux, Y, ldy, ba, bb,
-                                                                          res32, ldr, mode, M, F, reinterpret_cast<hipStream_t>(stream),
-                                                                          dry);
-}
-// (internal, blocks.hip: would svol_mlp_chain take this call?  The backward program and its weight-gradient program must agree on
-// who produces the first layer's bias gradient)
-int svol_mlp_chain_ok(const void* X, int64_t ldx, const void* Wa, const void* Wb, void* hid, int64_t ldh, const void* aux_in, void* aux_out,
-                      int64_t ldaux, void* Y, int64_t ldy, const float* ba, const float* bb, const float* res32, int64_t ldr, int mode,
-                      int64_t M, int64_t D, int64_t F, int dtype) {
-    return mlp_chain_impl(X, ldx, Wa, Wb, hid, ldh, aux_in, aux_out, ldaux, Y, ldy, ba, bb, res32, ldr, mode, M, D, F, dtype, nullptr, 1);
-}
-
 extern "C" {
 
 int svol_abi_version(void) { return 4; }
@@ -749,11 +723,6 @@ int svol_gemm_nt_split(const void* A, int64_t lda, const void* W_hilo, int64_t l
                         SVOL_BF16, stream);
 }
 
-int svol_mlp_chain(const void* X, int64_t ldx, const void* Wa, const void* Wb, void* hid, int64_t ldh, const void* aux_in, void* aux_out,
-                   int64_t ldaux, void* Y, int64_t ldy, const float* ba, const float* bb, const float* res32, int64_t ldr, int mode,
-                   int64_t M, int64_t D, int64_t F, int dtype, void* stream) {
-    return mlp_chain_impl(X, ldx, Wa, Wb, hid, ldh, aux_in, aux_out, ldaux, Y, ldy, ba, bb, res32, ldr, mode, M, D, F, dtype, stream, 0);
-}
 int svol_gemm_nt_dact(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* aux,
                       int64_t ldaux, int act, float* colsum, int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
     if (!A || !B || !C || !aux || M < 0 || N < 0 || K <= 0) return SVOL_E_INVALID;

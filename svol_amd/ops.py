@@ -329,35 +329,6 @@ def gemm_nt_dact(A, B, aux, act, want_colsum=True, colsum_out=None):
     return out, cs
 
 
-def mlp_chain_fwd(X, Wa, ba, Wb, bb, res32):
-    """(hid, dpre, Y32) = svol_mlp_chain mode 0: hid = gelu(X Wa^T + ba), dpre = gelu'(X Wa^T + ba), Y32 = hid Wb^T + bb + res32
-    in ONE launch (X [M,256] 16-bit, Wa [F,256], Wb [256,F]).  Raises on shapes the kernel does not take."""
-    M, D = X.shape
-    F = Wa.shape[0]
-    assert Wa.is_contiguous() and Wb.is_contiguous() and Wb.shape == (D, F) and X.stride(1) == 1 and res32.dtype == torch.float32
-    hid = torch.empty((M, F), dtype=X.dtype, device=X.device)
-    dpre = torch.empty_like(hid)
-    Y = torch.empty((M, D), dtype=torch.float32, device=X.device)
-    rc = _lib.lib().svol_mlp_chain(_ptr(X), X.stride(0), _ptr(Wa), _ptr(Wb), _ptr(hid), F, None, _ptr(dpre), F, _ptr(Y), D, _ptr(ba),
-                                   _ptr(bb), _ptr(res32), res32.stride(0), 0, M, D, F, _dt(X), _stream())
-    _lib.check(rc, 'svol_mlp_chain')
-    return hid, dpre, Y
-
-
-def mlp_chain_bwd(dY, Wb_t, dpre, Wa_t):
-    """(dT, dX) = svol_mlp_chain mode 1: dT = (dY Wb_t^T) * dpre, dX = dT Wa_t^T in ONE launch (dY [M,256] 16-bit, Wb_t [F,256] = the
-    second layer's weight transposed, Wa_t [256,F] = the first layer's weight transposed).  No column sums (bias gradient: gemm_tn)."""
-    M, D = dY.shape
-    F = Wb_t.shape[0]
-    assert Wb_t.is_contiguous() and Wa_t.is_contiguous() and Wa_t.shape == (D, F) and dY.stride(1) == 1 and dpre.stride(1) == 1
-    dT = torch.empty((M, F), dtype=dY.dtype, device=dY.device)
-    dX = torch.empty((M, D), dtype=dY.dtype, device=dY.device)
-    rc = _lib.lib().svol_mlp_chain(_ptr(dY), dY.stride(0), _ptr(Wb_t), _ptr(Wa_t), _ptr(dT), F, _ptr(dpre), None, dpre.stride(0), _ptr(dX),
-                                   D, None, None, None, 0, 1, M, D, F, _dt(dY), _stream())
-    _lib.check(rc, 'svol_mlp_chain')
-    return dT, dX
-
-
 def gemm_nt_dgelu(A, B, pre, want_colsum=True, colsum_out=None):
     return gemm_nt_dact(A, B, pre, ACT_GELU, want_colsum, colsum_out)
 

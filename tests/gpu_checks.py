@@ -271,70 +271,6 @@ def check_attn_weights():
     return res
 
 
-def check_mlp_chain():
-    """svol_mlp_chain (both products of the MLP in one launch) against fp64 on the same 16-bit operands: the hidden tensors to the
-    rounding of their type, the second product against the hidden tensor the kernel itself wrote (what the two-launch form reads back)."""
-    import math
-    res = {}
-    for dt in DTYPES16[1:]:
-        eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
-        for (M, F) in [(256, 64), (1000, 512), (4352, 2048)]:
-            X = _rnd((M, 256), dt, 1, 1.0)
-            Wa, Wb = _rnd((F, 256), dt, 2, 1.0 / 16), _rnd((256, F), dt, 3, 1.0 / math.sqrt(F))
-            ba, bb = _rnd((F,), torch.float32, 4, 0.5), _rnd((256,), torch.float32, 5, 0.5)
-            r32 = _rnd((M, 256), torch.float32, 6, 1.0)
-            hid, dpre, Y = ops.mlp_chain_fwd(X.to(DEV), Wa.to(DEV), ba.to(DEV), Wb.to(DEV), bb.to(DEV), r32.to(DEV))
-            T = X.double() @ Wa.double().t() + ba.double()
-            Phi = 0.5 * (1 + torch.erf(T / math.sqrt(2)))
-            g = T * Phi
-            dg = Phi + T * torch.exp(-0.5 * T * T) / math.sqrt(2 * math.pi)
-            tag = f'mlp_chain/{dt}/M{M}F{F}'
-            res[tag + '/fwd/hid'] = (float(((hid.cpu().double() - g).abs() / (g.abs() + 1e-2)).max()), 1.2 * eps)
-            res[tag + '/fwd/dpre'] = (float(((dpre.cpu().double() - dg).abs() / (dg.abs() + 1e-2)).max()), 1.2 * eps)
-            Yr = hid.cpu().double() @ Wb.double().t() + bb.double() + r32.double()
-            res[tag + '/fwd/Y'] = (rel_err(Y, Yr), 2e-6)
-            dY = _rnd((M, 256), dt, 7, 1.0)
-            Wbt, Wat = Wb.t().contiguous(), Wa.t().contiguous()   # [F,256], [256,F]
-            dT, dX = ops.mlp_chain_bwd(dY.to(DEV), Wbt.to(DEV), dpre, Wat.to(DEV))
-            dTr = (dY.double() @ Wbt.double().t()) * dpre.cpu().double()
-            res[tag + '/bwd/dT'] = (float(((dT.cpu().double() - dTr).abs() / (dTr.abs() + 1e-2)).max()), 1.2 * eps)
-            dXr = dT.cpu().double() @ Wat.double().t()
-            res[tag + '/bwd/dX'] = (float((dX.cpu().double() - dXr).abs().max() / dXr.abs().max()), 1.2 * eps)
-    return res
-
-
-def dropout_keep_numpy(shape, p, seed):
-    """numpy twin of the device keep mask (svol_amd/csrc/common.h: drop_seed32 / drop_row / drop_scale_rk) over a tensor viewed as
-    [-1, shape[-1]]: True where the element is kept."""
-    import numpy as np
-    M64 = (1 << 64) - 1
-
-    def hash_u64(x):
-        x &= M64
-        x ^= x >> 33
-        x = (x * 0xff51afd7ed558ccd) & M64
-        x ^= x >> 33
-        x = (x * 0xc4ceb9fe1a85ec53) & M64
-        x ^= x >> 33
-        return x & 0xffffffff
-    s0 = hash_u64((int(seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & M64)
-    n = int(np.prod(shape))
-    L = int(shape[-1])
-    i = np.arange(n, dtype=np.uint64)
-    r, k = i // np.uint64(L), i % np.uint64(L)
-    m32 = np.uint64(0xffffffff)
-    x = (np.uint64(s0) ^ (((r & m32) * np.uint64(0x9E3779B1)) & m32) ^ (((r >> np.uint64(32)) * np.uint64(0x7F4A7C15)) & m32)
-         ^ (((k >> np.uint64(1)) * np.uint64(0x85EBCA6B)) & m32)) & m32
-    x ^= x >> np.uint64(16)
-    x = (x * np.uint64(0x7FEB352D)) & m32
-    x ^= x >> np.uint64(15)
-    x = (x * np.uint64(0x846CA68B)) & m32
-    x ^= x >> np.uint64(16)
-    field = np.where((k & np.uint64(1)) == 1, x >> np.uint64(16), x & np.uint64(0xffff))   # 16 mask bits per column, a pair per call
-    thr = np.uint64(int(np.ceil(np.float32(p) * np.float32(65536.0))))
-    return (field >= thr).reshape(shape)
-
-
 def check_dropout_mask():
     """the stateless keep mask: svol_dropout over ones == the numpy twin, element for element (all dtypes); svol_dropout_add and the
     attention kernels' mask are the same function (the enc/dec tests replay it through the oracle); keep rate at 4M elements."""

@@ -50,10 +50,6 @@ def test_dropout_mask_matches_the_numpy_twin(G):
     _assert(G.check_dropout_mask())
 
 
-def test_mlp_chain(G):
-    _assert(G.check_mlp_chain())
-
-
 def test_gemm_tn(G):
     _assert(G.check_gemm_tn())
 
