@@ -271,6 +271,38 @@ def check_attn_weights():
     return res
 
 
+def dropout_keep_numpy(shape, p, seed):
+    """numpy twin of the device keep mask (svol_amd/csrc/common.h: drop_seed32 / drop_row / drop_scale_rk) over a tensor viewed as
+    [-1, shape[-1]]: True where the element is kept."""
+    import numpy as np
+    M64 = (1 << 64) - 1
+
+    def hash_u64(x):
+        x &= M64
+        x ^= x >> 33
+        x = (x * 0xff51afd7ed558ccd) & M64
+        x ^= x >> 33
+        x = (x * 0xc4ceb9fe1a85ec53) & M64
+        x ^= x >> 33
+        return x & 0xffffffff
+    s0 = hash_u64((int(seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & M64)
+    n = int(np.prod(shape))
+    L = int(shape[-1])
+    i = np.arange(n, dtype=np.uint64)
+    r, k = i // np.uint64(L), i % np.uint64(L)
+    m32 = np.uint64(0xffffffff)
+    x = (np.uint64(s0) ^ (((r & m32) * np.uint64(0x9E3779B1)) & m32) ^ (((r >> np.uint64(32)) * np.uint64(0x7F4A7C15)) & m32)
+         ^ (((k >> np.uint64(1)) * np.uint64(0x85EBCA6B)) & m32)) & m32
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & m32
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & m32
+    x ^= x >> np.uint64(16)
+    field = np.where((k & np.uint64(1)) == 1, x >> np.uint64(16), x & np.uint64(0xffff))   # 16 mask bits per column, a pair per call
+    thr = np.uint64(int(np.ceil(np.float32(p) * np.float32(65536.0))))
+    return (field >= thr).reshape(shape)
+
+
 def check_dropout_mask():
     """the stateless keep mask: svol_dropout over ones == the numpy twin, element for element (all dtypes); svol_dropout_add and the
     attention kernels' mask are the same function (the enc/dec tests replay it through the oracle); keep rate at 4M elements."""
