@@ -382,10 +382,12 @@ int svol_bn_colstats(const void* z, const float* shift, float shift_scale, float
                      void* stream);
 /* the [C]-sized step between the two column passes and svol_bn_apply, one launch: mean = sum / M, rstd = (sumsq_centered / M + eps)^-1/2,
  * scale = gamma * rstd, shift = beta - mean * scale, and nn.BatchNorm2d's running update (running_* may be NULL):
- * running_mean = (1 - momentum) running_mean + momentum mean, running_var likewise with the UNBIASED batch variance. */
-int svol_bn_finalize(const float* sum, const float* sumsq_centered, const float* gamma, const float* beta, float* running_mean,
-                     float* running_var, float momentum, float eps, int64_t M, int64_t C, float* mean, float* rstd, float* scale, float* shift,
-                     void* stream);
+ * running_mean = (1 - momentum) running_mean + momentum mean, running_var likewise with the UNBIASED batch variance.
+ * pivot (may be NULL): the sums were taken in ONE pass about a per-channel pivot s (svol_bn_colstats(z, s, 1.0, ...), s = any sample of
+ * the channel, e.g. the first row of z): then mean = s + sum / M and var = sumsq / M - (sum / M)^2. */
+int svol_bn_finalize(const float* sum, const float* sumsq_centered, const float* pivot, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, int64_t M, int64_t C, float* mean, float* rstd,
+                     float* scale, float* shift, void* stream);
 /* nn.Conv2d weights fp32 [Cout, Cin, kh, kw] -> the GEMMs' 16-bit layout: flip = 0: out [Cout, Kp], column (ky*kw + kx)*Cin + c, zero
  * beyond kh*kw*Cin; flip = 1 (the data gradient of a stride-1 convolution as a convolution of dz): out [Cin, Kp], column
  * (ky*kw + kx)*Cout + co = w[co, ci, kh-1-ky, kw-1-kx].  svol_conv_weight_unpack_add: grad [Cout, Cin, kh, kw] (fp32) += dWp [Cout, Kp]

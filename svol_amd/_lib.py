@@ -51,7 +51,7 @@ SIGNATURES = {
     'svol_maxpool_nhwc': [_p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p],
     'svol_avgpool_nhwc': [_p, _p, _i64, _i64, _i64, _int, _p],
     'svol_bn_colstats': [_p, _p, _f32, _p, _p, _i64, _i64, _int, _p],
-    'svol_bn_finalize': [_p, _p, _p, _p, _p, _p, _f32, _f32, _i64, _i64, _p, _p, _p, _p, _p],
+    'svol_bn_finalize': [_p, _p, _p, _p, _p, _p, _p, _f32, _f32, _i64, _i64, _p, _p, _p, _p, _p],
     'svol_conv_weight_pack': [_p, _p, _i64, _i64, _i64, _i64, _i64, _int, _int, _p],
     'svol_conv_weight_unpack_add': [_p, _p, _i64, _i64, _i64, _i64, _i64, _p],
     'svol_conv_wgrad_nhwc': [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p],

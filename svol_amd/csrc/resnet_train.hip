@@ -248,12 +248,18 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 // everything [C]-sized between the two column passes and the apply, in one launch: batch mean / rstd, the affine pair of svol_bn_apply,
 // nn.BatchNorm2d's running-statistics update (momentum m, UNBIASED variance)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq_c,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
-                                                          float* running_var, float momentum, float eps, float inv_m, float unbias, int C,
-                                                          float* mean, float* rstd, float* scale, float* shift) {
+                                                          const float* __restrict__ pivot, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* running_mean, float* running_var, float momentum,
+                                                          float eps, float inv_m, float unbias, int C, float* mean, float* rstd, float* scale,
+                                                          float* shift) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    const float mu = sum[c] * inv_m, var = sumsq_c[c] * inv_m;
+    // pivot == NULL: sum = sum z, sumsq_c = sum (z - mean)^2 (two passes).  pivot != NULL: ONE pass of sums about a per-channel pivot s
+    // (a sample of the channel: |mean - s| is a few standard deviations at most, so the subtraction below loses a few bits, not the
+    // variance): mean = s + sum / M, var = sumsq / M - (sum / M)^2
+    const float d = sum[c] * inv_m;
+    const float mu = pivot ? pivot[c] + d : d;
+    const float var = pivot ? fmaxf(sumsq_c[c] * inv_m - d * d, 0.f) : sumsq_c[c] * inv_m;
     const float rs = 1.0f / sqrtf(var + eps);
     const float sc = gamma[c] * rs;
     mean[c] = mu;
@@ -353,12 +359,12 @@ int svol_bn_colstats(const void* z, const float* shift, float shift_scale, float
     return SVOL_OK;
 }
 
-int svol_bn_finalize(const float* sum, const float* sumsq_centered, const float* gamma, const float* beta, float* running_mean,
-                     float* running_var, float momentum, float eps, int64_t M, int64_t C, float* mean, float* rstd, float* scale, float* shift,
-                     void* stream) {
+int svol_bn_finalize(const float* sum, const float* sumsq_centered, const float* pivot, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, int64_t M, int64_t C, float* mean, float* rstd,
+                     float* scale, float* shift, void* stream) {
     if (!sum || !sumsq_centered || !gamma || !beta || !mean || !rstd || !scale || !shift || M <= 0 || C <= 0) return SVOL_E_INVALID;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), sum,
-                       sumsq_centered, gamma, beta, running_mean, running_var, momentum, eps, 1.0f / (float)M,
+                       sumsq_centered, pivot, gamma, beta, running_mean, running_var, momentum, eps, 1.0f / (float)M,
                        M > 1 ? (float)M / (float)(M - 1) : 1.0f, (int)C, mean, rstd, scale, shift);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;

@@ -319,7 +319,7 @@ def test_resnet_training_kernels_stay_inside_their_buffers():
         st, d_, s_ = t['stats'], ops._dt(x), ops._stream()
         _lib.check(lib.svol_bn_colstats(P(z), None, 0.0, P(st[0]), P(st[1]), M, Cout, d_, s_), 'colstats')
         _lib.check(lib.svol_bn_colstats(P(z), P(st[0]), 1.0 / M, P(st[2]), P(st[3]), M, Cout, d_, s_), 'colstats')
-        _lib.check(lib.svol_bn_finalize(P(st[0]), P(st[3]), P(gamma), P(gamma), None, None, 0.1, 1e-5, M, Cout, P(st[4]), P(st[5]), P(st[6]), P(st[7]), s_), 'finalize')
+        _lib.check(lib.svol_bn_finalize(P(st[0]), P(st[3]), None, P(gamma), P(gamma), None, None, 0.1, 1e-5, M, Cout, P(st[4]), P(st[5]), P(st[6]), P(st[7]), s_), 'finalize')
         _lib.check(lib.svol_bn_apply(P(z), P(st[6]), P(st[7]), P(dy), 1, P(t['y']), M, Cout, d_, s_), 'apply')
         _lib.check(lib.svol_bn_bwd_reduce(P(dy), P(t['y']), P(z), P(st[4]), P(st[5]), P(t['sums'][0]), P(t['sums'][1]), M, Cout, d_, s_), 'bwd_reduce')
         _lib.check(lib.svol_bn_bwd_apply(P(dy), P(t['y']), P(z), P(st[4]), P(st[5]), P(gamma), P(t['sums'][0]), P(t['sums'][1]), P(t['dz']), P(t['dres']), M,

@@ -287,6 +287,11 @@ def test_resnet_training_kernels():
         if s == 1:
             dx2 = ops.conv_nhwc(dz, ops.conv_weight_pack(w32, dt, flip=True), None, ops.ACT_NONE, n, Ho, Wo, Cout, k, k, 1, p)[0]
             res[tag + ' dx (as a convolution of dz)'] = (rel(dx2.view(n, H, W, C).permute(0, 3, 1, 2), xr.grad), 5e-3)
+    # one-pass statistics about a pivot: channels whose mean is far from zero (60 standard deviations) must not lose their variance
+    zo = (torch.randn(70001, 64, generator=g) * 0.5 + torch.linspace(-30, 30, 64)).to(dt).to(DEV)
+    mean, rstd, _, _ = ops.bn_train_stats(zo, torch.ones(64, device=DEV), torch.zeros(64, device=DEV), None, None, 0.1, 1e-5)
+    res['offset channels mean'] = (rel(mean, zo.double().cpu().mean(0)), 1e-5)
+    res['offset channels rstd'] = (rel(rstd, 1.0 / torch.sqrt(zo.double().cpu().var(0, unbiased=False) + 1e-5)), 1e-4)
     n, H, W, C = 2, 9, 9, 16
     x16 = torch.relu(torch.randn(n, C, H, W, generator=g)).permute(0, 2, 3, 1).reshape(-1, C).to(dt).to(DEV).contiguous()
     xr = x16.double().cpu().view(n, H, W, C).permute(0, 3, 1, 2).requires_grad_(True)
