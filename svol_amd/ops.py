@@ -531,18 +531,31 @@ def avgpool_nhwc(x, N, HW, C):
 
 
 # ---- the backbone in training mode (csrc/resnet_train.hip) --------------------------------------------------------------
+BN_STATS_TWO_PASS = os.environ.get('SVOL_BN_TWO_PASS') is not None   # batch mean first, then the moment about it (tests: torch's own order)
+
+
 def bn_train_stats(z, gamma, beta, running_mean, running_var, momentum, eps):
     """train-mode nn.BatchNorm2d statistics of an NHWC activation z [M, C] (16-bit) in ONE pass over z: sums of (z - s) and (z - s)^2
     about a per-channel pivot s = the first row of z (a sample of the channel: the variance's subtraction loses a few bits, not the
-    variance — a plain sum z^2 would at |mean| >> std), then everything [C]-sized at once (svol_bn_finalize): -> fp32 [C] rows
-    (mean, rstd, scale = gamma * rstd, shift = beta - mean * scale); running_mean / running_var (may be None) are updated in place."""
+    variance — a plain sum z^2 would at |mean| >> std; measured against fp64: mean 1e-7 of a standard deviation, rstd 1e-6), then
+    everything [C]-sized at once (svol_bn_finalize): -> fp32 [C] rows (mean, rstd, scale = gamma * rstd, shift = beta - mean * scale);
+    running_mean / running_var (may be None) are updated in place.  BN_STATS_TWO_PASS (SVOL_BN_TWO_PASS=1): the batch mean first, then
+    the second moment about it — one more pass over z, statistics equal to torch's to the last bits (the end-to-end gradient test
+    compares with a torch network whose ReLU masks flip with the 7th digit of a statistic)."""
     M, C = z.shape
     buf = torch.zeros((7, C), dtype=torch.float32, device=z.device)
-    buf[6].copy_(z[0])
     L_ = _lib.lib()
     dt, s = _dt(z), _stream()
-    _lib.check(L_.svol_bn_colstats(_ptr(z), _ptr(buf[6]), 1.0, _ptr(buf[0]), _ptr(buf[1]), M, C, dt, s), 'svol_bn_colstats')
-    _lib.check(L_.svol_bn_finalize(_ptr(buf[0]), _ptr(buf[1]), _ptr(buf[6]), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+    if BN_STATS_TWO_PASS:
+        _lib.check(L_.svol_bn_colstats(_ptr(z), None, 0.0, _ptr(buf[0]), _ptr(buf[6]), M, C, dt, s), 'svol_bn_colstats')
+        buf[6].zero_()
+        _lib.check(L_.svol_bn_colstats(_ptr(z), _ptr(buf[0]), 1.0 / M, _ptr(buf[6]), _ptr(buf[1]), M, C, dt, s), 'svol_bn_colstats')
+        pivot = None
+    else:
+        buf[6].copy_(z[0])
+        _lib.check(L_.svol_bn_colstats(_ptr(z), _ptr(buf[6]), 1.0, _ptr(buf[0]), _ptr(buf[1]), M, C, dt, s), 'svol_bn_colstats')
+        pivot = buf[6]
+    _lib.check(L_.svol_bn_finalize(_ptr(buf[0]), _ptr(buf[1]), _ptr(pivot), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                    float(momentum), float(eps), M, C, _ptr(buf[2]), _ptr(buf[3]), _ptr(buf[4]), _ptr(buf[5]), s),
                'svol_bn_finalize')
     return buf[2], buf[3], buf[4], buf[5]

@@ -171,7 +171,8 @@ def _emulated_bf16_reference(sd, depths, x, probe_fmap, avg):
 
 @pytest.mark.parametrize('name', ['resnet_tiny_train', 'resnet_tiny3_train'])
 @pytest.mark.parametrize('avg', [False, True], ids=['tokens', 'pooled'])
-def test_resnet_training_mode_gradients(name, avg):
+@pytest.mark.parametrize('two_pass', [True, False], ids=['two-pass-stats', 'one-pass-stats'])
+def test_resnet_training_mode_gradients(name, avg, two_pass, monkeypatch):
     """ResNetExtractor(trainable=True).train(): batch-statistics BatchNorm forward, every parameter gradient and the running statistics
     — VERDICT r4 "Next round 8" (the reference optimises the backbone too: train.py:72, backbone.py:133-152).  Two references on the
     same weights, pixels and probe: (a) the fp64 oracle, itself pinned to transformers.ResNetModel.train() by the *_train fixtures:
@@ -180,8 +181,13 @@ def test_resnet_training_mode_gradients(name, avg):
     bf16 roundings (activations, their gradients, conv weights): gradients per tensor to a few per cent.  The kernels themselves are
     checked one by one against fp64 in test_resnet_training_kernels."""
     from oracle import resnet_oracle as R
+    from svol_amd import ops
     from svol_amd.modeling.resnet import ResNetExtractor
     from tests.test_oracle_resnet import resnet_case
+    # two_pass: the statistics in torch's own order (mean, then the moment about it), equal to the references' to the last bits — the
+    # tight bounds; the product's default (one pass about a pivot, 1e-6 from them) flips a few bf16 roundings and ReLU masks of these
+    # 32 ... 2048-sample normalisations: the loose bounds
+    monkeypatch.setattr(ops, 'BN_STATS_TWO_PASS', two_pass)
     z, meta, sd, x = resnet_case(name)
     depths = tuple(meta['depths'])
     g = torch.Generator().manual_seed(11)
@@ -217,7 +223,7 @@ def test_resnet_training_mode_gradients(name, avg):
     assert max(e64.values()) <= 0.6, {k: round(v, 3) for k, v in e64.items() if v > 0.6}
     med = sorted(eem.values())[len(eem) // 2]
     bad = {k: round(v, 4) for k, v in eem.items() if not v <= 0.2}
-    assert not bad and med <= (0.03 if name == 'resnet_tiny3_train' else 0.12), (bad, med)
+    assert not bad and med <= (0.03 if (name == 'resnet_tiny3_train' and two_pass) else 0.12), (bad, med)
 
 
 def test_resnet_training_kernels():
@@ -253,9 +259,9 @@ def test_resnet_training_kernels():
         mean, rstd, scale, shift = ops.bn_train_stats(z, gamma, beta, rm, rv, 0.1, 1e-5)
         zd = z.double().cpu()
         var_ref = zd.var(0, unbiased=False)
-        res[tag + ' mean'] = (rel(mean, zd.mean(0)), 1e-5)
+        res[tag + ' mean'] = (float(((mean.double().cpu() - zd.mean(0)).abs() / zd.std(0)).max()), 1e-6)   # (in standard deviations)
         res[tag + ' rstd'] = (rel(rstd, 1.0 / torch.sqrt(var_ref + 1e-5)), 1e-5)
-        res[tag + ' running_mean'] = (rel(rm, 0.1 * zd.mean(0)), 1e-5)
+        res[tag + ' running_mean'] = (float(((rm.double().cpu() - 0.1 * zd.mean(0)).abs() / zd.std(0)).max()), 1e-6)
         res[tag + ' running_var'] = (rel(rv, 0.9 + 0.1 * zd.var(0, unbiased=True)), 1e-5)
         idt = torch.randn(M, Cout, generator=g).to(dt).to(DEV)
         y = ops.bn_apply(z, scale, shift, idt, True)
