@@ -16,7 +16,8 @@ workload: BASELINE.json configs[1]  — B=8 videos per GPU, T=32 frames, P=196 t
           per-step fp32->bf16 weight refresh is inside the timed region too).  Launches are eager (host issue ~5-6 ms/step,
           hidden behind ~18 ms of GPU work: `host_issue_ms_per_step` in the line) at every N, so the N = 1 and N > 1 numbers are the same program; --graph
           replays the step as one hipGraph instead.  --workload selects the other measured configurations (cfg4: ViT
-          extractor online, cfg5: long video, encdec: enc/dec Transformer head, resnet: ResNet extractors online).
+          extractor online, cfg5: long video, encdec: enc/dec Transformer head, resnet: ResNet extractors online — frozen, or with
+          --train-backbone in training mode and in the optimiser as the reference's train.py has them).
 Prints ONE JSON line on rank 0.
 """
 import argparse
