@@ -66,7 +66,8 @@ def resnet_features_train(sd, depths, pixel_values, avgpool=False):
 
 def resnet_train_grads(sd, depths, pixel_values, probe, avgpool=False, dtype=torch.float64):
     """loss = sum(features * probe) in `dtype`: -> (features, {parameter key: gradient}, updated running statistics)."""
-    sdd = {k: (v.to(dtype).requires_grad_(v.is_floating_point() and 'running' not in k) if v.is_floating_point() else v) for k, v in sd.items()}
+    # (detach + clone: with dtype = the tensors' own, .to() would return the caller's tensors and requires_grad_ would mutate them)
+    sdd = {k: (v.detach().clone().to(dtype).requires_grad_('running' not in k) if v.is_floating_point() else v) for k, v in sd.items()}
     f, stats = resnet_features_train(sdd, depths, pixel_values.to(dtype), avgpool)
     (f * probe.to(dtype)).sum().backward()
     return f.detach(), {k: v.grad for k, v in sdd.items() if torch.is_tensor(v) and v.requires_grad}, stats

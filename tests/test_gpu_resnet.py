@@ -149,7 +149,7 @@ def _emulated_bf16_reference(sd, depths, x, probe_fmap, avg):
     weights): a reference whose ReLU masks and BatchNorm cancellations see bf16 activations like the product does."""
     import torch.nn.functional as F
     r = _RoundBf16.apply
-    P = {k: (v.to(DEV).float().requires_grad_('running' not in k) if v.is_floating_point() else v) for k, v in sd.items()}
+    P = {k: (v.detach().to(DEV).float().requires_grad_('running' not in k) if v.is_floating_point() else v) for k, v in sd.items()}
     w = lambda k: r(P[k])
 
     def bn(z, p):
@@ -435,3 +435,47 @@ def test_build_model_with_a_trained_backbone_and_checkpoint_round_trip(tmp_path)
         o1 = model(sk, vid, torch.ones(B, 1, device=DEV), torch.ones(B, T, device=DEV))
         o2 = m2(sk, vid, torch.ones(B, 1, device=DEV), torch.ones(B, T, device=DEV))
     assert torch.equal(o1['pred_boxes'], o2['pred_boxes'])
+
+
+@pytest.mark.parametrize('depths,name', [((2, 2, 2, 2), 'resnet18'), ((3, 4, 6, 3), 'resnet34')])
+def test_full_size_resnet_training_gradients(depths, name):
+    """The real networks at the real resolution (2 images of 224 x 224: BatchNorm over 25 088 ... 98 samples) in training mode: features,
+    running statistics and all 60 / 108 parameter gradients against the fp32 oracle on the CPU (the oracle's training mode is pinned to
+    transformers.ResNetModel.train() in fp64 by the *_train fixtures) AND against a torch evaluation with the product's bf16 roundings
+    on the GPU.  See the comment at the assertions for what can and cannot be concluded at this depth."""
+    from oracle import resnet_oracle as R
+    from svol_amd.modeling.resnet import ResNetExtractor
+    sd = syn.synth_resnet_state_dict(syn.resnet_param_shapes(depths), seed=1)
+    x = syn.synth_images(2, syn.vit_config(image_size=224), seed=7)
+    m = ResNetExtractor(depths, compute_dtype='bf16', trainable=True)
+    m.load_state_dict(sd)
+    m.to(DEV).train()
+    out = m(x.to(DEV))
+    probe = torch.randn(out.shape, generator=torch.Generator().manual_seed(5))
+    (out.float() * probe.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    probe_fmap = probe.transpose(1, 2).reshape(2, -1, 7, 7)
+    f, grads, stats = R.resnet_train_grads(sd, depths, x, probe_fmap, dtype=torch.float32)
+    ref_out = f.flatten(2).transpose(1, 2)
+    l2 = float((out.detach().float().cpu() - ref_out).norm() / ref_out.norm())
+    errs = {k: float((p.grad.float().cpu() - grads[k]).norm() / max(float(grads[k].norm()), 1e-20)) for k, p in m.named_parameters()}
+    fe, ge = _emulated_bf16_reference(sd, depths, x, probe_fmap, False)
+    assert not [k for k, v in ge.items() if v is None], [k for k, v in ge.items() if v is None][:8]
+    l2e = float((out.detach().float() - fe.flatten(2).transpose(1, 2)).norm() / fe.norm())
+    erre = {k: float((p.grad.float() - ge[k]).norm() / max(float(ge[k].norm()), 1e-20)) for k, p in m.named_parameters()}
+    eme = {k: float((ge[k].float().cpu() - grads[k]).norm() / max(float(grads[k].norm()), 1e-20)) for k in grads}
+    srt, srte, srtm = sorted(errs.values()), sorted(erre.values()), sorted(eme.values())
+    print(f'{name}: vs fp32 oracle: feature L2 {l2:.2e}, gradient L2 max {srt[-1]:.2e} median {srt[len(srt) // 2]:.2e}; '
+          f'vs the bf16-rounding reference: feature L2 {l2e:.2e}, gradient L2 max {srte[-1]:.2e} median {srte[len(srte) // 2]:.2e} (worst: {max(erre, key=erre.get)}); '
+          f'the bf16-rounding reference vs fp32: gradient L2 max {srtm[-1]:.2e} median {srtm[len(srtm) // 2]:.2e}')
+    for k, v in stats.items():
+        have = dict(m.named_buffers())[k].float().cpu()
+        assert float((have - v).abs().max()) <= 3e-2 * max(1.0, float(v.abs().max())), k
+    # measured (round 5): ResNet-18 vs fp32 0.26 median / vs the rounding reference 0.20; ResNet-34 0.42 / 0.36 — and the rounding
+    # reference itself is 0.43 from fp32: with random weights, 17 / 33 BatchNorm + ReLU units deep, two bf16 evaluations of the SAME
+    # network disagree with each other as much as with fp32 (ReLU masks flip, BatchNorm re-normalises the difference).  So the full-size
+    # check is relative: the product must be no further from fp32 than a plain torch evaluation with the same roundings is (a wiring
+    # error — a missing branch, a wrong stride — gives errors of order 1); the tight checks are the kernel-by-kernel test and the toy nets.
+    assert l2 <= 8e-2 and l2e <= 6e-2, (l2, l2e)
+    assert srt[len(srt) // 2] <= 1.2 * srtm[len(srtm) // 2] + 0.02, (srt[len(srt) // 2], srtm[len(srtm) // 2])
+    assert srt[-1] <= 1.2 * srtm[-1] + 0.05, (srt[-1], srtm[-1])
