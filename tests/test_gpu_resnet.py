@@ -479,3 +479,37 @@ def test_full_size_resnet_training_gradients(depths, name):
     assert l2 <= 8e-2 and l2e <= 6e-2, (l2, l2e)
     assert srt[len(srt) // 2] <= 1.2 * srtm[len(srtm) // 2] + 0.02, (srt[len(srt) // 2], srtm[len(srtm) // 2])
     assert srt[-1] <= 1.2 * srtm[-1] + 0.05, (srt[-1], srtm[-1])
+
+
+def test_resnet_training_kernels_in_deterministic_mode():
+    """SVOL_DETERMINISTIC=1 re-routes the column reductions of csrc/resnet_train.hip through partial rows folded in index order and
+    leaves the gathered weight-gradient GEMM unsplit (one adder per output element): the kernel-by-kernel fp64 checks and the gradient-sink
+    check again, in a child process (the switch is read once), and two backward passes of one extractor must agree bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SVOL_DETERMINISTIC='1', PYTHONPATH=root)
+    r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_resnet.py', '-q', '-m', 'gpu', '-x', '-k',
+                        'test_resnet_training_kernels or weight_gradients_into_gradient_sinks', '-p', 'no:cacheprovider',
+                        '--deselect', 'tests/test_gpu_resnet.py::test_resnet_training_kernels_in_deterministic_mode'],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    code = r'''
+import torch
+from svol_amd import synthetic as syn
+from svol_amd.modeling.resnet import ResNetExtractor
+sd = syn.synth_resnet_state_dict(syn.resnet_param_shapes((1, 2), (32, 64), 32), seed=1)
+x = syn.synth_images(4, syn.vit_config(image_size=64), seed=5).cuda()
+outs = []
+for rep in range(2):
+    m = ResNetExtractor((1, 2), (32, 64), 32, compute_dtype='bf16', trainable=True)
+    m.load_state_dict(sd); m.cuda().train()
+    out = m(x)
+    (out.float() * torch.randn(out.shape, generator=torch.Generator().manual_seed(3)).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    outs.append([p.grad.clone() for p in m.parameters()] + [b.clone() for b in m.buffers()])
+print('RESNET', 'identical' if all(torch.equal(a, b) for a, b in zip(*outs)) else 'DIFFERENT')
+'''
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and 'RESNET identical' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
