@@ -151,15 +151,19 @@ def cross_modal_layer(sd, p: str, h: int, src_vid, src_skch, out, vid_pad_mask, 
 
 
 def svanet_forward(sd: Dict[str, torch.Tensor], args, src_sketch, src_sketch_mask, src_video, src_video_mask,
-                   return_hs: bool = False):
-    """SVANet.forward, svanet.py:65-141 (eval mode: dropout identity).
+                   return_hs: bool = False, dropout_masks=None):
+    """SVANet.forward, svanet.py:65-141.  Eval mode by default (dropout identity); TRAINING mode (svanet.py:168-171: the only
+    dropout on this path is ``input_dropout`` inside LinearLayer) when ``dropout_masks`` = {'video': [m_0, ...],
+    'sketch': [m_0, ...]} is given — one keep mask per projection layer, already scaled by 1/(1-p), applied between LayerNorm
+    and Linear exactly where nn.Dropout sits (svanet.py:166,178).
     ``sd`` uses the head's own state-dict keys (no ``head.`` prefix)."""
     d, h, nl = args.hidden_dim, args.nheads, args.num_layers
     dtype = src_video.dtype
-    vid = input_proj(src_video, sd, 'input_video_proj', args.n_input_proj)
+    dm = dropout_masks or {}
+    vid = input_proj(src_video, sd, 'input_video_proj', args.n_input_proj, dm.get('video'))
     mask_video = src_video_mask.bool()
     pos_video = position_embedding_sine(mask_video, d, dtype)
-    skch = input_proj(src_sketch, sd, 'input_sketch_proj', args.n_input_proj)
+    skch = input_proj(src_sketch, sd, 'input_sketch_proj', args.n_input_proj, dm.get('sketch'))
     # transformer (cross_modal_transformer.py:27-81)
     B = vid.shape[0]
     query_pos = sd['query_embed.weight'].unsqueeze(0).expand(B, -1, -1)
@@ -349,14 +353,22 @@ def weight_dict(args) -> Dict[str, float]:
     return wd
 
 
-def set_criterion(args, outputs, targets, return_indices: bool = False):
+def set_criterion(args, outputs, targets, return_indices: bool = False, indices=None):
     """SetCriterion.forward, loss.py:126-157: match the last layer, then
-    RE-MATCH every aux layer (loss.py:148-155)."""
+    RE-MATCH every aux layer (loss.py:148-155).
+
+    ``indices`` (test use): a list [last, aux_0, ...] of per-video (pred_idx, tgt_idx) assignments to score INSTEAD of matching —
+    the matcher is @no_grad (matcher.py:38), so the losses and their gradients are functions of the outputs and a FIXED assignment;
+    feeding the assignment a 16-bit device run found (bit-exact w.r.t. its own outputs, but possibly a near-tie flip away from
+    the fp32 one) gives the fp32 gradient reference for exactly the loss that run differentiated."""
     losses = {}
     all_idx = []
 
     def one(lo, suffix):
-        idx = match(args, lo['pred_logits'].detach(), lo['pred_boxes'].detach(), targets)
+        if indices is not None:
+            idx = [(torch.as_tensor(p, dtype=torch.int64), torch.as_tensor(t, dtype=torch.int64)) for p, t in indices[len(all_idx)]]
+        else:
+            idx = match(args, lo['pred_logits'].detach(), lo['pred_boxes'].detach(), targets)
         all_idx.append(idx)
         ll, ce = loss_labels(lo['pred_logits'], idx, args.eos_coef)
         lb, lg = loss_boxes(lo['pred_boxes'], idx, targets)

@@ -68,6 +68,10 @@ HEAD_CASES = {
     # the same with the last 8 of the 32 frames padded: 4704 valid keys = 36.75 key tiles, the key-padding mask at L = 6272
     'cfg2_b1_video_pad': (dict(hidden_dim=256, nheads=8, num_layers=6, num_queries=100, num_queries_per_frame=10,
                                num_frames=32, matcher='video_matcher'), 1, 32, 196, 8, True),
+    # the shipped recipe's matcher scale THROUGH THE HEAD (train_sketchy.sh:21-23: 32 frames x 10 queries per frame = 320 queries,
+    # per_frame_matcher) at the benchmark depth / width; P = 49 (the ResNet-34 map) keeps the reference's L x L tensors small
+    'cfg2w_b1_frame': (dict(hidden_dim=256, nheads=8, num_layers=6, num_queries=320, num_queries_per_frame=10,
+                            num_frames=32, matcher='per_frame_matcher'), 1, 32, 49, 4, True),
 }
 
 CRIT_CASES = {
@@ -154,6 +158,78 @@ def run_head_case(name, over, B, T, P, pad, pad_all=False):
             rec[f'idx/{tag}/pred'] = p
             rec[f'idx/{tag}/tgt'] = t
             rec[f'idx/{tag}/offs'] = o
+    for k, p in model.named_parameters():
+        grad_record(rec, k, p.grad)
+    path = os.path.join(HERE, f'head_{name}.npz')
+    np.savez_compressed(path, **rec)
+    print(f'{name}: loss_total={float(total):.6f}  -> {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+# TRAINING mode of the primary path (svanet.py:168-171: input_dropout inside LinearLayer is the only dropout).  The
+# keep masks nn.Dropout drew are RECORDED (forward hooks on the reference's own Dropout modules) and stored as packed bits, so
+# that the oracle's placement of the dropout can be pinned against the reference whatever RNG produced the masks.
+TRAIN_CASES = {
+    # name: (args overrides, B, T, P, pad_frames)
+    'train_cfg1_video': (dict(hidden_dim=64, nheads=8, num_layers=1, num_queries=10, num_queries_per_frame=10,
+                              num_frames=4, matcher='video_matcher', input_dropout=0.4), 1, 4, 49, 0),
+    'train_mid32_video': (dict(hidden_dim=256, nheads=8, num_layers=2, num_queries=100, num_queries_per_frame=10,
+                               num_frames=8, input_vid_dim=64, input_skch_dim=64, matcher='video_matcher',
+                               input_dropout=0.4), 2, 8, 24, 2),
+}
+
+
+def run_train_case(name, over, B, T, P, pad):
+    args = syn.head_args(**over)
+    torch.manual_seed(1)
+    model = build_svanet(args)
+    sd = syn.synth_state_dict(args, seed=1)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    criterion = build_loss(args)
+    criterion.train()
+    masks = {}
+
+    def hook(tag):
+        def h(_m, a, out):
+            assert bool((a[0] != 0).all()), 'a LayerNorm output is exactly 0: the keep mask cannot be read off the output'
+            masks[tag] = (out != 0).numpy()
+        return h
+
+    for which, seq in (('video', model.input_video_proj), ('sketch', model.input_sketch_proj)):
+        for j, layer in enumerate(seq):
+            layer.net[0].register_forward_hook(hook(f'{which}/{j}'))
+    inp = syn.synth_inputs(args, B, T, P, seed=1, pad_frames=pad)
+    targets = syn.synth_targets(B, T, seed=1)
+    torch.manual_seed(7)
+    outputs = model(inp['src_sketch'], inp['src_sketch_mask'], inp['src_video'], inp['src_video_mask'])
+    loss_dict = criterion(outputs, targets)
+    wd = criterion.weight_dict
+    total = sum(loss_dict[k] * wd[k] for k in loss_dict.keys() if k in wd)
+    total.backward()
+    rec = {}
+    rec['meta'] = np.asarray(json.dumps(dict(args=vars(args), B=B, T=T, P=P, pad_frames=pad, pad_all=False, torch=torch.__version__)))
+    rec['keys'] = np.asarray('\n'.join(model.state_dict().keys()))
+    for tag, m in masks.items():
+        rec[f'mask/{tag}/shape'] = np.asarray(m.shape, np.int64)
+        rec[f'mask/{tag}/bits'] = np.packbits(m.reshape(-1))
+        keep = float(m.mean())
+        assert abs(keep - (1 - args.input_dropout)) < 0.1, (tag, keep)
+    rec['pred_logits'] = outputs['pred_logits'].detach().numpy()
+    rec['pred_boxes'] = outputs['pred_boxes'].detach().numpy()
+    if 'aux_outputs' in outputs and len(outputs['aux_outputs']):
+        rec['aux_logits'] = np.stack([a['pred_logits'].detach().numpy() for a in outputs['aux_outputs']])
+        rec['aux_boxes'] = np.stack([a['pred_boxes'].detach().numpy() for a in outputs['aux_outputs']])
+    names = sorted(loss_dict.keys())
+    rec['loss_names'] = np.asarray('\n'.join(names))
+    rec['loss_values'] = np.asarray([float(loss_dict[k]) for k in names], np.float64)
+    rec['loss_total'] = np.asarray(float(total), np.float64)
+    with torch.no_grad():
+        layers = [{'pred_logits': outputs['pred_logits'], 'pred_boxes': outputs['pred_boxes']}]
+        layers += list(outputs.get('aux_outputs', []))
+        for li, lo in enumerate(layers):
+            p, t, o = pack_indices(criterion.matcher(lo, targets))
+            tag = 'last' if li == 0 else f'aux{li - 1}'
+            rec[f'idx/{tag}/pred'], rec[f'idx/{tag}/tgt'], rec[f'idx/{tag}/offs'] = p, t, o
     for k, p in model.named_parameters():
         grad_record(rec, k, p.grad)
     path = os.path.join(HERE, f'head_{name}.npz')
@@ -253,6 +329,9 @@ if __name__ == '__main__':
     for n, c in HEAD_CASES.items():
         if not only or n in only:
             run_head_case(n, *c)
+    for n, c in TRAIN_CASES.items():
+        if not only or n in only:
+            run_train_case(n, *c)
     if not only:
         for n, c in CRIT_CASES.items():
             run_crit_case(n, *c)

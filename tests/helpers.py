@@ -30,6 +30,23 @@ def head_case(name, dtype=torch.float32):
     return z, meta, args, sd, inp, tg
 
 
+def recorded_dropout_masks(z, p):
+    """the keep masks a train-mode golden recorded from the reference's nn.Dropout modules (make_golden.py::run_train_case), as
+    the oracle takes them: {'video': [m_0, ...], 'sketch': [...]}, float32, already scaled by 1 / (1 - p)."""
+    out = {}
+    for which in ('video', 'sketch'):
+        ms = []
+        j = 0
+        while f'mask/{which}/{j}/bits' in z.files:
+            shape = tuple(int(v) for v in z[f'mask/{which}/{j}/shape'])
+            n = int(np.prod(shape))
+            keep = np.unpackbits(z[f'mask/{which}/{j}/bits'])[:n].reshape(shape).astype(np.float32)
+            ms.append(torch.from_numpy(keep) * np.float32(1.0 / (1.0 - p)))
+            j += 1
+        out[which] = ms
+    return out
+
+
 def unpack_indices(z, prefix):
     p, t, o = z[prefix + '/pred'], z[prefix + '/tgt'], z[prefix + '/offs']
     return [(p[o[i]:o[i + 1]], t[o[i]:o[i + 1]]) for i in range(len(o) - 1)]

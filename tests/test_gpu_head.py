@@ -8,7 +8,9 @@ pytestmark = pytest.mark.gpu
 
 # cfg2_b1_video(_pad): BASELINE configs[1] at full depth / width / sequence length (L = 6272, 6 layers, d = 256, N = 100), one
 # video, without and with 8 padded frames — reference-generated values at the shapes the bench launches
-CASES = ['tiny_video', 'tiny_frame', 'cfg1_video', 'cfg1_frame', 'mid_video', 'mid32_video', 'cfg2_b1_video', 'cfg2_b1_video_pad']
+# cfg2w_b1_frame: per_frame_matcher at the shipped recipe's scale (32 frames x 10 queries = 320) through the 6-layer d = 256 head
+CASES = ['tiny_video', 'tiny_frame', 'cfg1_video', 'cfg1_frame', 'mid_video', 'mid32_video', 'cfg2_b1_video', 'cfg2_b1_video_pad',
+         'cfg2w_b1_frame']
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -20,7 +22,7 @@ def test_head_golden(name, dtype):
     assert not bad, '\n'.join(f'{k}: err={e:.3e} tol={t:.1e}' for k, (e, t) in bad.items())
 
 
-@pytest.mark.parametrize('name', ['cfg1_video', 'cfg1_frame', 'mid32_video', 'cfg2_b1_video', 'cfg2_b1_video_pad'])
+@pytest.mark.parametrize('name', ['cfg1_video', 'cfg1_frame', 'mid32_video', 'cfg2_b1_video', 'cfg2_b1_video_pad', 'cfg2w_b1_frame'])
 def test_head_golden_fp16(name):
     """fp16 operands (``--compute_dtype fp16``, BASELINE configs[4]'s stated dtype): the same goldens, outputs within 3e-3."""
     from tests import gpu_checks as G
@@ -75,6 +77,100 @@ def test_model_level_mask_expansion_matches_the_head_golden(name, dtype):
                  src_sketch_mask=inp['src_sketch_mask'].cuda(), src_video_mask=torch.ones(B, T).cuda())
     assert float((out2['pred_logits'] - out['pred_logits'])[1::2].abs().max()) > 1e-4
     assert float((out2['pred_logits'] - out['pred_logits'])[0::2].abs().max()) <= (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+def _device_input_dropout_masks(model, B, L, p):
+    """the keep masks (scaled by 1 / (1 - p)) the product's LinearLayers drew in the training forward that just ran: stateless
+    functions of (seed, row, column) — regenerated by the same LayerNorm kernel over gamma = 0, beta = 1 — and checked against the
+    numpy twin of the generator."""
+    import numpy as np
+    from svol_amd import ops
+    from tests.gpu_checks import dropout_keep_numpy
+    out = {}
+    for which, seq, salt, rows in (('video', model.input_video_proj, 0, B * L), ('sketch', model.input_sketch_proj, 1, B)):
+        ms = []
+        for j, layer in enumerate(seq):
+            D = layer.LayerNorm.weight.numel()
+            seed = (model.base_seed << 32) + (model._step << 8) + salt * 16 + j
+            x = torch.randn(rows, D, device='cuda')
+            _, y, _, _, _ = ops.layernorm_fwd(x, torch.zeros(D, device='cuda'), torch.ones(D, device='cuda'), torch.float32, None, p, seed)
+            y = y.cpu()
+            keep = dropout_keep_numpy((rows, D), p, seed)
+            assert np.array_equal(y.numpy() > 0, keep), (which, j)
+            assert float((y[y > 0] - 1 / (1 - p)).abs().max()) < 1e-6
+            ms.append(y.view(B, rows // B, D))
+        out[which] = ms
+    return out
+
+
+@pytest.mark.parametrize('name', ['train_cfg1_video', 'train_mid32_video'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16], ids=['fp32', 'bf16', 'fp16'])
+def test_training_mode_input_dropout_matches_the_oracle_under_shared_masks(name, dtype):
+    """The mode bench.py TIMES: SVANet in ``.train()`` with ``input_dropout`` 0.4 (svanet.py:168-181; configs.py:127).  One training
+    step (forward + criterion + backward) of the product against the oracle's training-mode forward under the SAME keep masks.
+    The oracle's placement of the dropout is pinned against masks recorded from the reference's own nn.Dropout modules
+    (tests/test_oracle_golden.py::test_training_mode_head_under_the_masks_the_reference_drew, same two configurations); the
+    device's masks are stateless functions of (seed, row, column) regenerated here.  Bars: north_star's 1e-3 fp32 / 1e-2 bf16
+    (3e-3 fp16) on logits and boxes of every layer, the matched loss, every parameter gradient (tests/gpu_checks.py::compare_param_grads)."""
+    from types import SimpleNamespace
+    from oracle import svol_oracle as O
+    from svol_amd.modeling.loss import build_loss
+    from svol_amd.modeling.svanet import build_svanet
+    from tests import gpu_checks as G
+    from tests.helpers import head_case
+    z, meta, args, sd, inp, tg = head_case(name)
+    p = args.input_dropout
+    assert p == 0.4
+    args.compute_dtype = {torch.float32: 'fp32', torch.bfloat16: 'bf16', torch.float16: 'fp16'}[dtype]
+    model = build_svanet(args)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().train()
+    crit = build_loss(args).cuda().train()
+    a = [inp[k].cuda() for k in ('src_sketch', 'src_sketch_mask', 'src_video', 'src_video_mask')]
+    out = model(*a)
+    ld = crit(out, tg)
+    tot = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+    if dtype == torch.float16:   # fp16 trains under a loss scale (gpu_checks.run_head_case)
+        (tot * G.FP16_LOSS_SCALE).backward()
+        with torch.no_grad():
+            for p_ in model.parameters():
+                if p_.grad is not None:
+                    p_.grad.mul_(1.0 / G.FP16_LOSS_SCALE)
+    else:
+        tot.backward()
+    torch.cuda.synchronize()
+    masks = _device_input_dropout_masks(model, meta['B'], meta['T'] * meta['P'], p)
+    keep = torch.cat([m.reshape(-1) for m in masks['video']])
+    assert abs(float((keep > 0).float().mean()) - (1 - p)) < 0.02
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.svanet_forward(sdr, args, inp['src_sketch'], inp['src_sketch_mask'], inp['src_video'], inp['src_video_mask'],
+                           dropout_masks=masks)
+    dev_idx = [[(pi.cpu().numpy(), ti.cpu().numpy()) for pi, ti in lay] for lay in crit.last_indices()]   # [aux0.., last]
+    r_ld, r_idx = O.set_criterion(SimpleNamespace(**vars(args)), ref, tg, return_indices=True)              # [last, aux0..]
+    flips = sum(int(pi.tolist() != rp.tolist() or ti.tolist() != rt.tolist())
+                for lay, rlay in zip(dev_idx[-1:] + dev_idx[:-1], r_idx) for (pi, ti), (rp, rt) in zip(lay, rlay))
+    if dtype == torch.float32:
+        assert flips == 0
+    elif flips:   # a 16-bit near-tie flip: differentiate the loss the device differentiated
+        r_ld = O.set_criterion(SimpleNamespace(**vars(args)), ref, tg, indices=dev_idx[-1:] + dev_idx[:-1])
+    r_tot = O.total_loss(args, r_ld)
+    r_tot.backward()
+    tol = {torch.float32: 1e-3, torch.bfloat16: 1e-2, torch.float16: 3e-3}[dtype]
+    lays = list(out.get('aux_outputs', [])) + [out]
+    rlays = list(ref.get('aux_outputs', [])) + [ref]
+    e_l = max(float((o['pred_logits'].detach().cpu() - r['pred_logits']).abs().max()) for o, r in zip(lays, rlays))
+    e_b = max(float((o['pred_boxes'].detach().cpu() - r['pred_boxes']).abs().max()) for o, r in zip(lays, rlays))
+    # an eval-mode forward of the same weights is far away: the masks really are applied
+    model.eval()
+    with torch.no_grad():
+        ev = model(*a)
+    assert float((ev['pred_logits'].cpu() - ref['pred_logits']).abs().max()) > 1e-2
+    print(f'training-mode {name} {dtype}: |dlogits| {e_l:.2e} |dboxes| {e_b:.2e} |dloss| {abs(float(tot) - float(r_tot)):.2e} flips {flips}')
+    assert e_l <= tol and e_b <= tol, (e_l, e_b)
+    assert abs(float(tot) - float(r_tot)) <= tol * max(1.0, abs(float(r_tot)))
+    res = G.compare_param_grads(f'train/{name}', model, {k: v.grad for k, v in sdr.items()}, dtype, G.grad_bars(dtype, args.hidden_dim))
+    bad = {k: v for k, v in res.items() if not (v[0] <= v[1])}
+    assert not bad, '\n'.join(f'{k}: err={e:.3e} tol={t:.1e}' for k, (e, t) in bad.items())
 
 
 @pytest.mark.parametrize('lag', ['side', 'main'])
