@@ -293,6 +293,13 @@ int svol_match_cost(const float* logits, const float* boxes, const float* tgt_bo
 int svol_lsap_batched(const float* cost, const int64_t* cost_off, const int32_t* pred_off, const int32_t* pred_cnt,
                       const int32_t* tgt_off, const int32_t* tgt_cnt, int32_t* match, int32_t* status,
                       int32_t n_problems, int32_t max_dim, void* stream);
+/* HOST entry (no device, no stream): one rectangular LSAP with scipy.optimize.linear_sum_assignment's semantics, for a
+ * caller that keeps the reference's host-side matching (matcher.py:86 `C.cpu()`, :93 / :158 `linear_sum_assignment(c)`).  cost = row-major
+ * [nr, nc] fp64 in HOST memory; rows / cols = caller-owned int64[min(nr, nc)] (host).  Returns the number of pairs (= min(nr, nc); rows
+ * ascending, (rows[k], cols[k]) the k-th pair), -1 when the matrix holds NaN / -inf (scipy: ValueError "matrix contains invalid numeric
+ * entries"; +inf is accepted), -2 when it is infeasible.  The training / evaluation path of this build does not call it — all layers'
+ * problems are solved on the device by svol_lsap_batched; the two are independent implementations tested against each other. */
+int svol_lsap_solve(const double* cost, int64_t nr, int64_t nc, int64_t* rows, int64_t* cols);
 /* Per decoder layer (rows_per_layer = B*N prediction rows each):
  *   losses[layer*4 + {0,1,2,3}] = loss_label (weighted CE, plain mean over B*N; loss.py:54-55),
  *                                 loss_bbox (L1 mean over matched*4; loss.py:93-94),

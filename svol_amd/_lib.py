@@ -22,6 +22,7 @@ _u64 = ctypes.c_uint64
 # name -> argtypes, exactly the declarations of include/svol_hip.h
 SIGNATURES = {
     'svol_block_trace_dump': [ctypes.c_char_p, _i64],
+    'svol_lsap_solve': [_p, _i64, _i64, _p, _p],
     'svol_cast': [_p, _int, _p, _int, _i64, _p],
     'svol_cast_transpose': [_p, _p, _p, _int, _i64, _i64, _p],
     'svol_cast_split': [_p, _i64, _p, _i64, _i64, _p],

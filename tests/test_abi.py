@@ -30,8 +30,61 @@ def test_header_symbols_exported():
         assert getattr(L, fn)(0, 0, 0) == -1
     for blk, first in ((0, 'X32'), (1, 'O32'), (2, 'O32')):
         assert L.svol_block_slot_names(blk).decode().split(',')[0] == first
-    assert L.svol_abi_version() == 5
+    assert L.svol_abi_version() == 6
     assert b'invalid' in L.svol_strerror(-1)
+
+
+def _host_lsap(cost):
+    import ctypes
+    import numpy as np
+    from svol_amd import _lib
+    c = np.ascontiguousarray(cost, dtype=np.float64)
+    nr, nc = c.shape
+    n = min(nr, nc)
+    rows, cols = np.full(max(n, 1), -7, np.int64), np.full(max(n, 1), -7, np.int64)
+    rc = _lib.lib().svol_lsap_solve(c.ctypes.data_as(ctypes.c_void_p), nr, nc, rows.ctypes.data_as(ctypes.c_void_p),
+                                    cols.ctypes.data_as(ctypes.c_void_p))
+    return rc, rows[:n], cols[:n]
+
+
+def test_host_lsap_known_answers():
+    """svol_lsap_solve (host entry of SURVEY §8b, svol_amd/csrc/lsap_host.hip — not the oracle's file) against the scipy 1.15.3
+    known answers of tests/golden/lsap_known_answers.npz (ties, zeros, tall / wide / empty, +inf), SURVEY §8c's vectors, live
+    random comparisons with scipy incl. heavy ties, and scipy's error conventions (NaN / -inf invalid, all-inf row infeasible)."""
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment
+    z = np.load(os.path.join(REPO, 'tests', 'golden', 'lsap_known_answers.npz'))
+    for i in range(int(z['n'])):
+        c = z[f'c{i}/cost']
+        rc, r, k = _host_lsap(c)
+        assert rc == len(z[f'c{i}/rows']), (i, rc)
+        assert r.tolist() == z[f'c{i}/rows'].tolist() and k.tolist() == z[f'c{i}/cols'].tolist(), (i, str(z[f'c{i}/kind']))
+    for c, rows, cols in [(np.zeros((4, 2)), [0, 1], [0, 1]), (np.zeros((2, 4)), [0, 1], [0, 1]), (np.zeros((3, 3)), [0, 1, 2], [0, 1, 2]),
+                          (np.array([[1, 2], [1, 2], [0, 2], [1, 0], [1, 0]], float), [2, 3], [0, 1]),
+                          (np.array([[.3, .1], [.1, .3], [.2, .2]], np.float32), [0, 1], [1, 0]),
+                          (np.random.default_rng(0).random((10, 3)).astype(np.float32), [1, 3, 4], [0, 2, 1])]:
+        rc, r, k = _host_lsap(c)
+        assert rc == len(rows) and r.tolist() == rows and k.tolist() == cols
+    assert _host_lsap(np.zeros((10, 0)))[0] == 0
+    rng = np.random.RandomState(11)
+    for it in range(300):
+        nr, nc = rng.randint(1, 90), rng.randint(1, 90)
+        c = (rng.randint(0, 3, size=(nr, nc)).astype(np.float32) if it % 3 == 0 else rng.random_sample((nr, nc)).astype(np.float32)
+             if it % 3 == 1 else rng.standard_normal((nr, nc)))
+        rr, cc = linear_sum_assignment(c)
+        rc, r, k = _host_lsap(c)
+        assert rc == len(rr) and r.tolist() == rr.tolist() and k.tolist() == cc.tolist(), (it, nr, nc)
+    bad = np.ones((3, 3))
+    bad[1, 1] = np.nan
+    assert _host_lsap(bad)[0] == -1
+    bad[1, 1] = -np.inf
+    assert _host_lsap(bad)[0] == -1
+    bad[1, :] = np.inf
+    assert _host_lsap(bad)[0] == -2
+    ok = np.array([[np.inf, 1.0], [2.0, np.inf], [0.5, 0.25]])
+    rr, cc = linear_sum_assignment(ok)
+    rc, r, k = _host_lsap(ok)
+    assert rc == 2 and r.tolist() == rr.tolist() and k.tolist() == cc.tolist()
 
 
 def test_argument_validation_without_gpu():
