@@ -11,7 +11,10 @@ reference command line parses unchanged.  Differences, all additive:
 * ``--backbone features`` feeds pre-extracted frame / sketch features straight
   to the head (the measured boundary, SURVEY.md D3);
 * ``--enc_layers --dec_layers --mode --feat_dim`` and ``--sketch_head svanet_variants``: what the reference's enc/dec
-  heads read but its parser never defines.
+  heads read but its parser never defines (SURVEY.md §8 f2);
+* ``--train_backbone {0,1}`` (``--backbone resnet``): default = the reference's behaviour (its training step optimises the
+  backbone, train.py:72), with the reference's dead ``--freeze_backbone`` honoured as the opt-out; ``--sync_bn`` is honoured
+  by the trainable extractors (global-batch BatchNorm statistics across ranks, train.py:65-68).
 """
 from __future__ import annotations
 
@@ -114,6 +117,10 @@ _EXTRA = [
     (('--mode',), dict(type=str, default='append_to_seq', choices=['concat_to_seq', 'append_to_seq', 'concat_to_qry'],
                        help='how svanet_variants presents the sketch to the enc/dec Transformer')),
     (('--feat_dim',), dict(type=int, default=512, help='feature width of the enc/dec heads (one width for sketch and video)')),
+    # --backbone resnet: the reference optimises the backbone too (train.py:72); None = "as the reference": trainable unless
+    # --freeze_backbone (a flag the reference parses and never reads) is given; 0 / 1 force the frozen / trainable extractors
+    (('--train_backbone',), dict(type=int, default=None, choices=[0, 1],
+                                 help='ResNet extractors in training mode and in the optimiser (default: 1 unless --freeze_backbone)')),
 ]
 
 

@@ -122,6 +122,9 @@ struct DetScratch {
     float* p = nullptr;
     hipStream_t s;
     DetScratch(size_t floats, hipStream_t s_, bool zero = false) : s(s_) {
+        if (floats == 0) return;   // the default (non-deterministic) mode asks for nothing: no runtime call on the hot launches
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;   // a debugging mode, not for graph capture: refuse (p stays null -> the entry returns an error)
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
         if (hipMallocAsync(reinterpret_cast<void**>(&p), floats * sizeof(float), s) != hipSuccess) p = nullptr;
         if (p && zero && hipMemsetAsync(p, 0, floats * sizeof(float), s) != hipSuccess) { (void)hipFreeAsync(p, s); p = nullptr; }
     }

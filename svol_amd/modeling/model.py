@@ -44,11 +44,16 @@ def build_backbone(args):
         args.input_skch_dim = 512
         cd = getattr(args, 'compute_dtype', 'bf16')
         # the torchvision IMAGENET1K_V1 weights are loaded by the caller (load_state_dict with the reference's backbone.* keys) —
-        # nothing is downloaded here.  args.train_backbone (default False = frozen extractors, eval-mode BatchNorm): True is what the
-        # reference's training step does (train.py:72 optimises every parameter, model.train() puts BatchNorm into batch-statistics
-        # mode; its --freeze_backbone flag is dead): convolution / BatchNorm gradients through csrc/resnet_train.hip
-        tb = bool(getattr(args, 'train_backbone', False))
-        return ResNetBackbone(resnet34(compute_dtype=cd, trainable=tb), resnet18(avgpool=True, compute_dtype=cd, trainable=tb))
+        # nothing is downloaded here.  The reference TRAINS its backbone: train.py:72 hands every parameter of build_model(args) to
+        # the optimiser and model.train() puts BatchNorm into batch-statistics mode (its --freeze_backbone flag is parsed and never
+        # read).  So a reference-style run gets the trainable extractors (csrc/resnet_train.hip) by default; --freeze_backbone — dead
+        # in the reference, honoured here — or --train_backbone 0 selects the frozen, BatchNorm-folded extractors (inference, or the
+        # features-are-fixed setting bench.py --workload resnet measures without --train-backbone).
+        tb = getattr(args, 'train_backbone', None)
+        tb = (not bool(getattr(args, 'freeze_backbone', False))) if tb is None else bool(tb)
+        sync = bool(getattr(args, 'sync_bn', False))   # train.py:65-68: apex convert_syncbn_model
+        return ResNetBackbone(resnet34(compute_dtype=cd, trainable=tb, sync_bn=sync),
+                              resnet18(avgpool=True, compute_dtype=cd, trainable=tb, sync_bn=sync))
     raise NotImplementedError(f"backbone '{args.backbone}' is not part of the MI355X build (the reference has it commented out)")
 
 

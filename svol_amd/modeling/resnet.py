@@ -69,13 +69,13 @@ def _w16(weight, dtype):
     return ops.conv_weight_pack(weight, dtype)
 
 
-def _bn_forward(z, bn, gamma, beta, residual, relu):
+def _bn_forward(z, bn, gamma, beta, residual, relu, sync=False):
     """train-mode BatchNorm of the conv output z [M, C] (+ identity) (+ ReLU); updates bn's running statistics as nn.BatchNorm2d does."""
     if bn.momentum is None:
         raise NotImplementedError('BatchNorm2d(momentum=None) (cumulative average) is not on the reference path')
     track = bn.track_running_stats and bn.running_mean is not None
     mean, rstd, scale, shift = ops.bn_train_stats(z, gamma.detach(), beta.detach(), bn.running_mean if track else None,
-                                                  bn.running_var if track else None, bn.momentum, bn.eps)
+                                                  bn.running_var if track else None, bn.momentum, bn.eps, sync)
     if track:
         with torch.no_grad():
             bn.num_batches_tracked += 1
@@ -111,12 +111,12 @@ class _ConvBnFn(torch.autograd.Function):
     """y [n*ho*wo, Cout] = relu?(BatchNorm_train(conv(x)) + identity) on NHWC activations; see the module docstring."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, identity, geom, relu, bn, dt):
+    def forward(ctx, x, weight, gamma, beta, identity, geom, relu, bn, dt, sync=False):
         n, H, W, C, kh, kw, stride, pad = geom
         w16 = _w16(weight, dt)
         z, Ho, Wo = ops.conv_nhwc(x, w16, None, ops.ACT_NONE, n, H, W, C, kh, kw, stride, pad)
-        y, mean, rstd = _bn_forward(z, bn, gamma, beta, identity, relu)
-        ctx.geom, ctx.relu, ctx.has_id, ctx.out_hw = geom, relu, identity is not None, (Ho, Wo)
+        y, mean, rstd = _bn_forward(z, bn, gamma, beta, identity, relu, sync)
+        ctx.geom, ctx.relu, ctx.has_id, ctx.out_hw, ctx.sync = geom, relu, identity is not None, (Ho, Wo), sync
         ctx.sink = ops._claim(weight, ctx.needs_input_grad[1])
         ctx.save_for_backward(x, weight, w16, z, y if relu else None, mean, rstd, gamma.detach())
         return y
@@ -126,7 +126,7 @@ class _ConvBnFn(torch.autograd.Function):
         x, weight, w16, z, y, mean, rstd, gamma = ctx.saved_tensors
         n, H, W, C, kh, kw, stride, pad = ctx.geom
         Ho, Wo = ctx.out_hw
-        dz, did, dgamma, dbeta = ops.bn_bwd(dy.contiguous(), y, z, mean, rstd, gamma, ctx.has_id and ctx.needs_input_grad[4])
+        dz, did, dgamma, dbeta = ops.bn_bwd(dy.contiguous(), y, z, mean, rstd, gamma, ctx.has_id and ctx.needs_input_grad[4], ctx.sync)
         Cout = weight.shape[0]
         dW = None
         if ctx.needs_input_grad[1]:
@@ -144,31 +144,35 @@ class _ConvBnFn(torch.autograd.Function):
                 dx = ops.conv_nhwc(dz, ops.conv_weight_pack(weight, x.dtype, flip=True), None, ops.ACT_NONE, n, Ho, Wo, Cout, kh, kw, 1, pad)[0]
             else:
                 dx = ops.col2im_nhwc(ops.gemm_nt(dz, w16.t().contiguous()), n, H, W, C, kh, kw, stride, pad)
-        return dx, dW, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, did, None, None, None, None
+        return dx, dW, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, did, None, None, None, None, None
 
 
 class _StemFn(torch.autograd.Function):
     """pixels [n,3,H,W] fp32 -> relu(BatchNorm_train(conv7x7 s2 p3)) as NHWC [n*ho*wo, C]; no gradient for the pixels."""
 
     @staticmethod
-    def forward(ctx, pix, weight, gamma, beta, bn, dt):
+    def forward(ctx, pix, weight, gamma, beta, bn, dt, sync=False):
         n, c, H, W = pix.shape
         w16 = _w16(weight, dt)
         kh, kw = weight.shape[2], weight.shape[3]
         cols, Ho, Wo = ops.im2col(pix, n, H, W, c, kh, kw, 2, 3, dt, strides=(c * H * W, W, 1, H * W), ldcols=w16.shape[1])
         z = ops.gemm_nt(cols, w16)
-        y, mean, rstd = _bn_forward(z, bn, gamma, beta, None, True)
+        y, mean, rstd = _bn_forward(z, bn, gamma, beta, None, True, sync)
+        ctx.sync = sync
         ctx.sink = ops._claim(weight, ctx.needs_input_grad[1])
         # the stem's im2col matrix is KEPT for the weight gradient (1 GB at 256 frames of 224 x 224 — 0.4 % of this part's HBM; building
-        # it again from the NCHW fp32 pixels costs 0.6 ms)
-        ctx.save_for_backward(cols, weight, z, y, mean, rstd, gamma.detach())
+        # it again from the NCHW fp32 pixels costs 0.6 ms) — unless the stem's weight takes no gradient
+        ctx.save_for_backward(cols if ctx.needs_input_grad[1] else None, weight, z, y, mean, rstd, gamma.detach())
         return y
 
     @staticmethod
     def backward(ctx, dy):
         cols, weight, z, y, mean, rstd, gamma = ctx.saved_tensors
-        dz, _, dgamma, dbeta = ops.bn_bwd(dy.contiguous(), y, z, mean, rstd, gamma, False)
-        return None, _weight_grad(dz, lambda: ops.gemm_tn(dz, cols), weight, ctx.sink, (cols, dz)), dgamma, dbeta, None, None
+        if not any(ctx.needs_input_grad[1:4]):   # a frozen stem: the pixels take no gradient either, nothing to compute
+            return None, None, None, None, None, None, None
+        dz, _, dgamma, dbeta = ops.bn_bwd(dy.contiguous(), y, z, mean, rstd, gamma, False, ctx.sync)
+        dW = _weight_grad(dz, lambda: ops.gemm_tn(dz, cols), weight, ctx.sink, (cols, dz)) if ctx.needs_input_grad[1] else None
+        return None, dW, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, None, None, None
 
 
 class _MaxPoolFn(torch.autograd.Function):
@@ -199,8 +203,12 @@ class _AvgPoolFn(torch.autograd.Function):
 
 
 class ResNetExtractor(nn.Module):
-    def __init__(self, depths=(2, 2, 2, 2), widths=(64, 128, 256, 512), stem=64, avgpool=False, compute_dtype='bf16', trainable=False):
+    def __init__(self, depths=(2, 2, 2, 2), widths=(64, 128, 256, 512), stem=64, avgpool=False, compute_dtype='bf16', trainable=False,
+                 sync_bn=False):
         super().__init__()
+        # --sync_bn (apex.parallel.convert_syncbn_model, train.py:65-68 / test.py:61): train-mode BatchNorm statistics over the
+        # GLOBAL batch of all ranks of the default process group; no effect at world size 1 or on the frozen extractor
+        self.sync_bn = bool(sync_bn)
         self.add_module('0', nn.Conv2d(3, stem, 7, 2, 3, bias=False))
         self.add_module('1', nn.BatchNorm2d(stem))
         inplanes = stem
@@ -257,7 +265,8 @@ class ResNetExtractor(nn.Module):
         x = pixel_values.float().contiguous()
         n, c, H, W = x.shape
         conv0, bn0 = getattr(self, '0'), getattr(self, '1')
-        y = _StemFn.apply(x, conv0.weight, bn0.weight, bn0.bias, bn0, dt)
+        sync = self.sync_bn
+        y = _StemFn.apply(x, conv0.weight, bn0.weight, bn0.bias, bn0, dt, sync)
         H, W, C = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1, conv0.out_channels
         y = _MaxPoolFn.apply(y, (n, H, W, C, 3, 2, 1))
         H, W = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
@@ -265,12 +274,12 @@ class ResNetExtractor(nn.Module):
             for blk in getattr(self, str(4 + li)):
                 s_, planes = blk.stride, blk.conv1.out_channels
                 Ho, Wo = (H + 2 - 3) // s_ + 1, (W + 2 - 3) // s_ + 1
-                t = _ConvBnFn.apply(y, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, None, (n, H, W, C, 3, 3, s_, 1), True, blk.bn1, dt)
+                t = _ConvBnFn.apply(y, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, None, (n, H, W, C, 3, 3, s_, 1), True, blk.bn1, dt, sync)
                 idt = y
                 if blk.downsample is not None:
                     idt = _ConvBnFn.apply(y, blk.downsample[0].weight, blk.downsample[1].weight, blk.downsample[1].bias, None,
-                                          (n, H, W, C, 1, 1, s_, 0), False, blk.downsample[1], dt)
-                y = _ConvBnFn.apply(t, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias, idt, (n, Ho, Wo, planes, 3, 3, 1, 1), True, blk.bn2, dt)
+                                          (n, H, W, C, 1, 1, s_, 0), False, blk.downsample[1], dt, sync)
+                y = _ConvBnFn.apply(t, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias, idt, (n, Ho, Wo, planes, 3, 3, 1, 1), True, blk.bn2, dt, sync)
                 H, W, C = Ho, Wo, planes
         if self.avgpool:
             return _AvgPoolFn.apply(y, n, H * W, C)
@@ -297,12 +306,12 @@ class ResNetExtractor(nn.Module):
         return y.view(n, H * W, C)
 
 
-def resnet18(avgpool=False, compute_dtype='bf16', trainable=False):
-    return ResNetExtractor((2, 2, 2, 2), avgpool=avgpool, compute_dtype=compute_dtype, trainable=trainable)
+def resnet18(avgpool=False, compute_dtype='bf16', trainable=False, sync_bn=False):
+    return ResNetExtractor((2, 2, 2, 2), avgpool=avgpool, compute_dtype=compute_dtype, trainable=trainable, sync_bn=sync_bn)
 
 
-def resnet34(avgpool=False, compute_dtype='bf16', trainable=False):
-    return ResNetExtractor((3, 4, 6, 3), avgpool=avgpool, compute_dtype=compute_dtype, trainable=trainable)
+def resnet34(avgpool=False, compute_dtype='bf16', trainable=False, sync_bn=False):
+    return ResNetExtractor((3, 4, 6, 3), avgpool=avgpool, compute_dtype=compute_dtype, trainable=trainable, sync_bn=sync_bn)
 
 
 class ResNetBackbone(nn.Module):

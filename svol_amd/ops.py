@@ -534,29 +534,51 @@ def avgpool_nhwc(x, N, HW, C):
 BN_STATS_TWO_PASS = os.environ.get('SVOL_BN_TWO_PASS') is not None   # batch mean first, then the moment about it (tests: torch's own order)
 
 
-def bn_train_stats(z, gamma, beta, running_mean, running_var, momentum, eps):
+def _bn_sync_world(sync):
+    """ranks whose batch statistics are shared (apex convert_syncbn_model, train.py:65-68): the default process group, > 1 only."""
+    if not sync:
+        return 1
+    import torch.distributed as dist
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def bn_train_stats(z, gamma, beta, running_mean, running_var, momentum, eps, sync=False):
     """train-mode nn.BatchNorm2d statistics of an NHWC activation z [M, C] (16-bit) in ONE pass over z: sums of (z - s) and (z - s)^2
     about a per-channel pivot s = the first row of z (a sample of the channel: the variance's subtraction loses a few bits, not the
     variance — a plain sum z^2 would at |mean| >> std; measured against fp64: mean 1e-7 of a standard deviation, rstd 1e-6), then
     everything [C]-sized at once (svol_bn_finalize): -> fp32 [C] rows (mean, rstd, scale = gamma * rstd, shift = beta - mean * scale);
     running_mean / running_var (may be None) are updated in place.  BN_STATS_TWO_PASS (SVOL_BN_TWO_PASS=1): the batch mean first, then
     the second moment about it — one more pass over z, statistics equal to torch's to the last bits (the end-to-end gradient test
-    compares with a torch network whose ReLU masks flip with the 7th digit of a statistic)."""
+    compares with a torch network whose ReLU masks flip with the 7th digit of a statistic).
+    sync (``--sync_bn`` with more than one rank: apex SyncBatchNorm, train.py:65-68): the statistics are those of the GLOBAL batch —
+    every rank sums about rank 0's pivot (one [C] broadcast), the [2, C] sums are all-reduced and divided by the global row count
+    (every rank holds the same number of rows: the per-GPU batch of svol_dataloader.py:70)."""
     M, C = z.shape
     buf = torch.zeros((7, C), dtype=torch.float32, device=z.device)
     L_ = _lib.lib()
     dt, s = _dt(z), _stream()
+    world = _bn_sync_world(sync)
+    if world > 1:
+        import torch.distributed as dist
     if BN_STATS_TWO_PASS:
         _lib.check(L_.svol_bn_colstats(_ptr(z), None, 0.0, _ptr(buf[0]), _ptr(buf[6]), M, C, dt, s), 'svol_bn_colstats')
         buf[6].zero_()
-        _lib.check(L_.svol_bn_colstats(_ptr(z), _ptr(buf[0]), 1.0 / M, _ptr(buf[6]), _ptr(buf[1]), M, C, dt, s), 'svol_bn_colstats')
+        if world > 1:
+            dist.all_reduce(buf[0])
+        _lib.check(L_.svol_bn_colstats(_ptr(z), _ptr(buf[0]), 1.0 / (M * world), _ptr(buf[6]), _ptr(buf[1]), M, C, dt, s), 'svol_bn_colstats')
+        if world > 1:
+            dist.all_reduce(buf[1])
         pivot = None
     else:
         buf[6].copy_(z[0])
+        if world > 1:
+            dist.broadcast(buf[6], src=0)
         _lib.check(L_.svol_bn_colstats(_ptr(z), _ptr(buf[6]), 1.0, _ptr(buf[0]), _ptr(buf[1]), M, C, dt, s), 'svol_bn_colstats')
+        if world > 1:
+            dist.all_reduce(buf[0:2])
         pivot = buf[6]
     _lib.check(L_.svol_bn_finalize(_ptr(buf[0]), _ptr(buf[1]), _ptr(pivot), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
-                                   float(momentum), float(eps), M, C, _ptr(buf[2]), _ptr(buf[3]), _ptr(buf[4]), _ptr(buf[5]), s),
+                                   float(momentum), float(eps), M * world, C, _ptr(buf[2]), _ptr(buf[3]), _ptr(buf[4]), _ptr(buf[5]), s),
                'svol_bn_finalize')
     return buf[2], buf[3], buf[4], buf[5]
 
@@ -602,13 +624,26 @@ def bn_apply(z, scale, shift, residual=None, relu=False):
     return y
 
 
-def bn_bwd(dy, y, z, mean, rstd, gamma, want_dres):
-    """(dz, dres | None, dgamma, dbeta) of y = relu?(BN_train(z) + res): y = the saved output when a ReLU follows, else None."""
+def bn_bwd(dy, y, z, mean, rstd, gamma, want_dres, sync=False):
+    """(dz, dres | None, dgamma, dbeta) of y = relu?(BN_train(z) + res): y = the saved output when a ReLU follows, else None.
+    sync: the statistics were the global batch's (bn_train_stats(sync=True)) — dz needs the GLOBAL means of g and g * xhat (one
+    [2, C] all-reduce); dgamma / dbeta stay this rank's sums, the gradient exchange averages them like every other parameter's."""
     M, C = z.shape
     sums = torch.zeros((2, C), dtype=torch.float32, device=z.device)
     L_ = _lib.lib()
     _lib.check(L_.svol_bn_bwd_reduce(_ptr(dy), _ptr(y), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(sums[0]), _ptr(sums[1]), M, C, _dt(z),
                                      _stream()), 'svol_bn_bwd_reduce')
+    world = _bn_sync_world(sync)
+    if world > 1:
+        import torch.distributed as dist
+        local = sums.clone()
+        dist.all_reduce(sums)
+        sums.mul_(1.0 / world)   # svol_bn_bwd_apply divides by ITS row count M: (sum over ranks / world) / M = global sum / (M * world)
+        dz = torch.empty_like(z)
+        dres = torch.empty_like(z) if want_dres else None
+        _lib.check(L_.svol_bn_bwd_apply(_ptr(dy), _ptr(y), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(sums[0]), _ptr(sums[1]), _ptr(dz),
+                                        _ptr(dres), M, C, _dt(z), _stream()), 'svol_bn_bwd_apply')
+        return dz, dres, local[1], local[0]
     dz = torch.empty_like(z)
     dres = torch.empty_like(z) if want_dres else None
     _lib.check(L_.svol_bn_bwd_apply(_ptr(dy), _ptr(y), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(sums[0]), _ptr(sums[1]), _ptr(dz),

@@ -365,9 +365,15 @@ class FlatAdamW(torch.optim.Optimizer):
 
     @scaler.setter
     def scaler(self, sc: Optional['DynamicLossScaler']):
+        # seed the new scaler's device count from the updates really TAKEN so far, read before the swap: with a scaler attached
+        # self.t counts step() CALLS (overflow-skipped ones included), and replacing the scaler mid-run from it would inflate the
+        # bias corrections
+        taken = self.steps_taken()
         self._scaler = sc
         if sc is not None:
-            sc.state[3] = float(self.t)
+            sc.state[3] = float(taken)
+        else:
+            self.t = taken
 
     def steps_taken(self) -> int:
         """Updates really applied (what torch calls 'step'); a host read of the device count when a scaler is attached."""

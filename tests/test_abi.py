@@ -99,6 +99,28 @@ def test_argument_validation_without_gpu():
     assert L.svol_cast(0, 0, 0, 1, 10, 0) == -1
 
 
+def test_reference_style_cli_trains_the_resnet_backbone_by_default():
+    """the reference's shipped runs (train_*.sh: --backbone resnet; train.py:72 optimises every parameter under
+    model.train(); its --freeze_backbone is parsed and never read) train the backbone.  A reference command line through
+    svol_amd.configs + build_model must therefore build TRAINABLE extractors by default; --freeze_backbone (honoured here) and
+    --train_backbone 0 select the frozen ones; --sync_bn reaches the extractors (train.py:65-68)."""
+    from svol_amd import configs
+    from svol_amd.modeling.model import build_model
+    base = ['--backbone', 'resnet', '--num_layers', '1', '--num_queries', '10', '--matcher', 'video_matcher']
+    for argv, want_train, want_sync in [(base, True, False), (base + ['--freeze_backbone'], False, False),
+                                        (base + ['--train_backbone', '0'], False, False),
+                                        (base + ['--freeze_backbone', '--train_backbone', '1', '--sync_bn'], True, True)]:
+        args = configs.parse_args(argv)
+        model = build_model(args)
+        bb = list(model.backbone.parameters())
+        assert len(bb) == 108 + 60
+        assert all(p.requires_grad == want_train for p in bb), argv
+        assert model.backbone.video_backbone.trainable == want_train and model.backbone.sketch_backbone.trainable == want_train
+        assert model.backbone.video_backbone.sync_bn == want_sync and model.backbone.sketch_backbone.sync_bn == want_sync
+        n_opt = sum(1 for p in model.parameters() if p.requires_grad)   # train.py:72's list
+        assert n_opt == sum(1 for p in model.head.parameters() if p.requires_grad) + (len(bb) if want_train else 0)
+
+
 def test_product_has_no_cpu_path():
     from svol_amd import synthetic as syn
     from svol_amd.modeling.loss import build_loss

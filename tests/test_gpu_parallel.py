@@ -34,6 +34,19 @@ def test_two_ranks_on_one_gpu(case):
     assert p.stdout.count('reducer == mean of per-rank gradients') == 2, p.stdout[-2000:]
 
 
+def test_sync_bn_two_ranks_equal_the_global_batch():
+    """--sync_bn (train.py:65-68: apex convert_syncbn_model) on the trainable ResNet extractor: two ranks with half a batch each
+    give the statistics, features and (summed) gradients of one process on the whole batch; without the flag they do not
+    (tests/syncbn_gpu_worker.py).  ADVICE r5: the flag used to be parsed and ignored."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(HERE, 'syncbn_gpu_worker.py')]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert p.stdout.count('sync_bn == one process on the global batch') == 2, p.stdout[-2000:]
+    print(p.stdout.strip().splitlines()[-1])
+
+
 def test_rccl_world1_forced_allreduce():
     """the RCCL path executes.  One rank, backend nccl, SVOL_FORCE_ALLREDUCE=1: every bucket of the full cfg2 step is
     all-reduced by RCCL on the communication stream behind the producer-stream waits (tests/rccl_world1_worker.py); gradients equal the
