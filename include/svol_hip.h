@@ -293,6 +293,27 @@ int svol_match_cost(const float* logits, const float* boxes, const float* tgt_bo
 int svol_lsap_batched(const float* cost, const int64_t* cost_off, const int32_t* pred_off, const int32_t* pred_cnt,
                       const int32_t* tgt_off, const int32_t* tgt_cnt, int32_t* match, int32_t* status,
                       int32_t n_problems, int32_t max_dim, void* stream);
+/* ---- the heads and the criterion's autograd glue as single launches (the forward -> backward turn of the training step) --------------
+ * svol_heads_fwd: SVANet's class head Linear(d, 2) (svanet.py:44,125) and box head MLP(d, d, 4, 3) -> sigmoid (svanet.py:42,126-127,144-156)
+ * on the stacked decoder states hs [R = layers * B * N, D] (fp32, exact-fp32 MFMA whatever the compute dtype): logits [R,2], boxes [R,4],
+ * and the two hidden activations h1, h2 [R,D] (post-ReLU) for the backward.  D a multiple of 32, <= 512.
+ * svol_heads_bwd: its backward from dlogits [R,2] / dboxes [R,4]: dhs [R,D]; gp0, gp1 [R,D] = the gradients w.r.t. the pre-activations
+ * of MLP layers 0 / 1 — the caller forms dW0 = gp0^T hs, db0 = colsum(gp0), dW1 = gp1^T h1, db1 = colsum(gp1) with svol_gemm_tn, off the
+ * critical path —; the 2- and 4-row weight gradients dWc [2,D], dbc [2], dW2 [4,D], db2 [4] are ADDED in place (fp32 atomics: the caller
+ * zeroes them or passes running sums; SVOL_E_UNSUPPORTED under SVOL_DETERMINISTIC).
+ * svol_set_loss_bwd: the criterion's backward (loss.py:39-60,76-103 differentiated): dlogits = g_label * dl[layer][0], dboxes = g_bbox *
+ * dl[layer][1] + g_giou * dl[layer][2] from svol_set_loss's unit gradients and dl [layers,4] (device) = d(objective) / d(loss table).
+ * svol_weighted_total / _bwd: out[0] = sum_i x[i] w[i] (train.py:227-228 on the [layers,4] loss table, w = weight_dict laid out
+ * likewise), dx[i] = w[i] dout[0]; n <= 1024. */
+int svol_heads_fwd(const float* hs, const float* Wc, const float* bc, const float* W0, const float* b0, const float* W1, const float* b1,
+                   const float* W2, const float* b2, float* logits, float* h1, float* h2, float* boxes, int64_t R, int64_t D, void* stream);
+int svol_heads_bwd(const float* dlogits, const float* dboxes, const float* hs, const float* h1, const float* h2, const float* boxes,
+                   const float* Wc, const float* W0, const float* W1, const float* W2, float* dhs, float* gp0, float* gp1, float* dWc,
+                   float* dbc, float* dW2, float* db2, int64_t R, int64_t D, void* stream);
+int svol_set_loss_bwd(const float* g_label, const float* g_bbox, const float* g_giou, const float* dl, float* dlogits, float* dboxes,
+                      int64_t n_layers, int64_t rows_per_layer, void* stream);
+int svol_weighted_total(const float* x, const float* w, int64_t n, float* out, void* stream);
+int svol_weighted_total_bwd(const float* w, const float* dout, int64_t n, float* dx, void* stream);
 /* HOST entry (no device, no stream): one rectangular LSAP with scipy.optimize.linear_sum_assignment's semantics, for a
  * caller that keeps the reference's host-side matching (matcher.py:86 `C.cpu()`, :93 / :158 `linear_sum_assignment(c)`).  cost = row-major
  * [nr, nc] fp64 in HOST memory; rows / cols = caller-owned int64[min(nr, nc)] (host).  Returns the number of pairs (= min(nr, nc); rows

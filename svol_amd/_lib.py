@@ -23,6 +23,11 @@ _u64 = ctypes.c_uint64
 SIGNATURES = {
     'svol_block_trace_dump': [ctypes.c_char_p, _i64],
     'svol_lsap_solve': [_p, _i64, _i64, _p, _p],
+    'svol_heads_fwd': [_p] * 13 + [_i64, _i64, _p],
+    'svol_heads_bwd': [_p] * 17 + [_i64, _i64, _p],
+    'svol_set_loss_bwd': [_p] * 6 + [_i64, _i64, _p],
+    'svol_weighted_total': [_p, _p, _i64, _p, _p],
+    'svol_weighted_total_bwd': [_p, _p, _i64, _p, _p],
     'svol_cast': [_p, _int, _p, _int, _i64, _p],
     'svol_cast_transpose': [_p, _p, _p, _int, _i64, _i64, _p],
     'svol_cast_split': [_p, _i64, _p, _i64, _i64, _p],

@@ -116,6 +116,8 @@ class SetCriterion(nn.Module):
                 for i in range(NL - 1):
                     t[i, col] = float(self.weight_dict.get(f'{name}_{i}', 0.0))
             w = self._wtab = t.to(losses.device)
+        if ops.FUSED_HEADS:   # one tiny launch each way instead of a multiply + a reduction (and their three backward kernels)
+            return ops.WeightedTotalFn.apply(losses, w)
         return (losses * w).sum()
 
     def last_indices(self):

@@ -118,8 +118,11 @@ class SVANet(nn.Module):
         hs = self.transformer(vid, skch.reshape(skch.shape[0], -1), kbias, pos_video,
                               self.query_embed.weight)  # [NL,B,N,d] fp32
         # heads run in fp32 (tiny; keeps logits / box coordinates at full precision)
-        outputs_class = ops.linear(hs, self.class_embed.weight, self.class_embed.bias)
-        outputs_coord = self.bbox_embed(hs, last_act=ops.ACT_SIGMOID)
+        if ops.heads_fusable(hs, self.class_embed, self.bbox_embed):   # both heads, all layers, one launch (csrc/heads.hip)
+            outputs_class, outputs_coord = ops.heads(hs, self.class_embed, self.bbox_embed)
+        else:
+            outputs_class = ops.linear(hs, self.class_embed.weight, self.class_embed.bias)
+            outputs_coord = self.bbox_embed(hs, last_act=ops.ACT_SIGMOID)
         out = {'pred_logits': outputs_class[-1], 'pred_boxes': outputs_coord[-1]}
         if self.aux_loss:
             out['aux_outputs'] = [{'pred_logits': a, 'pred_boxes': b}

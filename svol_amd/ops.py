@@ -1430,6 +1430,115 @@ def cast_ag(x, dtype):
     return x if x.dtype == dtype else CastFn.apply(x, dtype)
 
 
+# ---- the forward -> backward turn: heads, criterion glue (csrc/heads.hip) ------------------------------------------------------------
+FUSED_HEADS = os.environ.get('SVOL_NO_FUSED_HEADS') is None and os.environ.get('SVOL_DETERMINISTIC') is None
+
+
+def heads_fusable(hs, class_embed, bbox_embed):
+    """the one-launch heads take: fp32 decoder states of width D (multiple of 32, <= 512), Linear(D, 2) and a 3-layer MLP(D, D, 4)."""
+    if not FUSED_HEADS or hs.dtype != torch.float32 or not hs.is_cuda:
+        return False
+    D = hs.shape[-1]
+    ls = list(bbox_embed.layers)
+    return (D % 32 == 0 and D <= 512 and len(ls) == 3 and tuple(class_embed.weight.shape) == (2, D) and class_embed.bias is not None
+            and tuple(ls[0].weight.shape) == (D, D) and tuple(ls[1].weight.shape) == (D, D) and tuple(ls[2].weight.shape) == (4, D)
+            and all(l.bias is not None for l in ls) and all(t.dtype == torch.float32 for t in (class_embed.weight, ls[0].weight)))
+
+
+class HeadsFn(torch.autograd.Function):
+    """(pred_logits, pred_boxes) of ALL decoder layers from the stacked states hs [..., D]: class_embed = Linear(D, 2) and
+    bbox_embed = MLP(D, D, 4, 3) -> sigmoid (svanet.py:125-127) in ONE launch, exact fp32; the backward is one launch for dhs and the
+    2- / 4-row weight gradients, the two D x D weight gradients go to the weight-gradient stream."""
+
+    @staticmethod
+    def forward(ctx, hs, Wc, bc, W0, b0, W1, b1, W2, b2):
+        shp = hs.shape
+        D = shp[-1]
+        hs2 = hs.reshape(-1, D)
+        if not hs2.is_contiguous():
+            hs2 = hs2.contiguous()
+        R = hs2.shape[0]
+        dev = hs.device
+        logits = torch.empty((R, 2), dtype=torch.float32, device=dev)
+        boxes = torch.empty((R, 4), dtype=torch.float32, device=dev)
+        hid = torch.empty((2, R, D), dtype=torch.float32, device=dev)
+        rc = _lib.lib().svol_heads_fwd(_ptr(hs2), _ptr(Wc), _ptr(bc), _ptr(W0), _ptr(b0), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(logits),
+                                       _ptr(hid[0]), _ptr(hid[1]), _ptr(boxes), R, D, _stream())
+        _lib.check(rc, 'svol_heads_fwd')
+        ctx.save_for_backward(hs2, hid, boxes, Wc, W0, W1, W2)
+        ctx.shp = shp
+        ni = ctx.needs_input_grad
+        ctx.sinks = tuple(_claim(p_, ni[i + 1]) for i, p_ in enumerate((Wc, bc, W0, b0, W1, b1, W2, b2)))
+        return logits.view(*shp[:-1], 2), boxes.view(*shp[:-1], 4)
+
+    @staticmethod
+    def backward(ctx, dlogits, dboxes):
+        hs2, hid, boxes, Wc, W0, W1, W2 = ctx.saved_tensors
+        R, D = hs2.shape
+        dev = hs2.device
+        dlogits = torch.zeros((R, 2), dtype=torch.float32, device=dev) if dlogits is None else dlogits.reshape(R, 2).float().contiguous()
+        dboxes = torch.zeros((R, 4), dtype=torch.float32, device=dev) if dboxes is None else dboxes.reshape(R, 4).float().contiguous()
+        sWc, sbc, sW0, sb0, sW1, sb1, sW2, sb2 = ctx.sinks
+        g = torch.empty((3, R, D), dtype=torch.float32, device=dev)   # dhs, g_pre0, g_pre1
+        small = None
+        if not (sWc is not None and sbc is not None and sW2 is not None and sb2 is not None):
+            small = torch.zeros((6 * D + 6,), dtype=torch.float32, device=dev)
+        dWc = sWc.view if sWc is not None else small[:2 * D].view(2, D)
+        dbc = sbc.view if sbc is not None else small[6 * D:6 * D + 2]
+        dW2 = sW2.view if sW2 is not None else small[2 * D:6 * D].view(4, D)
+        db2 = sb2.view if sb2 is not None else small[6 * D + 2:]
+        rc = _lib.lib().svol_heads_bwd(_ptr(dlogits), _ptr(dboxes), _ptr(hs2), _ptr(hid[0]), _ptr(hid[1]), _ptr(boxes), _ptr(Wc), _ptr(W0),
+                                       _ptr(W1), _ptr(W2), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(dWc), _ptr(dbc), _ptr(dW2), _ptr(db2),
+                                       R, D, _stream())
+        _lib.check(rc, 'svol_heads_bwd')
+        ni = ctx.needs_input_grad
+        out = [g[0].view(ctx.shp) if ni[0] else None]
+        out += [None if sWc is not None else dWc, None if sbc is not None else dbc]
+        for gp, x, sW, sb, iw in ((g[1], hs2, sW0, sb0, 3), (g[2], hid[0], sW1, sb1, 5)):
+            if sW is not None and sb is not None:
+                gemm_tn_sink(gp, x, out=sW.view, colsum=sb.view)      # off the critical path (weight-gradient stream)
+                out += [None, None]
+            else:
+                buf = torch.zeros((D * D + D,), dtype=torch.float32, device=dev)
+                gemm_tn(gp, x, out=buf[:D * D].view(D, D), colsum=buf[D * D:])
+                dW_, db_ = buf[:D * D].view(D, D), buf[D * D:]
+                if sW is not None:
+                    sW.view.add_(dW_)
+                    dW_ = None
+                if sb is not None:
+                    sb.view.add_(db_)
+                    db_ = None
+                out += [dW_ if ni[iw] else None, db_ if ni[iw + 1] else None]
+        out += [None if sW2 is not None else dW2, None if sb2 is not None else db2]
+        return tuple(out)
+
+
+def heads(hs, class_embed, bbox_embed):
+    ls = bbox_embed.layers
+    return HeadsFn.apply(hs, class_embed.weight, class_embed.bias, ls[0].weight, ls[0].bias, ls[1].weight, ls[1].bias, ls[2].weight, ls[2].bias)
+
+
+class WeightedTotalFn(torch.autograd.Function):
+    """sum(losses * w) over the [layers, 4] loss table (train.py:227-228) as one tiny launch each way."""
+
+    @staticmethod
+    def forward(ctx, losses, w):
+        x = losses.contiguous()
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().svol_weighted_total(_ptr(x), _ptr(w), x.numel(), _ptr(out), _stream()), 'svol_weighted_total')
+        ctx.save_for_backward(w)
+        ctx.shape = losses.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (w,) = ctx.saved_tensors
+        d = dout.float().contiguous()
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=w.device)
+        _lib.check(_lib.lib().svol_weighted_total_bwd(_ptr(w), _ptr(d), w.numel(), _ptr(dx), _stream()), 'svol_weighted_total_bwd')
+        return dx, None
+
+
 class SetCriterionFn(torch.autograd.Function):
     """All decoder layers' matching + losses in three launches (cost, LSAP, loss); no host sync.
     logits [NL,B,N,2], boxes [NL,B,N,4] fp32 -> losses [NL,4] = (label, bbox, giou, class_error)."""
@@ -1458,6 +1567,13 @@ class SetCriterionFn(torch.autograd.Function):
     def backward(ctx, dl, _dmatch):
         g_label, g_bbox, g_giou = ctx.saved_tensors
         dl = dl.float()
+        if FUSED_HEADS and dl.is_contiguous():   # one launch instead of five elementwise ones (csrc/heads.hip)
+            dlog, dbox = torch.empty_like(g_label), torch.empty_like(g_bbox)
+            NL = g_label.shape[0]
+            rc = _lib.lib().svol_set_loss_bwd(_ptr(g_label), _ptr(g_bbox), _ptr(g_giou), _ptr(dl), _ptr(dlog), _ptr(dbox), NL,
+                                              g_label.numel() // (2 * NL), _stream())
+            _lib.check(rc, 'svol_set_loss_bwd')
+            return dlog, dbox, None, None, None, None, None
         dlog = g_label * dl[:, 0].view(-1, 1, 1, 1)
         dbox = g_bbox * dl[:, 1].view(-1, 1, 1, 1) + g_giou * dl[:, 2].view(-1, 1, 1, 1)
         return dlog, dbox, None, None, None, None, None

@@ -677,6 +677,64 @@ def check_lsap_vs_scipy(n_cases=60):
     return {'lsap/mismatching_problems': (float(bad), 0.0), 'lsap/status_nonzero': (float(status.abs().max()), 0.0)}
 
 
+def check_heads():
+    """svol_heads_fwd / _bwd, svol_set_loss_bwd, svol_weighted_total(_bwd) (csrc/heads.hip: the forward -> backward turn) against fp64
+    torch on the same fp32 values: class Linear(D, 2) + box MLP(D, D, 4, 3) -> sigmoid (svanet.py:125-127,144-156) and every gradient,
+    ragged row counts (rows past the last 32-row tile), D = 32 / 64 / 256 / 512, with and without reducer-owned gradient sinks."""
+    import torch.nn as nn
+    from svol_amd import parallel
+    from svol_amd.modeling.svanet import MLP
+    res = {}
+    for (shape, D) in [((3, 70), 32), ((2, 5, 13), 64), ((6, 8, 100), 256), ((1, 33), 512)]:
+        for sinks in (False, True):
+            torch.manual_seed(D + sinks)
+            ce, be = nn.Linear(D, 2), MLP(D, D, 4, 3)
+            ce.cuda(), be.cuda()
+            hs = torch.randn(*shape, D, device=DEV, requires_grad=True)
+            assert ops.heads_fusable(hs, ce, be)
+            params = list(ce.parameters()) + list(be.parameters())
+            if sinks:
+                red = parallel.BucketedGradAllReduce(params, bucket_bytes=1 << 20)
+                red.zero_grad()
+            lg, bx = ops.heads(hs, ce, be)
+            pl, pb = torch.randn_like(lg), torch.randn_like(bx)
+            ((lg * pl).sum() + (bx * pb).sum()).backward()
+            if sinks:
+                red.finish()
+            torch.cuda.synchronize()
+            h64 = hs.detach().double().cpu().requires_grad_(True)
+            p64 = [p_.detach().double().cpu().requires_grad_(True) for p_ in params]
+            rl = h64 @ p64[0].t() + p64[1]
+            x = torch.relu(h64 @ p64[2].t() + p64[3])
+            x = torch.relu(x @ p64[4].t() + p64[5])
+            rb = torch.sigmoid(x @ p64[6].t() + p64[7])
+            ((rl * pl.double().cpu()).sum() + (rb * pb.double().cpu()).sum()).backward()
+            tag = f'heads/D{D}/rows{hs.numel() // D}{"/sinks" if sinks else ""}'
+            res[tag + '/logits'] = (rel_err(lg, rl), 2e-6)
+            res[tag + '/boxes'] = (rel_err(bx, rb), 2e-6)
+            res[tag + '/dhs'] = (rel_err(hs.grad, h64.grad), 2e-5)
+            names = ['dWc', 'dbc', 'dW0', 'db0', 'dW1', 'db1', 'dW2', 'db2']
+            for n_, p_, r_ in zip(names, params, p64):
+                res[tag + '/' + n_] = (rel_err(p_.grad, r_.grad), 2e-5)
+    # the criterion's backward and the weighted total
+    NL, B, N = 3, 2, 17
+    gl, gb, gg = (torch.randn(NL, B, N, k, device=DEV) for k in (2, 4, 4))
+    dl = torch.randn(NL, 4, device=DEV)
+    dlog, dbox = torch.empty_like(gl), torch.empty_like(gb)
+    from svol_amd import _lib
+    _lib.check(_lib.lib().svol_set_loss_bwd(gl.data_ptr(), gb.data_ptr(), gg.data_ptr(), dl.data_ptr(), dlog.data_ptr(), dbox.data_ptr(), NL, B * N,
+                                            torch.cuda.current_stream().cuda_stream), 'svol_set_loss_bwd')
+    res['heads/set_loss_bwd/dlogits'] = (float((dlog - gl * dl[:, 0].view(-1, 1, 1, 1)).abs().max()), 0.0)
+    res['heads/set_loss_bwd/dboxes'] = (float((dbox - (gb * dl[:, 1].view(-1, 1, 1, 1) + gg * dl[:, 2].view(-1, 1, 1, 1))).abs().max()), 2e-6)
+    x = torch.randn(6, 4, device=DEV, requires_grad=True)
+    w = torch.rand(6, 4, device=DEV)
+    t = ops.WeightedTotalFn.apply(x, w)
+    (t * 3.0).backward()
+    res['heads/weighted_total'] = (abs(float(t) - float((x.detach().double() * w.double()).sum())), 1e-5)
+    res['heads/weighted_total_bwd'] = (float((x.grad - 3.0 * w).abs().max()), 1e-6)
+    return res
+
+
 # ---------------------------------------------------------------------------
 def run_head_case(name, dtype, sinks=False):
     """Full head + criterion forward/backward through the product modules; returns

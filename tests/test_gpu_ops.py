@@ -58,6 +58,10 @@ def test_gemm_tn_grouped(G):
     _assert(G.check_gemm_tn_grouped())
 
 
+def test_heads_and_criterion_glue_single_launches(G):
+    _assert(G.check_heads())
+
+
 def test_small_ops(G):
     _assert(G.check_small_ops())
 
