@@ -540,6 +540,11 @@ def main():
             res['allreduce_exposed_ms'] = ar_report['exposed_ms']
             res['allreduce_buckets'] = ar_report['buckets']
             res['allreduce_backend'] = 'nccl (RCCL), forced at world size 1' if force_ar else backend
+            res['allreduce_launch_order'] = [b_['bucket'] for b_ in ar_report['buckets']]   # = 0, 1, 2, ...: buckets fire in arrival order
+            if 'spin_model' in ar_report:
+                # SVOL_ALLREDUCE_SPIN: every bucket's collective is followed by a spin kernel of its modelled 8-rank xGMI duration
+                res['allreduce_spin_model'] = ar_report['spin_model']
+                res['allreduce_modelled_ms'] = ar_report['modelled_ms']
         if issue_per_rank is not None:
             res['host_issue_ms_per_rank'] = issue_per_rank
             res['host_cores_per_rank'] = cores_rank

@@ -103,6 +103,16 @@ class BucketedGradAllReduce:
         self.spans = []            # per launched bucket: (bucket index, start event, end event) on the communication stream (GPU only)
         self.exposed = None        # (event, event) around finish()'s wait for the communication stream: the exchange backward did not hide
         self.record_spans = self.force or os.environ.get('SVOL_DP_SPANS') == '1'
+        # SVOL_ALLREDUCE_SPIN=ring|direct (with SVOL_FORCE_ALLREDUCE=1 only): a one-rank communicator's all-reduce is a copy — to
+        # rehearse a collective that COSTS TIME on one GPU, a spin kernel of the exchange's modelled duration over xGMI at 8 ranks
+        # follows every bucket's collective on the communication stream (7 links x ~153 GB/s per GPU,
+        # point to point): ring 2 (7/8) bytes / 153 GB/s (per-link bound), direct reduce-scatter + all-gather 2 (bytes / 8) / 153 GB/s
+        # + 20 us.  The spin holds one CU and moves no bytes: it tests the ORDER and EXPOSURE of the exchange (which buckets hide
+        # behind backward, what finish() waits for), not the bandwidth RCCL's copies take from the weight-gradient stream.
+        self.spin = os.environ.get('SVOL_ALLREDUCE_SPIN') if self.force else None
+        if self.spin not in (None, 'ring', 'direct'):
+            raise ValueError('SVOL_ALLREDUCE_SPIN must be ring or direct')
+        self._spin_cycles_per_ms = None
         self.pending_scale = 1.0   # see finish(mean=False)
         self.fire_order: List[int] = []   # diagnostics: bucket index of every hook of the current step, in firing order
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
@@ -187,6 +197,9 @@ class BucketedGradAllReduce:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(self.comm_stream)
                 h = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.spin is not None:
+                    h.wait()
+                    torch.cuda._sleep(int(self.modelled_exchange_ms(b['flat'].numel() * 4) * self._spin_rate()))
                 if self.record_spans:
                     h.wait()       # (stream-side wait: orders the communication stream behind the collective, does not block the host)
                     e1.record(self.comm_stream)
@@ -194,6 +207,26 @@ class BucketedGradAllReduce:
         else:
             h = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._handles.append((h, b))
+
+    def modelled_exchange_ms(self, nbytes: int, ranks: int = 8, link_gbs: float = 153.0) -> float:
+        """duration of one bucket's all-reduce over xGMI in the SVOL_ALLREDUCE_SPIN model (see __init__)."""
+        if self.spin == 'direct':
+            return 2.0 * (nbytes / ranks) / (link_gbs * 1e9) * 1e3 + 0.02
+        return 2.0 * (ranks - 1) / ranks * nbytes / (link_gbs * 1e9) * 1e3
+
+    def _spin_rate(self) -> float:
+        """torch.cuda._sleep cycles per millisecond on this device (calibrated once, synchronising; first use only)."""
+        if self._spin_cycles_per_ms is None:
+            s_ = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(s_):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda._sleep(1_000_000)
+                e0.record(s_)
+                torch.cuda._sleep(20_000_000)
+                e1.record(s_)
+            e1.synchronize()
+            self._spin_cycles_per_ms = 20_000_000 / max(e0.elapsed_time(e1), 1e-3)
+        return self._spin_cycles_per_ms
 
     def zero_grad(self):
         """Zero the flat buckets (replaces optimizer.zero_grad(); keeps the grad views alive)."""
@@ -262,7 +295,11 @@ class BucketedGradAllReduce:
         out = [{'bucket': bi, 'mib': round(self.buckets[bi]['flat'].numel() * 4 / 2 ** 20, 2), 'start_ms': round(t0.elapsed_time(e0), 3),
                 'ms': round(e0.elapsed_time(e1), 3)} for bi, e0, e1 in self.spans]
         exposed = self.exposed[0].elapsed_time(self.exposed[1]) if self.exposed else 0.0
-        return {'buckets': out, 'exposed_ms': round(exposed, 4)}
+        rep = {'buckets': out, 'exposed_ms': round(exposed, 4)}
+        if self.spin is not None:
+            rep['spin_model'] = self.spin
+            rep['modelled_ms'] = [round(self.modelled_exchange_ms(self.buckets[bi]['flat'].numel() * 4), 3) for bi, _e0, _e1 in self.spans]
+        return rep
 
     def bucket_fire_spans(self):
         """diagnostics after a backward: per bucket (first, last) position of its hooks in the step's firing order —

@@ -70,6 +70,38 @@ def test_bench_reports_allreduce_spans_with_rccl_at_world1():
     assert len(line['allreduce_buckets']) >= 4 and all(b['ms'] > 0 for b in line['allreduce_buckets']), line['allreduce_buckets']
 
 
+def test_bench_hides_a_collective_that_costs_time_behind_backward():
+    """rehearse, on ONE GPU, an all-reduce that takes time.  SVOL_FORCE_ALLREDUCE=1 runs every bucket through a
+    one-rank RCCL communicator; SVOL_ALLREDUCE_SPIN=ring follows each collective with a spin kernel of the exchange's modelled
+    8-rank xGMI duration (ring: 2 (7/8) bytes / 153 GB/s — 0.19 ms for a 16 MiB bucket, 0.89 ms for the step's 74 MiB).  Asserted: the
+    buckets fire in arrival order (0, 1, 2, ...), every bucket but the last is hidden behind backward — the step grows by no more
+    than the LAST bucket's span (+ noise) although the exchange as a whole is several times longer —, and finish() waits about that
+    last span."""
+    import json
+    bench = os.path.join(os.path.dirname(HERE), 'bench.py')
+    lines = {}
+    for spin in (None, 'ring'):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', SVOL_FORCE_ALLREDUCE='1')
+        if spin:
+            env['SVOL_ALLREDUCE_SPIN'] = spin
+        p = subprocess.run([sys.executable, bench, '--steps', '10', '--warmup', '4', '--blocks', '3', '--no-cpu-baseline'], env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+        lines[spin] = json.loads(p.stdout.strip().splitlines()[-1])
+    base, spun = lines[None], lines['ring']
+    bk = spun['allreduce_buckets']
+    assert spun['allreduce_launch_order'] == list(range(len(bk))) and len(bk) >= 4
+    total = sum(b['ms'] for b in bk)
+    last = bk[-1]['ms']
+    assert all(abs(b['ms'] - m) <= 0.25 * m + 0.05 for b, m in zip(bk, spun['allreduce_modelled_ms'])), (bk, spun['allreduce_modelled_ms'])
+    growth = spun['ms_per_step'] - base['ms_per_step']
+    print(f'spin rehearsal: exchange {total:.2f} ms in {len(bk)} buckets (last {last:.3f} ms), step {base["ms_per_step"]:.2f} -> '
+          f'{spun["ms_per_step"]:.2f} ms (+{growth:.2f}), exposed in finish() {spun["allreduce_exposed_ms"]:.3f} ms')
+    assert total > 0.6
+    assert growth <= last + 0.25, (growth, last)               # (0.25 ms: run-to-run noise of two bench processes on one box)
+    assert spun['allreduce_exposed_ms'] <= last + 0.1
+
+
 @pytest.mark.gpu
 def test_flat_adamw_matches_torch_adamw():
     """svol_amd.parallel.FlatAdamW (one kernel per gradient bucket) against torch.optim.AdamW on the same gradients, 4 steps;
