@@ -1667,6 +1667,153 @@ __device__ __forceinline__ void mma_packed(f32x16& acc, const uint4 (&a)[2], con
 }
 __device__ __forceinline__ void sp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ===========================================================================================
+// FEW-QUERY backward (round 6): the query -> video cross-attention (cross_modal_transformer.py:151-156) has N = 100 queries against
+// L = 6272 keys.  It used to take the general two-pass kernels (a key-split dQ pass + a dK/dV pass, 256 + 3136 workgroups, 16 MFMAs and
+// two exp passes per 32 x 32 block) — on the query stream, i.e. BESIDE the video stream's single-pass attention backward, whose
+// one-wave-per-SIMD workgroups cannot share a CU with anything: a timing-only ablation (zero fills in place of these launches) moved the
+// whole step from 17.20 to 16.29 ms (profiles/round6_summary.md).  Here the launch is ONE key-stationary pass, the single-pass
+// algorithm in its plain, compiler-scheduled form: a workgroup owns `tiles_per_split` consecutive 128-key tiles of one (batch, head)
+// (a wave: 32 keys of each), the <= 128 queries stay in LDS for its whole life,
+//   S = Q K^T, P = exp2(S - lse + key bias), dV^T += dO^T P, dP = dO V^T, dS = P (dP - delta), dK^T += Q^T dS  (key on the lane), and
+//   dQ[q][d] += dS[q][key] K[key][d]: the packed dS block crosses the wave's own LDS image once and comes back transposed; its B
+//   operand is the K tile read in natural row order;
+// dK / dV of a tile are final when its 32-query blocks are done; dQ stays in 64 accumulator registers per wave over all the
+// workgroup's tiles, the four waves' partials meet in LDS and leave as fp32 atomics into the key-split path's zeroed fp32 image
+// (attn_delta_bf16 zeroes it, attn_dq_finish_bf16 scales and rounds it): 10 MFMAs and one exp pass per block, ~450 short workgroups.
+template <bool KBIAS>
+__global__ __launch_bounds__(256, 2) void attn_bwd_fq_bf16(Args p) {
+    __shared__ __attribute__((aligned(16))) char smem[3 * IMG + 2 * KT * 4 + 4 * 2048];
+    char* sQ = smem;                 // [128 q][32 d]
+    char* sdO = smem + IMG;
+    char* sK = smem + 2 * IMG;       // the current key tile (row reads for the score product, natural-order transposed reads for dQ)
+    float* sL = reinterpret_cast<float*>(smem + 3 * IMG);   // [KT] -lse2
+    float* sD = sL + KT;                                    // [KT] delta
+    char* sT = smem + 3 * IMG + 2 * KT * 4;                 // [wave][32 keys][32 q] dS images
+    float* sRed = reinterpret_cast<float*>(smem);           // epilogue: [wave][32 q][32 d] fp32 partials (over sQ / sdO: 16 KiB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, hh = blockIdx.y;
+    const h16_t* Q = reinterpret_cast<const h16_t*>(p.q) + (int64_t)b * p.Lq * p.ldq + hh * 32;
+    const h16_t* dO = reinterpret_cast<const h16_t*>(p.d_o) + (int64_t)b * p.Lq * p.lddo + hh * 32;
+    const h16_t* K = reinterpret_cast<const h16_t*>(p.k) + (int64_t)b * p.Lk * p.ldk + hh * 32;
+    const h16_t* V = reinterpret_cast<const h16_t*>(p.v) + (int64_t)b * p.Lk * p.ldv + hh * 32;
+    h16_t* dKo = reinterpret_cast<h16_t*>(p.dk) + (int64_t)b * p.Lk * p.lddk + hh * 32;
+    h16_t* dVo = reinterpret_cast<h16_t*>(p.dv) + (int64_t)b * p.Lk * p.lddv + hh * 32;
+    const float c = p.premul != 0.f ? 1.f : p.scale * LOG2E;
+    const float kmul = p.premul != 0.f ? p.scale / p.premul : p.scale;
+    const int nsub = (p.Lq + 31) >> 5;                      // 32-query blocks (launcher: Lq <= 128)
+    const int ntk = (p.Lk + KT - 1) / KT;
+    const int t0 = blockIdx.x * p.tiles_per_split, t1 = min(ntk, t0 + p.tiles_per_split);
+    Stage st;
+    {
+        Stage sq, sdo;
+        load_regs(sq, Q, p.ldq, 0, p.Lq, 32, tid);
+        load_regs(sdo, dO, p.lddo, 0, p.Lq, 32, tid);
+        load_regs(st, K, p.ldk, t0 * KT, p.Lk, 32, tid);
+        if (tid < KT) {
+            const int64_t si = ((int64_t)b * p.H + hh) * p.Lq + tid;
+            sL[tid] = tid < p.Lq ? -p.lse2[si] : -INFINITY;   // exp2(x - inf) = 0 for rows past Lq
+            sD[tid] = tid < p.Lq ? p.delta[si] : 0.f;
+        }
+        store_lds(sQ, sq, tid);
+        store_lds(sdO, sdo, tid);
+        store_lds(sK, st, tid);
+    }
+    __syncthreads();
+    f32x16 dQ[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dQ[i] = zero16();
+    char* img = sT + wave * 2048;
+    for (int t = t0; t < t1; ++t) {
+        const int krow = t * KT + wave * 32 + r;
+        const bool kvalid = krow < p.Lk;
+        uint4 kbk[2], vbk[2], kd[2];
+        read_rows(kbk, sK, wave * 32 + r, h);
+        read_tr_nat(kd, sK, wave, lane);
+        load_lane_block(vbk, V, p.ldv, krow, kvalid, 32, h);
+        if (t + 1 < t1) load_regs(st, K, p.ldk, (t + 1) * KT, p.Lk, 32, tid);   // next key tile in flight under this tile's products
+        float kbl = kvalid ? 0.f : -INFINITY;
+        if (KBIAS && kvalid) kbl = p.kbias[(int64_t)b * p.Lk + krow] * LOG2E;
+        f32x16 dKa = zero16(), dVa = zero16();
+        if (!__all(kbl == -INFINITY)) {   // (a wave whose 32 keys are all masked has P = 0: dK = dV = 0, nothing for dQ)
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {   // (unrolled: the dQ accumulators keep compile-time register names)
+                if (sub >= nsub) break;
+                uint4 a[2];
+                read_rows(a, sQ, sub * 32 + r, h);
+                f32x16 S = mma_first(a, kbk);   // S[q][key]
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 ls = *reinterpret_cast<const f32x4*>(sL + sub * 32 + 8 * g + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) S[4 * g + e] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[4 * g + e], c, kbl + ls[e]));
+                }
+                read_tr(a, sdO, sub, lane);
+                mma_second(dVa, a, S);          // dV^T += dO^T P
+                read_rows(a, sdO, sub * 32 + r, h);
+                const f32x16 dP = mma_first(a, vbk);   // dP[q][key] = dO V^T
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 dl = *reinterpret_cast<const f32x4*>(sD + sub * 32 + 8 * g + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) S[4 * g + e] = S[4 * g + e] * (dP[4 * g + e] - dl[e]);
+                }
+                uint4 ds[2];
+                pack16(ds, S);
+                read_tr(a, sQ, sub, lane);
+                mma_packed(dKa, a, ds);         // dK^T += Q^T dS
+                // dS [q][key] -> this wave's [key][q] image -> back transposed as the A operand of dQ += dS K
+                *reinterpret_cast<uint2*>(img + ds_off(r, 0, h)) = make_uint2(ds[0].x, ds[0].y);
+                *reinterpret_cast<uint2*>(img + ds_off(r, 1, h)) = make_uint2(ds[0].z, ds[0].w);
+                *reinterpret_cast<uint2*>(img + ds_off(r, 2, h)) = make_uint2(ds[1].x, ds[1].y);
+                *reinterpret_cast<uint2*>(img + ds_off(r, 3, h)) = make_uint2(ds[1].z, ds[1].w);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                read_ds_tr(a, img, lane);
+                mma_packed(dQ[sub], a, kd);
+                __builtin_amdgcn_wave_barrier();   // (the image is rewritten by the next block only after this read)
+            }
+        }
+        store_acc(dKa, dKo, p.lddk, krow, kvalid, 32, h, kmul);
+        store_acc(dVa, dVo, p.lddv, krow, kvalid, 32, h, 1.f);
+        __syncthreads();                 // every wave is done with this key tile's image
+        if (t + 1 < t1) {
+            store_lds(sK, st, tid);
+            __syncthreads();
+        }
+    }
+    // dQ: the four waves' partials per 32-query block meet in LDS (over the Q / dO images: every wave passed the loop's last barrier), one
+    // row group per thread quad, and leave as fp32 atomics into the zeroed [B, Lq, H, 32] image
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+        if (sub >= nsub) break;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sRed[(wave * 32 + 8 * g + 4 * h + e) * 32 + r] = dQ[sub][4 * g + e];
+        __syncthreads();
+        {
+            const int row = tid >> 3, d0 = (tid & 7) * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(sRed + row * 32 + d0);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(sRed + (w * 32 + row) * 32 + d0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += u[e];
+            }
+            const int q = sub * 32 + row;
+            if (q < p.Lq) {
+                float* z = p.ws_dq + ((int64_t)b * p.Lq + q) * (p.H * 32) + hh * 32 + d0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) unsafeAtomicAdd(z + e, v[e]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // before the single pass: delta = rowsum(dO * O); the row constants as plain fp32 vectors nl = -lse2, nd = -delta ([B,H,Lq], the
 // loop DMAs 64 of them per wave instruction); the fp32 dQ image zeroed.  One thread per (row, head), 32 rows x H heads per block;
 // the [B,H,Lq] side is read / written through LDS so that both sides of the transposition are coalesced.
@@ -2710,6 +2857,12 @@ static bool sp_shape_ok(int B, int H, int Lq, int Lk, int dh) {
     static const int min_lk = getenv("SVOL_ATTN_SP_MIN_LK") ? atoi(getenv("SVOL_ATTN_SP_MIN_LK")) : 2 * SP_KEYS;
     return !no_sp && dh == 32 && H == 8 && (B * H) % 8 == 0 && Lq % KT == 0 && Lk % KT == 0 && Lk >= min_lk;
 }
+// the single-pass few-query backward (attn_bwd_fq_bf16): <= 128 queries, the key-split path's fp32 dQ image bound (ksplit > 1: few
+// query tiles, many key tiles, workspace large enough), head width 32, no attention dropout; SVOL_ATTN_NO_FEWQ=1: the two-pass kernels
+static bool fewq_ok(const Args& p) {
+    static const bool off = getenv("SVOL_ATTN_NO_FEWQ") != nullptr;
+    return !off && !attn_deterministic() && p.ksplit > 1 && p.Lq <= KT && p.dh == 32 && p.drop_p == 0.f && p.ws_dq != nullptr;
+}
 static int64_t sp_ws_floats(int B, int H, int Lq, int Lk) { return (int64_t)B * Lq * H * 32 + (int64_t)B * H * 4 * 2 * (Lk % SP_KEYS) * 32; }
 int64_t svol_attn_ws_floats_bf16(int B, int H, int Lq, int Lk, int dh) {
     int tps;
@@ -2857,6 +3010,17 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
             if (dma) hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre_dma, gk2, dim3(256), 0, s, pk);
             else hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre, gk2, dim3(256), 0, s, pk);
         }
+    } else if (fewq_ok(p)) {
+        // few queries against many keys (the query -> video cross attention): ONE key-stationary pass (attn_bwd_fq_bf16); the delta launch
+        // above has zeroed the fp32 dQ image (ksplit > 1), attn_dq_finish_bf16 scales and rounds it
+        Args pf = p;
+        const int want = max(1, 512 / (B * H));                 // ~512 workgroups
+        const int chunks = min(ntk, want);
+        pf.tiles_per_split = (ntk + chunks - 1) / chunks;
+        const dim3 gf((unsigned)((ntk + pf.tiles_per_split - 1) / pf.tiles_per_split), (unsigned)H, (unsigned)B);
+        if (kbias) hipLaunchKernelGGL(attn_bwd_fq_bf16<true>, gf, dim3(256), 0, s, pf);
+        else hipLaunchKernelGGL(attn_bwd_fq_bf16<false>, gf, dim3(256), 0, s, pf);
+        hipLaunchKernelGGL(attn_dq_finish_bf16, gd, dim3(256), 0, s, p);
     } else if (masked) {
         hipLaunchKernelGGL(attn_bwd_dq_bf16<true>, gq, dim3(256), 0, s, p);
         if (p.ksplit > 1) hipLaunchKernelGGL(attn_dq_finish_bf16, gd, dim3(256), 0, s, p);

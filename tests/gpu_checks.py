@@ -506,7 +506,9 @@ def check_attention():
     cases = [(2, 4, 70, 150, 8, True), (1, 8, 200, 200, 32, False), (2, 8, 100, 333, 32, True), (1, 2, 129, 64, 16, False),
              (1, 8, 384, 384, 32, False), (2, 4, 200, 256, 32, False), (1, 2, 100, 128, 8, False),
              # few queries x many keys: the bf16 path splits the keys over workgroups (last splits fully masked / ragged)
-             (2, 4, 100, 1500, 32, True), (1, 8, 70, 2048, 32, False), (2, 2, 130, 1100, 16, True),
+             # (round 6: <= 128 queries at head width 32 take the single-pass few-query backward, attn_bwd_fq_bf16: 1 - 4 query blocks)
+             (2, 4, 100, 1500, 32, True), (1, 8, 70, 2048, 32, False), (2, 2, 130, 1100, 16, True), (1, 8, 128, 1280, 32, True),
+             (2, 8, 7, 1100, 32, False),
              # many queries, masked + ragged keys: the fast kernels with per-tile classes (plain / mixed / skipped tiles)
              (2, 8, 1600, 1100, 32, True), (1, 16, 1700, 1153, 32, False)]
     for dt in DTYPES16:
