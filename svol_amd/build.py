@@ -19,7 +19,7 @@ SOURCES = ['gemm.hip', 'gemm_bf16.hip', 'gemm_tn_bf16.hip', 'gemm_ws_bf16.hip', 
 # the MFMA-path files are written against h16_t (csrc/common.h) and compiled a second time with fp16 operands
 H16_SOURCES = ['gemm_bf16.hip', 'gemm_tn_bf16.hip', 'gemm_ws_bf16.hip', 'gemm_n256_bf16.hip', 'attention_bf16.hip']
 ARCH = 'gfx950'
-COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function'] + os.environ.get('SVOL_BUILD_DEFS', '').split()   # (SVOL_BUILD_DEFS: lab builds, e.g. -DSVOL_GELU_AS)
 PER_FILE = {'criterion.hip': ['-ffp-contract=off'], 'posteval.hip': ['-ffp-contract=off'],  # bit-exact cost / LSAP arithmetic
             # SLP-packed f32 math (v_pk_mul_f32 on odd register pairs + v_mov/v_perm fix-ups) costs the VALU-bound
             # attention loops 20-30 % more vector instructions than the scalar form

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_r${RN:-5}
 rm -rf $O; mkdir -p $O
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o r${RN:-5} -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o r${RN:-5} -- python3 bench.py --steps 10 --warmup 3 --blocks 1 --no-cpu-baseline > $O/bench.json 2> $O/bench.err
 F=$(find $O/kt -name "*kernel_stats.csv" | head -1)
 cp $F $O/round${RN:-5}_kernel_stats.csv
 python tools/prof_summary.py $F 16 > $O/round${RN:-5}_kernel_stats.txt

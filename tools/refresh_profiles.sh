@@ -18,10 +18,10 @@ echo "== block trace (no profiler)"
 SVOL_BLOCK_TRACE=1 python tools/block_trace.py 10 > $O/round${RN}_block_trace.txt 2>&1
 SVOL_BLOCK_TRACE=2 python tools/block_trace.py 6 > $O/round${RN}_block_timeline.txt 2>&1
 echo "== cfg5 fp16: traffic, kernel stats, roofline"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch5 -o f -- python3 bench.py --workload cfg5 --dtype fp16 --steps 2 --warmup 1 --no-cpu-baseline > $O/f5.json 2> $O/f5.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write5 -o w -- python3 bench.py --workload cfg5 --dtype fp16 --steps 2 --warmup 1 --no-cpu-baseline > $O/w5.json 2> $O/w5.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch5 -o f -- python3 bench.py --workload cfg5 --dtype fp16 --steps 2 --warmup 1 --blocks 1 --no-cpu-baseline > $O/f5.json 2> $O/f5.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write5 -o w -- python3 bench.py --workload cfg5 --dtype fp16 --steps 2 --warmup 1 --blocks 1 --no-cpu-baseline > $O/w5.json 2> $O/w5.err
 python tools/hbm_traffic.py $(find $O/fetch5 -name "*counter_collection.csv") $(find $O/write5 -name "*counter_collection.csv") $O/round${RN}_cfg5_fp16_hbm_traffic $HEAD > /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt5 -o r5 -- python3 bench.py --workload cfg5 --dtype fp16 --steps 5 --warmup 2 --no-cpu-baseline > $O/kt5_bench.json 2> $O/kt5_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt5 -o r5 -- python3 bench.py --workload cfg5 --dtype fp16 --steps 5 --warmup 2 --blocks 1 --no-cpu-baseline > $O/kt5_bench.json 2> $O/kt5_bench.err
 cp $(find $O/kt5 -name "*kernel_stats.csv" | head -1) $O/round${RN}_cfg5_fp16_kernel_stats.csv
 python tools/fwd_traffic.py $(find $O/kt5 -name "*kernel_trace.csv" | head -1) $O/round${RN}_cfg5_fp16_hbm_traffic.json 224 "cfg5 (B=1, T=128, P=256, L=32768, fp16)" > $O/round${RN}_cfg5_fp16_roofline.txt 2>&1 || true
 rm -rf $O/fetch5 $O/write5 $O/kt5
