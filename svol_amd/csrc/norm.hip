@@ -234,9 +234,20 @@ __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ m
         const float dim_t = powf(10000.f, (float)(2 * (i / 2)) / (float)D);
         const bool odd = i & 1;
         T* out = pos + ((int64_t)b * L + l0) * D + i;
-        for (int t = 0; t < ntok; ++t) {
-            const float a = xe[t] / dim_t;
-            out[(int64_t)t * D] = from_f32<T>(odd ? cosf(a) : sinf(a));
+        if constexpr (sizeof(T) == 4) {   // fp32 (the parity mode): the reference's own arithmetic — a true division, libm sin / cos
+            for (int t = 0; t < ntok; ++t) {
+                const float a = xe[t] / dim_t;
+                out[(int64_t)t * D] = from_f32<T>(odd ? cosf(a) : sinf(a));
+            }
+        } else {
+            // 16-bit outputs (8 / 11 significant bits): the argument lies in [0, 2 pi] (x is normalised to 2 pi, dim_t >= 1), where the
+            // hardware sine / cosine (v_sin_f32 / v_cos_f32 on revolutions) are good to ~1e-6 absolute — libm's range reduction and
+            // polynomial made this kernel VALU-bound at 51 us for a 26 MB output (round 6: the step's first kernels are a serial chain)
+            const float inv = 0.15915494309189535f / dim_t;   // revolutions per unit of x
+            for (int t = 0; t < ntok; ++t) {
+                const float rev = xe[t] * inv;
+                out[(int64_t)t * D] = from_f32<T>(odd ? __builtin_amdgcn_cosf(rev) : __builtin_amdgcn_sinf(rev));
+            }
         }
     }
 }
