@@ -330,6 +330,21 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_bf16_m2(WsArgs p) { gemm_ws_bo
 // in the same basic block as slab j+1's MFMAs (the activation, the epilogue flags are template parameters: no branches),
 // so it fills the LDS latency and the matrix pipe's shadow.  Everything slab j's epilogue needs from LDS (MODE 2: the
 // saved pre-activation) is read with the fragments, because sync(j) hands slab j's slot back to the DMA ring.
+
+// A THIRD compiler trap (round 6).  buffer_store_dwordx4 reads its 16 bytes of data per lane over several cycles, a quarter of the wave
+// at a time; a VALU instruction that OVERWRITES one of the four data registers right behind the store can win the race for the last
+// lanes of the later dwords.  LLVM pads this hazard only for stores WITHOUT an SGPR soffset (GCNHazardRecognizer::createsVALUHazard);
+// with one — every epilogue store here: the slab advances the scalar offset — hipcc (ROCm 7.2) emitted
+//     buffer_store_dwordx4 v[0:3], v212, s[0:3], s4 offen ; v_pk_mul_f32 v[0:1], v[8:9], v[8:9]
+// and on gfx950 the `pre` output carried the low halves of fp32 squares in element 2 of rows 12-15 of a slab (lanes 48-63, dword 1):
+// NaN / +-65 440 in ~1 element of 5 000, sporadic, `out` untouched.  Round 1-5's epilogues never put a writer of the data registers
+// directly behind a store (allocation luck); a shorter GELU epilogue tried in round 6 did (that epilogue itself measured +-0 in the
+// step and was not kept).  The data registers are kept alive across two wait states here.
+__device__ __forceinline__ void store_b128_guarded(u32x4_t v, __amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voffset, soffset, 0);
+    asm volatile("s_nop 1" ::"v"(v));
+}
+
 template <int MODE, int ACT, bool PRE, bool SCALE, int VPM>
 __device__ __forceinline__ void gemm_wsp_body(const WsArgs& p) {
     static_assert(MODE == 0 || MODE == 2, "bf16 outputs only");
@@ -483,8 +498,8 @@ __device__ __forceinline__ void gemm_wsp_body(const WsArgs& p) {
                 for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[hf][e] = (h16_t)pre_save_fast(v[hf][e], ACT);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[0]), rP, voffP, j * pstep, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[1]), rP, voffP + 64, j * pstep, 0);
+                store_b128_guarded(__builtin_bit_cast(u32x4_t, o[0]), rP, voffP, j * pstep);
+                store_b128_guarded(__builtin_bit_cast(u32x4_t, o[1]), rP, voffP + 64, j * pstep);
             }
             h16x8 o[2];
 #pragma unroll
@@ -496,8 +511,8 @@ __device__ __forceinline__ void gemm_wsp_body(const WsArgs& p) {
                     if constexpr (ACT == SVOL_ACT_RELU) y = fmaxf(y, 0.f);
                     o[hf][e] = (h16_t)y;
                 }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[0]), rC, voffC, j * cstep, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[1]), rC, voffC + 64, j * cstep, 0);
+            store_b128_guarded(__builtin_bit_cast(u32x4_t, o[0]), rC, voffC, j * cstep);
+            store_b128_guarded(__builtin_bit_cast(u32x4_t, o[1]), rC, voffC + 64, j * cstep);
         } else {
             h16x8 o[2];
 #pragma unroll
@@ -511,8 +526,8 @@ __device__ __forceinline__ void gemm_wsp_body(const WsArgs& p) {
                     o[hf][e] = (h16_t)d;
                 }
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[0]), rC, voffC, j * cstep, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[1]), rC, voffC + 64, j * cstep, 0);
+            store_b128_guarded(__builtin_bit_cast(u32x4_t, o[0]), rC, voffC, j * cstep);
+            store_b128_guarded(__builtin_bit_cast(u32x4_t, o[1]), rC, voffC + 64, j * cstep);
         }
     };
 
