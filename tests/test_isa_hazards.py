@@ -231,3 +231,51 @@ def test_no_attention_kernel_spills(tmp_path, flag):
         if spill or scratch:
             bad[name] = (spill, scratch)
     assert not bad, bad
+
+
+def _store_data_hazards(asm_text, min_states=2):
+    """every `buffer_store_dwordx{3,4}` whose soffset is an SGPR: the instructions within `min_states` wait states behind it must not
+    WRITE one of its data registers.  LLVM pads this hazard only for stores without an SGPR soffset (GCNHazardRecognizer::
+    createsVALUHazard); on gfx950 an overwrite right behind an SGPR-offset store corrupted the wave's last lanes (round 6,
+    svol_amd/csrc/gemm_ws_bf16.hip::store_b128_guarded).  Returns (stores seen, list of violations)."""
+    lines = asm_text.split('\n')
+    insts = [(n, _parse(l)) for n, l in enumerate(lines)]
+    insts = [(n, p) for n, p in insts if p]
+    seen, bad = 0, []
+    for k, (n, (op, ops)) in enumerate(insts):
+        if not re.fullmatch(r'buffer_store_dwordx[34]', op) or len(ops) < 4:
+            continue
+        if not re.fullmatch(r's\d+', ops[3]):       # soffset: an SGPR (an immediate / `off` form is the case LLVM handles itself)
+            continue
+        data = _regs(ops[0])
+        if not data:
+            continue
+        seen += 1
+        states = 0
+        for n2, (op2, ops2) in insts[k + 1:]:
+            if states >= min_states or op2.startswith('s_cbranch') or op2 in ('s_branch', 's_endpgm', 's_barrier'):
+                break
+            if op2.startswith('v_') and ops2:
+                dst = _regs(ops2[0])
+                if dst and dst[0] == data[0] and (dst[1] & data[1]):
+                    bad.append((states, lines[n].strip(), lines[n2].strip()))
+                    break
+            states += _wait_states(op2, ops2, 8)
+    return seen, bad
+
+
+@pytest.mark.parametrize('flag', [[], ['-DSVOL_H16_FP16']], ids=['bf16', 'fp16'])
+def test_buffer_store_data_registers_are_not_overwritten_behind_the_store(tmp_path, flag):
+    """Round 6's compiler trap: the weight-stationary GEMM's epilogue stores (buffer_store_dwordx4 with an SGPR soffset) followed at
+    once by a VALU write of their data registers — hipcc emits no wait states there, the hardware needs some.  Static check of the
+    emitted code of the file that uses such stores, both operand types."""
+    hipcc = _hipcc()
+    if hipcc is None:
+        pytest.skip('hipcc not found')
+    from svol_amd import build
+    src = os.path.join(REPO, 'svol_amd', 'csrc', 'gemm_ws_bf16.hip')
+    out = str(tmp_path / 'ws.s')
+    subprocess.check_call([hipcc] + build.COMMON + flag + ['--cuda-device-only', '-S', src, '-o', out], stderr=subprocess.DEVNULL)
+    seen, bad = _store_data_hazards(open(out).read())
+    assert seen >= 40, seen                   # ten pipelined kernels x (loop + tail) x 2 - 4 stores
+    assert not bad, bad[:5]
