@@ -250,6 +250,20 @@ int svol_gate_bwd(const float* dy32, const void* dy, const void* dy2, const floa
                   const float* ws, float* ws2, float* dx32, float* du, float* dgamma, float* dbeta, int64_t B,
                   int64_t L, int64_t D, int64_t H, int dtype, void* stream);
 
+/* The gate of layer i + 1 with its score pass folded into layer i's last LayerNorm (round 6; cross_modal_transformer.py:122-127 behind
+ * :143): the gate vectors of every layer depend only on the sketch token, so they exist before the layer loop.
+ *   svol_layernorm_gate_scores_fwd: y = LN(x32) exactly as svol_layernorm_fwd (no dropout; y32 / y / ypos = y + pos, each may be
+ *     NULL, not all; pos REQUIRED, one row per token) and scores_next[b,h,l] = (y + pos)[b,l,:] . u_next[b,h,:] — the bits of
+ *     svol_gate_fwd's own score pass over the stored fp32 row.  scores_next = the first B*H*L floats of the NEXT gate's ws.
+ *     L % 4 != 0 or D > 256 -> SVOL_E_UNSUPPORTED (run svol_layernorm_fwd, and svol_gate_fwd for the next layer).
+ *   svol_gate_fwd_scored: svol_gate_fwd with ws[0 .. B*H*L) already filled that way (statistics + apply only). */
+int svol_layernorm_gate_scores_fwd(const float* x32, const float* gamma, const float* beta, float* y32, void* y, void* ypos,
+                                   const void* pos, float* mean, float* rstd, const float* u_next, float* scores_next,
+                                   int64_t B, int64_t L, int64_t D, int64_t H, int dtype, void* stream);
+int svol_gate_fwd_scored(const float* x32, const void* pos, const float* u, const float* gamma, const float* beta,
+                         float* y32, void* y, void* ypos, float* a, float* mean, float* rstd, float* ws, int64_t B,
+                         int64_t L, int64_t D, int64_t H, int dtype, void* stream);
+
 /* Gate VECTORS (the B*d-sized algebra in front of the gate): q[b,:] = W_q s_b + b_q, u[b,h,:] = d_h^-1/2 * W_k,h^T q[b,h,:],
  * with W_in [3d,d] / b_in [3d] the packed nn.MultiheadAttention in_proj parameters (rows 0..d-1 = W_q, d..2d-1 = W_k),
  * skch [B,d] the projected sketch token, all fp32.  Backward: du [B,H,d] -> dskch [B,d] (may be NULL), and dW_in / db_in are
@@ -494,6 +508,9 @@ int svol_block_trace_dump(char* buf, int64_t cap);
 /* video half (:122-143): gate -> LN1 ; q|k, v projections, self-attention, out-proj + residual -> LN2 ; fc1+GELU, fc2 + residual
  * -> LN3 (+pos).  M = B*L rows.
  *  in : X32 f32 [M,D] · POS dt [M,D] · U f32 [B,H,D] (svol_gate_vectors_fwd)
+ *       optional (round 6, all three NULL = the plain program): GATE_PRE non-NULL = GATE_WS already holds this layer's scores (the
+ *       layer before wrote them through ITS GATE_WS_NEXT: the caller points both layers' slots at one buffer) · U_NEXT f32 [B,H,D]
+ *       + GATE_WS_NEXT f32 [B*H*(L+2)]: LN3 also writes the NEXT layer's gate scores (svol_layernorm_gate_scores_fwd; L % 4 == 0, D <= 256)
  *  par: G1,BT1,G2,BT2,G3,BT3 f32 [D] (norm weight, bias) · B_IN f32 [3D] · B_O [D] · B_FC1 [F] · B_FC2 [D] · QSCALE f32 [2D] or NULL
  *  w  : W_IN dt [3D,D] · WV_HILO bf16 [D,2D] or NULL · W_O dt [D,D] · W_FC1 dt [F,D] · W_FC2 dt [D,F] and the transposes
  *       W_IN_T [D,3D] · W_O_T · W_FC1_T [D,F] · W_FC2_T [F,D]
@@ -508,7 +525,8 @@ int svol_block_trace_dump(char* buf, int64_t cap);
 #define SVOL_VH_SLOTS(X) \
     X(X32) X(POS) X(U) X(G1) X(BT1) X(G2) X(BT2) X(G3) X(BT3) X(B_IN) X(B_O) X(B_FC1) X(B_FC2) X(QSCALE) \
     X(W_IN) X(WV_HILO) X(W_O) X(W_FC1) X(W_FC2) X(W_IN_T) X(W_O_T) X(W_FC1_T) X(W_FC2_T) \
-    X(Y1) X(Y1POS) X(A) X(MEAN1) X(RSTD1) X(GATE_WS) X(QKV) X(O) X(LSE) X(S2) X(Y2) X(MEAN2) X(RSTD2) X(PRE) X(HID) X(S3) \
+    X(Y1) X(Y1POS) X(A) X(MEAN1) X(RSTD1) X(GATE_WS) X(GATE_PRE) X(U_NEXT) X(GATE_WS_NEXT) \
+    X(QKV) X(O) X(LSE) X(S2) X(Y2) X(MEAN2) X(RSTD2) X(PRE) X(HID) X(S3) \
     X(MEAN3) X(RSTD3) X(M32) X(M) X(MPOS) X(Y1_32) X(Y2_32) X(ATTN_WS) \
     X(DM32) X(DM) X(DMPOS) X(DS32_3) X(DS3) X(DPRE) X(DY2) X(DS32_2) X(G2D) X(DO) X(DQKV) X(DELTA) X(DXQP) X(DXQ) X(GATE_WS2) \
     X(DX32) X(DU) \

@@ -25,6 +25,12 @@ from . import _lib, ops
 
 WGRAD_SPLIT = os.environ.get('SVOL_WGRAD_SPLIT') is not None   # measured: +0.16 ms/step (more work beside the attention backward than the shorter tail saves)
 ENABLED = os.environ.get('SVOL_NO_BLOCKS') is None
+# SVOL_GATE_SCORES_FUSE=1: layer i's LN3 also writes layer i + 1's gate scores (svol_layernorm_gate_scores_fwd) and that layer skips its
+# own score pass — same bits (tests/test_gpu_head.py).  OFF by default: alone the pair of launches is 25 us per layer shorter
+# (LN3 28.5 -> 33.3 us, gate 72.5 -> 42.6 us), in the step it is 0.1-0.2 ms per step SLOWER on three alternating same-box pairs
+# (17.35-17.45 against 17.25-17.30 ms): the query stream's block, which used to run beside the gate and the projections, slides
+# under the attention forward (430 -> 446 us per layer in the block trace) — profiles/round6_summary.md.
+GATE_SCORES_FUSE = os.environ.get('SVOL_GATE_SCORES_FUSE') is not None
 VH, QS, QC = 0, 1, 2
 _F32, _BF16 = 0, 1
 _ESZ = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2}
@@ -388,7 +394,10 @@ class VideoHalfFn(torch.autograd.Function):
     """(m32, m, m + pos) = LN3(. + MLP1(.)) o LN2(. + SelfAttn(.)) o LN1(gate(x32))  — cross_modal_transformer.py:122-143."""
 
     @staticmethod
-    def forward(ctx, pl, x32, pos, u, *params):
+    def forward(ctx, pl, x32, pos, u, u_next, sc_in, *params):
+        """u_next: the NEXT layer's gate vectors or None; sc_in: the gate workspace the layer before filled with THIS layer's scores
+        (its fourth output) or None.  Fourth output: the next layer's gate workspace (empty when u_next is None) — plain storage,
+        not differentiable: the next layer's gate backward differentiates the scores through ITS x32, as it always did."""
         ctx.set_materialize_grads(False)
         B, L, D = x32.shape
         layer = pl.layer()
@@ -415,6 +424,18 @@ class VideoHalfFn(torch.autograd.Function):
         tbl.set('X32', x2.data_ptr())
         tbl.set('POS', pos2.data_ptr())
         tbl.set('U', u.data_ptr())
+        if sc_in is not None:
+            assert sc_in.dtype == torch.float32 and sc_in.numel() == B * H * (L + 2) and sc_in.is_contiguous()
+            tbl.set('GATE_WS', sc_in.data_ptr())
+            tbl.set('GATE_PRE', sc_in.data_ptr())
+        if u_next is not None:
+            u_next = u_next.contiguous()
+            assert u_next.dtype == torch.float32 and u_next.shape == u.shape and L % 4 == 0
+            sc_next = torch.empty((B * H * (L + 2),), dtype=torch.float32, device=dev)
+            tbl.set('U_NEXT', u_next.data_ptr())
+            tbl.set('GATE_WS_NEXT', sc_next.data_ptr())
+        else:
+            sc_next = torch.empty((0,), dtype=torch.float32, device=dev)
         dims = _dims(B, L, 0, D, H, F, dt, dt, wsb)
         big = B * H * L * L >= ops._WGRAD_FLUSH_MIN_SCORES
         if big:
@@ -426,21 +447,25 @@ class VideoHalfFn(torch.autograd.Function):
         _lib.check(_lib.lib().svol_video_half_fwd(dims, tbl.arr, ops._stream()), 'svol_video_half_fwd')
         tbl.set('EV_A0', None)
         tbl.set('EV_A1', None)
+        tbl.set('U_NEXT', None)
+        tbl.set('GATE_WS_NEXT', None)
         ctx.pl, ctx.tbl, ctx.dims, ctx.arena, ctx.shape, ctx.big = pl, tbl, dims, arena, (B, L, D, H, F), big
         ctx.n_par = len(params)
+        ctx.sc_in = sc_in   # (GATE_WS of the backward; statistics are written behind the scores: not a saved TENSOR, its version moves)
         ctx.save_for_backward(x2, pos2, u)
+        ctx.mark_non_differentiable(sc_next)
         return (lay.view(arena, 'M32', torch.float32, (B, L, D)), lay.view(arena, 'M', dt, (B, L, D)),
-                lay.view(arena, 'MPOS', dt, (B, L, D)))
+                lay.view(arena, 'MPOS', dt, (B, L, D)), sc_next)
 
     @staticmethod
-    def backward(ctx, dm32, dm, dmpos):
+    def backward(ctx, dm32, dm, dmpos, _dsc=None):
         pl, tbl, dims = ctx.pl, ctx.tbl, ctx.dims
         B, L, D, H, F = ctx.shape
         x2, pos2, u = ctx.saved_tensors
         n_par = ctx.n_par
         if dm32 is None and dm is None and dmpos is None:
             pl.done(n_par > 0)
-            return (None,) * (4 + n_par)
+            return (None,) * (6 + n_par)
         dt = pl.dt
         e = _ESZ[dt]
         dev = x2.device
@@ -485,12 +510,22 @@ class VideoHalfFn(torch.autograd.Function):
         pl.done(n_par > 0)
         dx32 = lay.view(tmp, 'DX32', torch.float32, (B, L, D))
         needs = ctx.needs_input_grad
-        return (None, dx32, None, du if needs[3] else None) + tuple(pl.grads_out(bufs, needs[4:], n_par > 0))
+        return (None, dx32, None, du if needs[3] else None, None, None) + tuple(pl.grads_out(bufs, needs[6:], n_par > 0))
 
 
-def video_half(layer, x32, pos, u, dt):
+def gate_scores_fusable(L, D, H):
+    """svol_layernorm_gate_scores_fwd's shapes (the four rows of a workgroup share one batch element's gate vectors)."""
+    return GATE_SCORES_FUSE and L % 4 == 0 and D % 4 == 0 and D <= 256 and H <= 8
+
+
+def video_half(layer, x32, pos, u, dt, u_next=None, sc_in=None):
+    """-> (m32, m, m + pos, sc_next): sc_next = the next layer's gate workspace with its scores when u_next was given (pass it to
+    that layer as sc_in), else None."""
     pl = plan(layer, VH, dt, dt)
-    return VideoHalfFn.apply(pl, x32, pos, u, *pl.inputs(x32, u))
+    if u_next is not None and not gate_scores_fusable(x32.shape[1], x32.shape[2], layer.nhead):
+        u_next = None
+    m32, m, mpos, sc = VideoHalfFn.apply(pl, x32, pos, u, u_next, sc_in, *pl.inputs(x32, u))
+    return m32, m, mpos, (sc if u_next is not None else None)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -185,8 +185,13 @@ int svol_video_half_fwd(const int64_t* dims, void* const* p, void* s) {
     const int dt = d.dt, xf = dt != SVOL_F32;
 #define P(n) p[SVOL_VH_##n]
     // gate + LN1 (:122-127)
-    RUN(svol_gate_fwd(f32(P(X32)), P(POS), f32(P(U)), f32(P(G1)), f32(P(BT1)), f32(P(Y1_32)), P(Y1), P(Y1POS), f32(P(A)), f32(P(MEAN1)),
-                      f32(P(RSTD1)), f32(P(GATE_WS)), d.B, d.L, D, d.H, dt, s));
+    // (GATE_PRE: the scores are in GATE_WS already — the LN3 of the layer before wrote them, see the end of this function)
+    if (P(GATE_PRE))
+        RUN(svol_gate_fwd_scored(f32(P(X32)), P(POS), f32(P(U)), f32(P(G1)), f32(P(BT1)), f32(P(Y1_32)), P(Y1), P(Y1POS), f32(P(A)),
+                                 f32(P(MEAN1)), f32(P(RSTD1)), f32(P(GATE_WS)), d.B, d.L, D, d.H, dt, s));
+    else
+        RUN(svol_gate_fwd(f32(P(X32)), P(POS), f32(P(U)), f32(P(G1)), f32(P(BT1)), f32(P(Y1_32)), P(Y1), P(Y1POS), f32(P(A)), f32(P(MEAN1)),
+                          f32(P(RSTD1)), f32(P(GATE_WS)), d.B, d.L, D, d.H, dt, s));
     // q | k from y + pos, v from y (:137-139)
     RUN(nt(P(Y1POS), D, P(W_IN), D, P(QKV), 3 * D, P(B_IN), P(QSCALE), M, 2 * D, D, dt, s));
     if (P(WV_HILO))
@@ -207,8 +212,12 @@ int svol_video_half_fwd(const int64_t* dims, void* const* p, void* s) {
     // library in round 5: tools/micro/mlp_chain_bf16.hip, profiles/round4_mlp_chain_lab.md)
     RUN(svol_gemm_nt(P(Y2), D, nullptr, 0, P(W_FC1), D, P(HID), F, f32(P(B_FC1)), nullptr, kVhGelu, P(PRE), F, nullptr, 0, 0, M, F, D, dt, s));
     RUN(nt_res(P(HID), F, P(W_FC2), F, P(S3), P(B_FC2), P(Y2_32), M, D, F, dt, s));
-    RUN(svol_layernorm_fwd(P(S3), xf, f32(P(G3)), f32(P(BT3)), f32(P(M32)), P(M), P(MPOS), P(POS), M, f32(P(MEAN3)), f32(P(RSTD3)), M, D,
-                           0.f, 0, nullptr, dt, s));
+    if (P(U_NEXT) && P(GATE_WS_NEXT))   // ... and the NEXT layer's gate scores from the row just normalised (S3 is fp32 in every mode)
+        RUN(svol_layernorm_gate_scores_fwd(f32(P(S3)), f32(P(G3)), f32(P(BT3)), f32(P(M32)), P(M), P(MPOS), P(POS), f32(P(MEAN3)),
+                                           f32(P(RSTD3)), f32(P(U_NEXT)), f32(P(GATE_WS_NEXT)), d.B, d.L, D, d.H, dt, s));
+    else
+        RUN(svol_layernorm_fwd(P(S3), xf, f32(P(G3)), f32(P(BT3)), f32(P(M32)), P(M), P(MPOS), P(POS), M, f32(P(MEAN3)), f32(P(RSTD3)), M, D,
+                               0.f, 0, nullptr, dt, s));
     return SVOL_OK;
 }
 

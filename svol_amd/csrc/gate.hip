@@ -15,6 +15,44 @@ namespace {
 constexpr int GP = 4;  // max passes: D <= 1024
 constexpr int GH = 8;  // max heads
 
+// 8 head sums over 64 lanes as ONE reduce-scatter butterfly: the xor-1 partners split the heads (each keeps four and adds the
+// partner's four), the xor-2 partners split again (two each), then two values ride the remaining four steps — 14 exchanges instead
+// of 8 x 6.  Lane q of quad 0 ends with heads {4*(q&1) + 2*(q>>1), +1} and stores them: scores[b, hh, l].
+__device__ __forceinline__ void store_head_sums(const float (&part)[GH], float* __restrict__ scores, int b, int l, int L, int H, int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float h4[4], h2[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float send = b0 ? part[i] : part[4 + i], keep = b0 ? part[4 + i] : part[i];
+        h4[i] = keep + dpp_f32<0xB1>(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float send = b1 ? h4[i] : h4[2 + i], keep = b1 ? h4[2 + i] : h4[i];
+        h2[i] = keep + dpp_f32<0x4E>(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float v = h2[i];
+        // the lanes of a quad hold DIFFERENT heads now: only lanes with the same position in their quad may be added — rotations of
+        // the 16-lane row by 4 and by 8 lanes.  (Until round 6 these two steps were wave_sum's row_half_mirror / row_mirror, which
+        // pair lane q with lane 3 - q of the neighbouring quad: every score was a mixture of heads.  LN1(x (1 + a)) is invariant to
+        // the per-token scale up to its epsilon, so no output, loss or parameter gradient moved beyond 1e-6 and nothing noticed;
+        // tests/gpu_checks.py::check_gate now compares the scores and the gate weights themselves.)
+        v += dpp_f32<0x124>(v);   // row_ror:4
+        v += dpp_f32<0x128>(v);   // row_ror:8
+        const HalfPair r16 = swap_rows16(__builtin_bit_cast(unsigned, v));
+        v = __builtin_bit_cast(float, r16.lo) + __builtin_bit_cast(float, r16.hi);
+        const HalfPair r32 = swap_halves(__builtin_bit_cast(unsigned, v));
+        h2[i] = __builtin_bit_cast(float, r32.lo) + __builtin_bit_cast(float, r32.hi);
+    }
+    if (lane < 4) {
+        const int hh0 = 4 * (lane & 1) + 2 * (lane >> 1);
+        if (hh0 < H) scores[((int64_t)b * H + hh0) * L + l] = h2[0];
+        if (hh0 + 1 < H) scores[((int64_t)b * H + hh0 + 1) * L + l] = h2[1];
+    }
+}
+
 // scores[b,hh,l] = (x+pos)[b,l,:] . u[b,hh,:]      grid = (ceil(L / (4*rpw)), B), one wave per row
 template <typename T, int NP>
 __global__ __launch_bounds__(256) void gate_scores_kernel(const float* __restrict__ x, const T* __restrict__ pos,
@@ -47,7 +85,6 @@ __global__ __launch_bounds__(256) void gate_scores_kernel(const float* __restric
         }
     };
     if (l0 < lend) fetch(l0, xv, pv);
-    const bool b0 = lane & 1, b1 = lane & 2;
     for (int l = l0; l < lend; ++l) {
         if (l + 1 < lend) fetch(l + 1, nxv, npv);  // next row in flight while this one is reduced
         float part[GH];
@@ -65,35 +102,7 @@ __global__ __launch_bounds__(256) void gate_scores_kernel(const float* __restric
                 }
             }
         }
-        // 8 head sums over 64 lanes as ONE reduce-scatter butterfly: the xor-1 partners split the heads (each keeps four and
-        // adds the partner's four), the xor-2 partners split again (two each), then two values ride the remaining four steps
-        // — 14 exchanges instead of 8 x 6.  Lane q of quad 0 ends with heads {4*(q&1) + 2*(q>>1), +1}.
-        float h4[4], h2[2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float send = b0 ? part[i] : part[4 + i], keep = b0 ? part[4 + i] : part[i];
-            h4[i] = keep + dpp_f32<0xB1>(send);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float send = b1 ? h4[i] : h4[2 + i], keep = b1 ? h4[2 + i] : h4[i];
-            h2[i] = keep + dpp_f32<0x4E>(send);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float v = h2[i];
-            v += dpp_f32<0x141>(v);
-            v += dpp_f32<0x140>(v);
-            const HalfPair r16 = swap_rows16(__builtin_bit_cast(unsigned, v));
-            v = __builtin_bit_cast(float, r16.lo) + __builtin_bit_cast(float, r16.hi);
-            const HalfPair r32 = swap_halves(__builtin_bit_cast(unsigned, v));
-            h2[i] = __builtin_bit_cast(float, r32.lo) + __builtin_bit_cast(float, r32.hi);
-        }
-        if (lane < 4) {
-            const int hh0 = 4 * (lane & 1) + 2 * (lane >> 1);
-            if (hh0 < H) scores[((int64_t)b * H + hh0) * L + l] = h2[0];
-            if (hh0 + 1 < H) scores[((int64_t)b * H + hh0 + 1) * L + l] = h2[1];
-        }
+        store_head_sums(part, scores, b, l, L, H, lane);
 #pragma unroll
         for (int j = 0; j < NP; ++j) { xv[j] = nxv[j]; pv[j] = npv[j]; }
     }
@@ -206,6 +215,112 @@ __global__ __launch_bounds__(256) void gate_apply_kernel(const float* __restrict
             if (ypos) op.store(ypos + row * D + c);
         }
     }
+}
+
+// LN3 of layer i with the gate scores of layer i + 1 as its epilogue: the row this wave has just normalised IS
+// the next layer's x, pos is already in registers for the + pos output, and every layer's gate vectors exist before the layer loop
+// (cross_modal_transformer.py: all_gate_vectors) — so the next layer's score pass (one more read of x32 + pos: 77 MB, 33 us at cfg2)
+// is 32 FMAs per lane here.  One row per wave as in ln_fwd_kernel (norm.hip: same arithmetic, same order -> the same bits), the four
+// rows of a workgroup belong to one batch element (launcher: L % 4 == 0) whose u[b] is staged in LDS once per workgroup; the
+// products and the head butterfly are gate_scores_kernel's, so the scores carry the same bits as the stand-alone pass too.
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void ln_scores_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y32, T* __restrict__ y,
+                                                        T* __restrict__ ypos, const T* __restrict__ pos, float* __restrict__ mean,
+                                                        float* __restrict__ rstd, const float* __restrict__ u,
+                                                        float* __restrict__ scores, int L, int D, int H) {
+    extern __shared__ __attribute__((aligned(16))) float su[];   // u[b]: [GH][D], rows >= H zero (no per-head branch below)
+    __builtin_assume(D % 4 == 0);   // (launcher) -> the rows of su are 16-byte aligned: ds_read_b128
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.y, l = blockIdx.x * 4 + (tid >> 6);   // grid = (L / 4, B)
+    const int64_t row = (int64_t)b * L + l;
+    {
+        const int nu = H * D;
+        const float* ub = u + (int64_t)b * nu;
+        for (int i = tid * 4; i < GH * D; i += 1024) {
+            f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < nu) w = *reinterpret_cast<const f32x4*>(ub + i);
+            *reinterpret_cast<f32x4*>(su + i) = w;
+        }
+    }
+    const float* xr = x + row * D;
+    const T* pr = pos + row * D;
+    Vec4<float> t[NP], gv[NP], bv[NP];
+    Vec4<T> pv[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < D) {
+            t[j].load(xr + c);
+            pv[j].load(pr + c);
+            gv[j].load(gamma + c);
+            bv[j].load(beta + c);
+        }
+    }
+    float v[NP][4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int c = (lane + 64 * j) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[j][e] = c < D ? t[j].get(e) : 0.f;
+            s += v[j][e];
+        }
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    float tp[NP][4];   // (y + pos) in fp32: what gate_scores_kernel forms from the stored fp32 row and pos
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int c = (lane + 64 * j) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tp[j][e] = 0.f;
+        if (c < D) {
+            Vec4<T> o, op;
+            Vec4<float> o32;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float r = (v[j][e] - mu) * rs * gv[j].get(e) + bv[j].get(e);
+                o.set(e, r);
+                o32.set(e, r);
+                op.set(e, r + pv[j].get(e));
+                tp[j][e] = r + pv[j].get(e);
+            }
+            if (y32) o32.store(y32 + row * D + c);
+            if (y) o.store(y + row * D + c);
+            if (ypos) op.store(ypos + row * D + c);
+        }
+    }
+    __syncthreads();
+    float part[GH];
+#pragma unroll
+    for (int hh = 0; hh < GH; ++hh) part[hh] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < D) {
+            f32x4 ur[GH];
+#pragma unroll
+            for (int hh = 0; hh < GH; ++hh) ur[hh] = *reinterpret_cast<const f32x4*>(su + hh * D + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int hh = 0; hh < GH; ++hh) part[hh] += tp[j][e] * ur[hh][e];
+            }
+        }
+    }
+    store_head_sums(part, scores, b, l, L, H, lane);
 }
 
 // backward pass 1: LN1 backward, dx_part = ds1*(1+a), da[row] = sum_d ds1*x ; dgamma/dbeta atomics.
@@ -646,9 +761,9 @@ int64_t gate_waves(int which) {
 
 extern "C" {
 
-int svol_gate_fwd(const float* x32, const void* pos, const float* u, const float* gamma, const float* beta, float* y32,
-                  void* y, void* ypos, float* a, float* mean, float* rstd, float* ws, int64_t B, int64_t L, int64_t D, int64_t H,
-                  int dtype, void* stream) {
+static int gate_fwd_impl(const float* x32, const void* pos, const float* u, const float* gamma, const float* beta, float* y32,
+                         void* y, void* ypos, float* a, float* mean, float* rstd, float* ws, int64_t B, int64_t L, int64_t D, int64_t H,
+                         int dtype, void* stream, bool scored) {
     if (!x32 || !pos || !u || !gamma || !beta || (!y && !y32) || !a || !mean || !rstd || !ws) return SVOL_E_INVALID;
     if (!aligned16(gamma) || !aligned16(beta)) return SVOL_E_INVALID;   // (16-byte vector loads of the affine parameters)
     if (B <= 0 || L <= 0 || D <= 0 || H <= 0) return SVOL_E_INVALID;
@@ -665,7 +780,8 @@ int svol_gate_fwd(const float* x32, const void* pos, const float* u, const float
     const unsigned g3 = (unsigned)((M + 3) / 4);
 #define SVOL_GATE_FWD(TT)                                                                                                   \
     do {                                                                                                                    \
-        if (np_ == 1) hipLaunchKernelGGL((gate_scores_kernel<TT, 1>), g1, dim3(256), 0, s, x32, (const TT*)pos, u, scores, (int)L, (int)D, (int)H, rpw); \
+        if (scored) { }                                                                                                      \
+        else if (np_ == 1) hipLaunchKernelGGL((gate_scores_kernel<TT, 1>), g1, dim3(256), 0, s, x32, (const TT*)pos, u, scores, (int)L, (int)D, (int)H, rpw); \
         else if (np_ == 2) hipLaunchKernelGGL((gate_scores_kernel<TT, 2>), g1, dim3(256), 0, s, x32, (const TT*)pos, u, scores, (int)L, (int)D, (int)H, rpw); \
         else hipLaunchKernelGGL((gate_scores_kernel<TT, 4>), g1, dim3(256), 0, s, x32, (const TT*)pos, u, scores, (int)L, (int)D, (int)H, rpw); \
         hipLaunchKernelGGL(gate_stats_kernel, dim3((unsigned)(B * H)), dim3(256), 0, s, scores, mx, sm, (int)L);            \
@@ -677,6 +793,43 @@ int svol_gate_fwd(const float* x32, const void* pos, const float* u, const float
     else if (dtype == SVOL_F16) SVOL_GATE_FWD(f16_t);
     else SVOL_GATE_FWD(float);
 #undef SVOL_GATE_FWD
+    SVOL_CHECK_LAUNCH();
+    return SVOL_OK;
+}
+
+int svol_gate_fwd(const float* x32, const void* pos, const float* u, const float* gamma, const float* beta, float* y32,
+                  void* y, void* ypos, float* a, float* mean, float* rstd, float* ws, int64_t B, int64_t L, int64_t D, int64_t H,
+                  int dtype, void* stream) {
+    return gate_fwd_impl(x32, pos, u, gamma, beta, y32, y, ypos, a, mean, rstd, ws, B, L, D, H, dtype, stream, false);
+}
+
+// ws already holds scores[b,h,l] (svol_layernorm_gate_scores_fwd of the layer before): statistics + apply only
+int svol_gate_fwd_scored(const float* x32, const void* pos, const float* u, const float* gamma, const float* beta, float* y32,
+                         void* y, void* ypos, float* a, float* mean, float* rstd, float* ws, int64_t B, int64_t L, int64_t D,
+                         int64_t H, int dtype, void* stream) {
+    return gate_fwd_impl(x32, pos, u, gamma, beta, y32, y, ypos, a, mean, rstd, ws, B, L, D, H, dtype, stream, true);
+}
+
+int svol_layernorm_gate_scores_fwd(const float* x32, const float* gamma, const float* beta, float* y32, void* y, void* ypos,
+                                   const void* pos, float* mean, float* rstd, const float* u_next, float* scores_next, int64_t B,
+                                   int64_t L, int64_t D, int64_t H, int dtype, void* stream) {
+    if (!x32 || !gamma || !beta || (!y && !y32 && !ypos) || !pos || !mean || !rstd || !u_next || !scores_next) return SVOL_E_INVALID;
+    if (!aligned16(gamma) || !aligned16(beta) || !aligned16(u_next)) return SVOL_E_INVALID;
+    if (B <= 0 || L <= 0 || D <= 0 || H <= 0) return SVOL_E_INVALID;
+    // (L % 4: the four rows of a workgroup share u[b]; D <= 256: one 16-byte column group per lane — the width at which this kernel's
+    // LayerNorm and svol_layernorm_fwd's compile to the same arithmetic, checked bit for bit by tests/gpu_checks.py)
+    if (D % 4 || D > 256 || H > GH || L % 4 || L > (1 << 24) || B > 65535) return SVOL_E_UNSUPPORTED;
+    if (!svol_is16(dtype) && dtype != SVOL_F32) return SVOL_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)(L / 4), (unsigned)B);
+    const size_t lds = (size_t)GH * D * sizeof(float);
+#define SVOL_LNS(TT)                                                                                                          \
+    hipLaunchKernelGGL((ln_scores_kernel<TT, 1>), grid, dim3(256), lds, s, x32, gamma, beta, y32, (TT*)y, (TT*)ypos,               \
+                       (const TT*)pos, mean, rstd, u_next, scores_next, (int)L, (int)D, (int)H)
+    if (dtype == SVOL_BF16) SVOL_LNS(bf16_t);
+    else if (dtype == SVOL_F16) SVOL_LNS(f16_t);
+    else SVOL_LNS(float);
+#undef SVOL_LNS
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }

@@ -211,10 +211,15 @@ class CrossModalTransformerLayer(nn.Module):
         m32, m, mpos = self.video_half(mem32, skch32, pos, u)
         return m32, self.query_half(out, m, mpos, qpos, kbias)
 
-    def video_half(self, mem32, skch32, pos, u=None):
-        """the "encoder-like" half, :122-143 -> (fp32 stream, compute-dtype copy, copy + pos)."""
+    def video_half(self, mem32, skch32, pos, u=None, u_next=None, sc_in=None):
+        """the "encoder-like" half, :122-143 -> (fp32 stream, compute-dtype copy, copy + pos).
+        With u_next (the NEXT layer's gate vectors; block programs only) -> (.., .., .., sc_next): this layer's last LayerNorm also
+        writes the next layer's gate scores; hand sc_next to that layer's call as sc_in (None when the shape is not fusable)."""
         if blocks.ENABLED:   # one C call for the whole half (svol_video_half_fwd), same kernels in the same order
-            return blocks.video_half(self, mem32, pos, self.gate_vectors(skch32) if u is None else u, pos.dtype)
+            uu = self.gate_vectors(skch32) if u is None else u
+            m32, m, mpos, sc = blocks.video_half(self, mem32, pos, uu, pos.dtype, u_next, sc_in)
+            return (m32, m, mpos) if u_next is None else (m32, m, mpos, sc)
+        assert sc_in is None
         h = self.nhead
         n = lambda m: (m.weight, m.bias)
         mha = lambda m: (m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias)
@@ -312,13 +317,19 @@ class CrossModalTransformer(nn.Module):
             # queued, overwritten by the video half before a lagging side stream had read it (a 1-in-15 garbage forward in
             # the test suite, in streaks; never seen in the bench, where the side stream does not lag at that point)
             out = initial_queries()
-        for layer, u in zip(self.layers, us):
+        sc = None   # the gate scores the layer before computed for this one (blocks.video_half)
+        for li, (layer, u) in enumerate(zip(self.layers, us)):
             # the query self-attention of layer i needs only layer i-1's queries: it goes out before this layer's video half is
             # issued and runs under it; only the cross-attention waits for the video tokens (the last layer's tail is shorter
             # by that block)
             with torch.cuda.stream(side):
                 out_sa = layer.query_self(out, qpos, vid_pos.dtype)
-            m32, m, mpos = layer.video_half(mem32, src_skch32, vid_pos, u)
+            if blocks.ENABLED and blocks.GATE_SCORES_FUSE and li + 1 < len(us):
+                m32, m, mpos, sc = layer.video_half(mem32, src_skch32, vid_pos, u, us[li + 1], sc)
+            elif sc is not None:
+                m32, m, mpos = layer.video_half(mem32, src_skch32, vid_pos, u, None, sc)
+            else:
+                m32, m, mpos = layer.video_half(mem32, src_skch32, vid_pos, u)
             side.wait_stream(main)
             m.record_stream(side)
             mpos.record_stream(side)

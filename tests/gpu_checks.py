@@ -592,6 +592,12 @@ def check_gate():
             res[tag + '/y32'] = (rel_err(y32, yr), 2e-5)
             res[tag + '/y'] = (rel_err(y, yr), TOL[dt])
             res[tag + '/ypos'] = (rel_err(ypos, ypr), TOL[dt])
+            # the scores and the gate weights themselves (the outputs above are nearly blind to them: see check_gate_scores_fused)
+            sv = y32.grad_fn.saved_tensors   # GateFn: (x2, pos2, u, gamma, a, mean, rstd, ws)
+            s64 = torch.einsum('bld,bhd->bhl', x64.detach() + pos.double(), u64.detach())
+            res[tag + '/scores'] = (float((sv[7][:B * H * L].view(B, H, L).double().cpu() - s64).abs().max() / s64.abs().max()), 2e-5)
+            a64 = torch.softmax(s64, -1).mean(1).reshape(-1)
+            res[tag + '/a'] = (float(((sv[4].double().cpu() - a64).abs() / a64).max()), 1e-4)
             (yr * (dy.double() + dy32.double()) + ypr * dyp.double()).sum().backward()
             torch.autograd.backward([y32, y, ypos], [dy32.to(DEV), dy.to(DEV), dyp.to(DEV)])
             res[tag + '/dx'] = (rel_err(xd.grad, x64.grad), 4e-5 if dt == torch.float32 else 1e-2)
@@ -601,6 +607,64 @@ def check_gate():
             res[tag + '/dbeta'] = (rel_err(bd.grad, b64.grad), 1e-4 if dt == torch.float32 else 1e-2)
     # a case where the gate gradient is NOT negligible: huge eps-equivalent via tiny-variance rows is not
     # constructible, so check dscore through du with a LARGE upstream signal on the softmax instead:
+    return res
+
+
+def check_gate_scores_fused():
+    """Layer i's LN3 with layer i + 1's gate scores as its epilogue (svol_layernorm_gate_scores_fwd + svol_gate_fwd_scored) against the
+    two stand-alone launches (svol_layernorm_fwd, svol_gate_fwd): every output, the saved statistics and the score workspace carry
+    the SAME BITS (same arithmetic in the same order), so nothing downstream — values, gradients, the oracle parity of the head
+    goldens — can tell which program ran.  cross_modal_transformer.py:143 + :122-127."""
+    from svol_amd import _lib
+    L_ = _lib.lib()
+    P, S = ops._ptr, ops._stream
+    res = {}
+    for dt in DTYPES16:
+        for (B, L, D, H) in [(2, 52, 32, 4), (3, 200, 256, 8), (1, 76, 128, 8), (2, 24, 64, 5), (1, 12, 252, 7), (2, 6272, 256, 8)]:
+            M = B * L
+            s3 = _rnd((M, D), torch.float32, 60).to(DEV)
+            pos = _rnd((M, D), dt, 61).to(DEV)
+            g3, b3 = (1 + 0.1 * _rnd((D,), torch.float32, 62)).to(DEV), (0.1 * _rnd((D,), torch.float32, 63)).to(DEV)
+            g1, b1 = (1 + 0.1 * _rnd((D,), torch.float32, 64)).to(DEV), (0.1 * _rnd((D,), torch.float32, 65)).to(DEV)
+            un = _rnd((B, H, D), torch.float32, 66, 0.2).to(DEV)
+            def outs():
+                e32 = lambda *sh: torch.empty(sh, dtype=torch.float32, device=DEV)
+                ed = lambda *sh: torch.empty(sh, dtype=dt, device=DEV)
+                return dict(m32=e32(M, D), m=ed(M, D), mpos=ed(M, D), mean3=e32(M), rstd3=e32(M), ws=torch.zeros(B * H * (L + 2), device=DEV),
+                            y32=e32(M, D), y=ed(M, D), ypos=ed(M, D), a=e32(M), mean1=e32(M), rstd1=e32(M))
+            r, f = outs(), outs()
+            d = ops._DT[dt]
+            _lib.check(L_.svol_layernorm_fwd(P(s3), 1, P(g3), P(b3), P(r['m32']), P(r['m']), P(r['mpos']), P(pos), M, P(r['mean3']),
+                                             P(r['rstd3']), M, D, 0.0, 0, None, d, S()), 'svol_layernorm_fwd')
+            _lib.check(L_.svol_gate_fwd(P(r['m32']), P(pos), P(un), P(g1), P(b1), P(r['y32']), P(r['y']), P(r['ypos']), P(r['a']),
+                                        P(r['mean1']), P(r['rstd1']), P(r['ws']), B, L, D, H, d, S()), 'svol_gate_fwd')
+            _lib.check(L_.svol_layernorm_gate_scores_fwd(P(s3), P(g3), P(b3), P(f['m32']), P(f['m']), P(f['mpos']), P(pos), P(f['mean3']),
+                                                         P(f['rstd3']), P(un), P(f['ws']), B, L, D, H, d, S()), 'svol_layernorm_gate_scores_fwd')
+            _lib.check(L_.svol_gate_fwd_scored(P(f['m32']), P(pos), P(un), P(g1), P(b1), P(f['y32']), P(f['y']), P(f['ypos']), P(f['a']),
+                                               P(f['mean1']), P(f['rstd1']), P(f['ws']), B, L, D, H, d, S()), 'svol_gate_fwd_scored')
+            torch.cuda.synchronize()
+            tag = f'gate_scores_fused/{dt}/B{B}L{L}D{D}H{H}'
+            for k in r:
+                res[f'{tag}/{k}_differing_elements'] = (float((r[k].float() != f[k].float()).sum()), 0.0)
+            # (and the scores are the dot products they claim to be)
+            sc = f['ws'][:B * H * L].view(B, H, L).double().cpu()
+            ref = torch.einsum('bld,bhd->bhl', (f['m32'].double().cpu() + pos.double().cpu()).view(B, L, D), un.double().cpu())
+            res[f'{tag}/scores_vs_fp64'] = (float((sc - ref).abs().max() / ref.abs().max().clamp_min(1e-30)), 2e-5)
+            # ... and the gate weights a = mean_h softmax_l(scores) (the model's outputs barely depend on them — LN1(x (1 + a)) is
+            # invariant to the per-token scale up to its epsilon —, so only a direct look can tell a wrong score from a right one:
+            # until round 6 the head butterfly of the score pass mixed heads and every parity test stayed green)
+            a_ref = torch.softmax(ref, -1).mean(1).reshape(-1)
+            res[f'{tag}/a_vs_fp64'] = (float(((f['a'].double().cpu() - a_ref).abs() / a_ref).max()), 1e-4)
+            res[f'{tag}/a_standalone_vs_fp64'] = (float(((r['a'].double().cpu() - a_ref).abs() / a_ref).max()), 1e-4)
+    # a token count that does not fill whole workgroups of one batch element is refused, not mis-computed
+    M, D, H = 2 * 50, 32, 4
+    z32 = torch.zeros((M, D), device=DEV)
+    zz = torch.zeros((M,), device=DEV)
+    v = torch.ones((D,), device=DEV)
+    rc = L_.svol_layernorm_gate_scores_fwd(P(z32), P(v), P(v), P(z32.clone()), None, None, P(z32), P(zz), P(zz.clone()),
+                                           P(torch.zeros((2, H, D), device=DEV)), P(torch.zeros((2 * H * 52,), device=DEV)), 2, 50, D, H,
+                                           ops._DT[torch.float32], S())
+    res['gate_scores_fused/L_not_multiple_of_4_is_unsupported'] = (float(rc != -2), 0.0)   # SVOL_E_UNSUPPORTED
     return res
 
 

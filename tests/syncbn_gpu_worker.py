@@ -48,9 +48,9 @@ def main():
         num = den = 0.0
         worst = 0.0
         for k, gl in grads.items():
-            gs = gl.clone()
+            gs = gl.cpu()
             dist.all_reduce(gs)                       # sum over ranks of d(sum of the per-rank losses) = the whole batch's gradient
-            ref = full_grads[k]
+            ref = full_grads[k].cpu()
             num += float((gs - ref).double().pow(2).sum())
             den += float(ref.double().pow(2).sum())
             worst = max(worst, float((gs - ref).norm() / ref.norm().clamp_min(1e-12)))

@@ -201,3 +201,67 @@ def test_forward_does_not_depend_on_which_stream_lags(lag):
             out = model(*x)
             torch.cuda.synchronize()
             assert torch.equal(out['pred_logits'], ref['pred_logits']) and torch.equal(out['pred_boxes'], ref['pred_boxes'])
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16], ids=['fp32', 'bf16', 'fp16'])
+def test_gate_scores_from_the_previous_layers_layernorm_change_nothing(dtype):
+    """Round 6: layer i's last LayerNorm can also write layer i + 1's gate scores (blocks.GATE_SCORES_FUSE / SVOL_GATE_SCORES_FUSE=1,
+    svol_layernorm_gate_scores_fwd; off by default — slower inside the step, see svol_amd/blocks.py) and that layer then skips its
+    own score pass.  Same arithmetic in the same order: the head's
+    outputs are BIT-identical with the fused launch on and off, and so are the losses; the gradients (the backward kernels and
+    what they read are unchanged, but float atomics land in run-to-run order and 16-bit modes round behind them) agree to
+    1e-4 (fp32) / 2e-2 (16-bit) of each parameter's largest gradient entry.  The fused program must really have run (trace of the
+    launches), and a video length that is not a multiple of 4 must quietly take the stand-alone pass."""
+    from svol_amd import blocks
+    from svol_amd.modeling.loss import build_loss
+    from svol_amd.modeling.svanet import build_svanet
+    from tests.helpers import head_case
+    assert blocks.ENABLED
+    default = blocks.GATE_SCORES_FUSE
+    z, meta, args, sd, inp, tg = head_case('mid32_video')
+    args.compute_dtype = {torch.float32: 'fp32', torch.bfloat16: 'bf16', torch.float16: 'fp16'}[dtype]
+    dev = torch.device('cuda', 0)
+    model = build_svanet(args)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    crit = build_loss(args).to(dev).eval()
+    x = [inp[k].to(dev) for k in ('src_sketch', 'src_sketch_mask', 'src_video', 'src_video_mask')]
+    L = x[2].shape[1] * (x[2].shape[2] if x[2].dim() == 4 else 1)
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        out = model(*x)
+        ld = crit(out, tg)
+        tot = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+        tot.backward()
+        torch.cuda.synchronize()
+        return out, float(tot), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    calls = []
+    real = blocks.VideoHalfFn.apply
+    def spy(pl, x32, pos, u, u_next, sc_in, *params):
+        calls.append((u_next is not None, sc_in is not None))
+        return real(pl, x32, pos, u, u_next, sc_in, *params)
+    blocks.VideoHalfFn.apply = spy
+    try:
+        blocks.GATE_SCORES_FUSE = True
+        on, tot_on, g_on = run()
+        fused_calls = list(calls)
+        blocks.GATE_SCORES_FUSE = False
+        calls.clear()
+        off, tot_off, g_off = run()
+        plain_calls = list(calls)
+    finally:
+        blocks.GATE_SCORES_FUSE = default
+        blocks.VideoHalfFn.apply = real
+    n = args.num_layers
+    if L % 4 == 0:
+        assert fused_calls == [(i + 1 < n, i > 0) for i in range(n)], fused_calls
+    assert plain_calls == [(False, False)] * n, plain_calls
+    for a, b in zip(list(on.get('aux_outputs', [])) + [on], list(off.get('aux_outputs', [])) + [off]):
+        assert torch.equal(a['pred_logits'], b['pred_logits']) and torch.equal(a['pred_boxes'], b['pred_boxes'])
+    assert tot_on == tot_off
+    assert g_on.keys() == g_off.keys()
+    for k in g_on:
+        scale = float(g_off[k].abs().max())
+        assert float((g_on[k] - g_off[k]).abs().max()) <= (1e-4 if dtype == torch.float32 else 2e-2) * scale + 1e-12, k

@@ -82,6 +82,10 @@ def test_gate_fwd_bwd(G):
     _assert(G.check_gate())
 
 
+def test_gate_scores_in_the_previous_layernorm_same_bits(G):
+    _assert(G.check_gate_scores_fused())
+
+
 def test_lsap_bit_exact_vs_scipy(G):
     _assert(G.check_lsap_vs_scipy())
 

@@ -123,12 +123,12 @@ def test_training_step_does_not_depend_on_stream_timing(dtype):
     mid = len(layers) // 2
     orig = type(layers[mid]).video_half
     for which in ('main', 'side', 'wgrad'):
-        def patched(self, mem32, skch32, pos, u=None, _which=which):
+        def patched(self, mem32, skch32, pos, u=None, *rest, _which=which):
             if self is layers[mid]:
                 stall(_which)
                 if mem32.requires_grad:
                     mem32.register_hook(lambda g, w=_which: (stall(w), g)[1])
-            return orig(self, mem32, skch32, pos, u)
+            return orig(self, mem32, skch32, pos, u, *rest)
         type(layers[mid]).video_half = patched
         try:
             l1, g1 = step()
