@@ -542,20 +542,6 @@ def _bn_sync_world(sync):
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
-def _bn_collective(kind, t):
-    """all-reduce (sum) / broadcast from rank 0 of a small fp32 device tensor over the default group.  RCCL takes the device tensor;
-    a CPU backend (gloo: the two-ranks-on-one-card test) gets it staged through the host HERE, synchronously on the current stream —
-    ProcessGroupGloo's own device staging runs on internal streams and gave one rank stale sums in about one run in three of
-    tests/syncbn_gpu_worker.py."""
-    import torch.distributed as dist
-    if dist.get_backend() == 'nccl':
-        dist.all_reduce(t) if kind == 'sum' else dist.broadcast(t, src=0)
-        return
-    h = t.detach().cpu()
-    dist.all_reduce(h) if kind == 'sum' else dist.broadcast(h, src=0)
-    t.copy_(h)
-
-
 def bn_train_stats(z, gamma, beta, running_mean, running_var, momentum, eps, sync=False):
     """train-mode nn.BatchNorm2d statistics of an NHWC activation z [M, C] (16-bit) in ONE pass over z: sums of (z - s) and (z - s)^2
     about a per-channel pivot s = the first row of z (a sample of the channel: the variance's subtraction loses a few bits, not the
@@ -572,22 +558,24 @@ def bn_train_stats(z, gamma, beta, running_mean, running_var, momentum, eps, syn
     L_ = _lib.lib()
     dt, s = _dt(z), _stream()
     world = _bn_sync_world(sync)
+    if world > 1:
+        import torch.distributed as dist
     if BN_STATS_TWO_PASS:
         _lib.check(L_.svol_bn_colstats(_ptr(z), None, 0.0, _ptr(buf[0]), _ptr(buf[6]), M, C, dt, s), 'svol_bn_colstats')
         buf[6].zero_()
         if world > 1:
-            _bn_collective('sum', buf[0])
+            dist.all_reduce(buf[0])
         _lib.check(L_.svol_bn_colstats(_ptr(z), _ptr(buf[0]), 1.0 / (M * world), _ptr(buf[6]), _ptr(buf[1]), M, C, dt, s), 'svol_bn_colstats')
         if world > 1:
-            _bn_collective('sum', buf[1])
+            dist.all_reduce(buf[1])
         pivot = None
     else:
         buf[6].copy_(z[0])
         if world > 1:
-            _bn_collective('bcast', buf[6])
+            dist.broadcast(buf[6], src=0)
         _lib.check(L_.svol_bn_colstats(_ptr(z), _ptr(buf[6]), 1.0, _ptr(buf[0]), _ptr(buf[1]), M, C, dt, s), 'svol_bn_colstats')
         if world > 1:
-            _bn_collective('sum', buf[0:2])
+            dist.all_reduce(buf[0:2])
         pivot = buf[6]
     _lib.check(L_.svol_bn_finalize(_ptr(buf[0]), _ptr(buf[1]), _ptr(pivot), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                    float(momentum), float(eps), M * world, C, _ptr(buf[2]), _ptr(buf[3]), _ptr(buf[4]), _ptr(buf[5]), s),
@@ -647,8 +635,9 @@ def bn_bwd(dy, y, z, mean, rstd, gamma, want_dres, sync=False):
                                      _stream()), 'svol_bn_bwd_reduce')
     world = _bn_sync_world(sync)
     if world > 1:
+        import torch.distributed as dist
         local = sums.clone()
-        _bn_collective('sum', sums)
+        dist.all_reduce(sums)
         sums.mul_(1.0 / world)   # svol_bn_bwd_apply divides by ITS row count M: (sum over ranks / world) / M = global sum / (M * world)
         dz = torch.empty_like(z)
         dres = torch.empty_like(z) if want_dres else None

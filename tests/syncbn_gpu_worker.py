@@ -2,7 +2,9 @@
 
 --sync_bn (the reference: apex.parallel.convert_syncbn_model, train.py:65-68) on the TRAINABLE ResNet extractor: each rank holds half
 of a batch of images; with sync_bn the train-mode BatchNorm statistics, the running statistics, the features and — summed over the ranks —
-the parameter gradients must equal ONE process running the whole batch; without it they must not (negative control)."""
+the parameter gradients must equal ONE process running the whole batch; without it they must not (negative control).  "Equal": see
+the comment at the assertions — exact where no bf16 rounding sits between the statistic and its inputs, to the resolution of a bf16
+network's run-to-run reproducibility elsewhere."""
 import os
 import sys
 
@@ -36,33 +38,57 @@ def main():
     n = 4
     imgs = syn.synth_images(n, syn.vit_config(image_size=64), seed=9)
     g = torch.Generator().manual_seed(5)
-    full_feat, full_grads, full_stats = run(imgs, torch.randn(n, 16, 256, generator=g), False)   # ONE process, the whole batch
-    g = torch.Generator().manual_seed(5)
     probe = torch.randn(n, 16, 256, generator=g)
     lo, hi = rank * n // 2, (rank + 1) * n // 2
-    out = {}
-    for sync in (True, False):
-        feat, grads, stats = run(imgs[lo:hi], probe[lo:hi], sync)
+    fulls = [run(imgs, probe, False) for _ in range(2)]                      # ONE process, the whole batch (twice: see below)
+
+    def compare(mine, full):
+        feat, grads, stats = mine
+        full_feat, full_grads, full_stats = full
+        rel = lambda k: float((stats[k] - full_stats[k]).abs().max() / full_stats[k].abs().max())
         e_feat = float((feat - full_feat[lo:hi]).abs().max() / full_feat.abs().max())
-        e_stat = max(float((stats[k] - full_stats[k]).abs().max() / full_stats[k].abs().max()) for k in stats)
+        e_stem = max(rel(k) for k in stats if k.startswith('1.'))           # the stem's BatchNorm: its input is the pixels themselves
+        e_stat = max(rel(k) for k in stats)
         num = den = 0.0
-        worst = 0.0
+        for k, gl in grads.items():
+            ref = full_grads[k].cpu()
+            num += float((gl - ref).double().pow(2).sum())
+            den += float(ref.double().pow(2).sum())
+        return (e_feat, e_stem, e_stat, (num / den) ** 0.5)
+
+    def ranks_summed(grads):
+        out = {}
         for k, gl in grads.items():
             gs = gl.cpu()
             dist.all_reduce(gs)                       # sum over ranks of d(sum of the per-rank losses) = the whole batch's gradient
-            ref = full_grads[k].cpu()
-            num += float((gs - ref).double().pow(2).sum())
-            den += float(ref.double().pow(2).sum())
-            worst = max(worst, float((gs - ref).norm() / ref.norm().clamp_min(1e-12)))
-        out[sync] = (e_feat, e_stat, (num / den) ** 0.5, worst)
-    s, ns = out[True], out[False]
-    print(f'rank {rank}: sync_bn: features {s[0]:.2e} running stats {s[1]:.2e} gradient L2 {s[2]:.2e} (worst parameter {s[3]:.2e}); '
-          f'without: features {ns[0]:.2e} running stats {ns[1]:.2e} gradient L2 {ns[2]:.2e}', flush=True)
-    # running statistics are fp32 sums of the same bf16 values in another order: ~1e-6; features / gradients carry bf16 activations whose
-    # roundings can flip with the 7th digit of a statistic (a few bf16 ulps on single elements), never more
-    assert s[1] <= 2e-5 and s[0] <= 2e-2 and s[2] <= 2e-2, s
-    # negative control: per-rank statistics of half the batch are somewhere else
-    assert ns[1] >= 1e-3 and ns[2] >= 5 * s[2], (s, ns)
+            out[k] = gs
+        return out
+
+    res = {}
+    for sync, times in ((True, 3), (False, 1)):
+        res[sync] = []
+        for _ in range(times):
+            feat, grads, stats = run(imgs[lo:hi], probe[lo:hi], sync)
+            mine = (feat, ranks_summed(grads), stats)
+            res[sync] += [compare(mine, f) for f in fulls]
+    worst = tuple(max(r[i] for r in res[True]) for i in range(4))
+    best = min(res[True], key=lambda r: r[2] + r[3])
+    ns = min(res[False], key=lambda r: r[2] + r[3])
+    print(f'rank {rank}: sync_bn, best of {len(res[True])} pairings: features {best[0]:.2e} stem statistics {best[1]:.2e} all running '
+          f'statistics {best[2]:.2e} gradient L2 {best[3]:.2e}; worst: {worst[0]:.2e} {worst[1]:.2e} {worst[2]:.2e} {worst[3]:.2e}; '
+          f'without: features {ns[0]:.2e} stem statistics {ns[1]:.2e} all {ns[2]:.2e} gradient L2 {ns[3]:.2e}', flush=True)
+    # Two bf16 networks are compared.  Usually they agree bit for bit in the features (statistics 1e-6: fp32 sums of the same values
+    # in another order; gradients 5e-5) — but a statistic that differs in its 7th digit (float atomics land in run-to-run order even
+    # in ONE process) can flip a bf16 rounding behind the stem, and through seven convolutions that flip becomes a one-ulp perturbation
+    # of everything: features 6e-3, deep statistics 8e-4, gradients 7e-2.  Measured between two IDENTICAL single-process runs (one
+    # run in eight with two processes on the card); it failed this test's first form, which allowed "a few bf16 ulps on single
+    # elements, never more".  Hence: (1) the stem's statistics — pixels in, nothing to amplify — must match in EVERY pairing;
+    # (2) three sync_bn runs against two whole-batch runs: the BEST pairing must meet the strict bars (six unlucky draws in a row:
+    # < 1e-4), (3) every pairing stays 10 x inside the unsynchronised network's distance (negative control).
+    assert worst[1] <= 5e-6, worst
+    assert best[2] <= 2e-5 and best[0] <= 2e-2 and best[3] <= 2e-2, best
+    assert worst[0] <= 3e-2 and worst[2] <= 5e-3 and worst[3] <= 0.15, worst
+    assert ns[1] >= 1e-3 and ns[2] >= 5e-2 and ns[3] >= 0.3, (best, ns)
     print(f'rank {rank}: sync_bn == one process on the global batch', flush=True)
     dist.destroy_process_group()
 
