@@ -605,8 +605,69 @@ def check_gate():
             res[tag + '/du_abs_vs_dx_scale'] = (float((ud.grad.cpu().double() - u64.grad).abs().max()) / scale, 3e-5)  # fp32 sums over L rows in a launch-dependent order (wave partials, LDS fold, atomics)
             res[tag + '/dgamma'] = (rel_err(gd.grad, g64.grad), 1e-4 if dt == torch.float32 else 1e-2)
             res[tag + '/dbeta'] = (rel_err(bd.grad, b64.grad), 1e-4 if dt == torch.float32 else 1e-2)
-    # a case where the gate gradient is NOT negligible: huge eps-equivalent via tiny-variance rows is not
-    # constructible, so check dscore through du with a LARGE upstream signal on the softmax instead:
+    # The regime where the gate is NOT invisible: rows whose variance is below LayerNorm's epsilon (x ~ 1e-3: var 1e-6 against
+    # eps 1e-5) — LN1 no longer forgets the per-token scale (1 + a), so the outputs depend on the gate weights to first order and
+    # the gradient through the scores (du, and dx's score term) is of the size of everything else.  A peaked softmax (|u| ~ 1,
+    # a up to ~0.5) on top.  Outputs, dx AND du on their own scale.  (Round 6; until then this function could not see the gate.)
+    for dt in DTYPES16:
+        for (B, L, D, H) in [(2, 52, 64, 8), (2, 200, 256, 8)]:
+            x, pos = 1e-3 * _rnd((B, L, D), torch.float32, 50), _rnd((B, L, D), dt, 51)
+            u = _rnd((B, H, D), torch.float32, 52, 8.0 / math.sqrt(D))
+            g = 1 + 0.1 * _rnd((D,), torch.float32, 53)
+            b = 0.1 * _rnd((D,), torch.float32, 54)
+            dy32 = _rnd((B, L, D), torch.float32, 55)
+            xd, ud = x.to(DEV).requires_grad_(True), u.to(DEV).requires_grad_(True)
+            y32, y, ypos = ops.gate(xd, pos.to(DEV), ud, g.to(DEV), b.to(DEV), H)
+            x64, u64 = x.double().requires_grad_(True), u.double().requires_grad_(True)
+            yr, _ = _gate_ref(x64, pos.double(), u64, g.double(), b.double(), H)
+            # how much the output moves when the gate is switched off: the sensitivity this case exists for
+            y_off = O.layer_norm(x.double(), g.double(), b.double())
+            tag = f'gate_small_variance/{dt}/B{B}L{L}D{D}H{H}'
+            res[tag + '/gate_is_visible'] = (1e-2 / max(float((yr.detach() - y_off).abs().max() / yr.detach().abs().max()), 1e-30), 1.0)   # >= 1 % of the output
+            res[tag + '/y32'] = (rel_err(y32, yr), 5e-5)
+            (yr * dy32.double()).sum().backward()
+            y32.backward(dy32.to(DEV))
+            res[tag + '/dx'] = (rel_err(xd.grad, x64.grad), 2e-4)
+            res[tag + '/du'] = (rel_err(ud.grad, u64.grad), 1e-3)
+            res[tag + '/du_is_not_noise'] = (1e-5 / max(float(u64.grad.abs().max() / x64.grad.abs().max()), 1e-30), 1.0)   # |du| >= 1e-5 |dx| (1e-10 at unit variance)
+    return res
+
+
+def check_gate_against_mha():
+    """The sketch -> video gate end to end against the attention it replaces (cross_modal_transformer.py:122-124: the head-averaged
+    weights of nn.MultiheadAttention with ONE query): the product folds the key projection into one vector per (batch, head)
+    (layer.gate_vectors -> svol_gate_vectors_fwd) and never forms K; the oracle's ``mha`` (pinned to torch.nn.MultiheadAttention by
+    tests/test_oracle_golden.py::test_oracle_mha_is_torchs) runs the attention as written.  Compared: the gate vectors against their
+    formula, and the gate weights a[b, l] the device saved against att1 — quantities the model's OUTPUTS are nearly blind to
+    (LN1(x (1 + a)) forgets the per-token scale), so nothing else would notice them being wrong."""
+    from svol_amd.modeling.cross_modal_transformer import CrossModalTransformerLayer
+    res = {}
+    for dt in DTYPES16:
+        for (B, L, D, H) in [(2, 52, 64, 8), (3, 200, 256, 8), (1, 77, 128, 4)]:
+            torch.manual_seed(7)
+            layer = CrossModalTransformerLayer(D, H, 2 * D)
+            m = layer.sketch_video_cross_attn
+            with torch.no_grad():   # (the default initialisation leaves the in_proj bias at zero)
+                m.in_proj_bias.copy_(0.3 * _rnd((3 * D,), torch.float32, 70))
+                m.in_proj_weight.mul_(3.0)
+            layer = layer.to(DEV)
+            sk = _rnd((B, D), torch.float32, 71)
+            x, pos = _rnd((B, L, D), torch.float32, 72), _rnd((B, L, D), dt, 73)
+            u = layer.gate_vectors(sk.to(DEV))
+            y32, _, _ = ops.gate(x.to(DEV), pos.to(DEV), u, layer.norm1.weight, layer.norm1.bias, H)
+            a_dev = y32.grad_fn.saved_tensors[4].double().cpu().view(B, L)
+            W, bb = m.in_proj_weight.detach().double().cpu(), m.in_proj_bias.detach().double().cpu()
+            dh = D // H
+            q = sk.double() @ W[:D].T + bb[:D]
+            u_ref = torch.einsum('bhj,hjd->bhd', q.view(B, H, dh), W[D:2 * D].view(H, dh, D)) / math.sqrt(dh)
+            tag = f'gate_vs_mha/{dt}/B{B}L{L}D{D}H{H}'
+            res[tag + '/u'] = (float((u.double().cpu() - u_ref).abs().max() / u_ref.abs().max()), 1e-5)
+            kv = x.double() + pos.double()
+            _, att1 = O.mha(sk.double()[:, None, :], kv, kv, W, bb, m.out_proj.weight.detach().double().cpu(),
+                            m.out_proj.bias.detach().double().cpu(), H, need_output=False)
+            att1 = att1[:, 0, :]
+            res[tag + '/a_vs_att1'] = (float(((a_dev - att1).abs() / att1).max()), 2e-4)
+            res[tag + '/att1_is_not_uniform'] = (float(1.0 / (att1.max() * L)), 0.5)   # (a flat softmax would hide a wrong score)
     return res
 
 

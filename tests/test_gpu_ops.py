@@ -82,6 +82,10 @@ def test_gate_fwd_bwd(G):
     _assert(G.check_gate())
 
 
+def test_gate_weights_equal_the_one_query_attention_they_replace(G):
+    _assert(G.check_gate_against_mha())
+
+
 def test_gate_scores_in_the_previous_layernorm_same_bits(G):
     _assert(G.check_gate_scores_fused())
 
