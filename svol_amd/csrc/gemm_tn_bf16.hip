@@ -26,6 +26,7 @@ struct TnFastArgs {
     const h16_t* A; const h16_t* B; float* C; float* colsum;
     int64_t lda, ldb, ldc;
     int Mc, N, K, m_chunk, ktiles, splits;
+    int split_major;   // workgroup -> work mapping, see tn_dma_body
 };
 
 // Implicit-GEMM weight gradient of a convolution (round 5, the trainable ResNet): B is not a matrix in memory but the im2col view of an NHWC
@@ -60,11 +61,26 @@ __device__ __forceinline__ void tn_dma_body(const TnFastArgs& p, const int bid, 
     // go round-robin over the 8 XCDs, so an item (A tile, row chunk) takes id % 8 = its XCD and its ktiles B tiles follow each
     // other 8 ids apart.  (Round 3 walked all row chunks of one output tile first: every A panel came from HBM ktiles times —
     // 947 MiB moved for 613 MiB of operands in the video half's grouped launch.)
-    const int per8 = 8 * p.ktiles, g8 = bid / per8, r8 = bid - g8 * per8;
-    const int kt_ = r8 >> 3, item = g8 * 8 + (r8 & 7);
-    const int nitems = p.splits * ((p.N + 127) / 128);
-    if (item >= nitems) return;               // (the last group of 8 is padded)
-    const int split = item % p.splits, nt_ = item / p.splits;
+    // Round 6, split_major (splits a multiple of 8): ALL output tiles of one row chunk on one XCD — id % 8 = chunk % 8, the chunk's
+    // ntiles x ktiles workgroups 8 ids apart — so the B panel is shared as well (it was fetched once per A tile: the video half's
+    // MLP pair moved 884 MB per launch for ~480 MB of operands, profiles/round6_hbm_traffic.txt).
+    int kt_, nt_, split;
+    if (p.split_major) {
+        const int ntiles = (p.N + 127) / 128, T = ntiles * p.ktiles;
+        const int xcd = bid & 7, j = bid >> 3, grp = j / T, tile = j - grp * T;
+        split = grp * 8 + xcd;
+        if (split >= p.splits) return;
+        nt_ = tile / p.ktiles;
+        kt_ = tile - nt_ * p.ktiles;
+    } else {
+        const int per8 = 8 * p.ktiles, g8 = bid / per8, r8 = bid - g8 * per8;
+        const int item = g8 * 8 + (r8 & 7);
+        kt_ = r8 >> 3;
+        const int nitems = p.splits * ((p.N + 127) / 128);
+        if (item >= nitems) return;               // (the last group of 8 is padded)
+        split = item % p.splits;
+        nt_ = item / p.splits;
+    }
     const int n0 = nt_ * 128, k0 = kt_ * 128;
     const int m_begin = split * p.m_chunk;
     const int m_end = min(p.Mc, m_begin + p.m_chunk);
@@ -286,17 +302,26 @@ bool tn_plan(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, i
     const int target_wgs = wgs_override ? wgs_override : (tiles <= 8 ? (force_wgs ? force_wgs : 128) : (force_wgs2 ? force_wgs2 : 128));
     int64_t want = (target_wgs + tiles - 1) / tiles;
     if (want > 8) want = want / 8 * 8;
-    if (svol_deterministic()) want = 1;   // no contraction split: one adder per output element
+    // split-major mapping (tn_dma_body): needs a multiple of 8 row chunks; taken when that costs at most 2 x the target
+    static const int split_major_on = getenv("SVOL_TN_SPLIT_MAJOR") ? atoi(getenv("SVOL_TN_SPLIT_MAJOR")) : 1;
+    bool split_major = false;
+    if (split_major_on && !wgs_override && 8 * tiles <= 2 * target_wgs) {
+        if (want < 8) want = 8;
+        split_major = true;
+    }
+    if (svol_deterministic()) { want = 1; split_major = false; }   // no contraction split: one adder per output element
     int64_t chunk = (Mc + want - 1) / want;
     chunk = ((chunk + CT - 1) / CT) * CT;
     if (chunk < 4 * CT) chunk = 4 * CT;
     const int64_t splits = (Mc + chunk - 1) / chunk;
     if (splits * tiles > (1ll << 28)) return false;
+    if (splits < 8) split_major = false;       // (short problems: the row chunks have a minimum length)
     const int64_t ldmax = lda > ldb ? lda : ldb;
     if (chunk * ldmax * 2 >= (1ll << 31)) return false;  // 32-bit buffer offsets
     out = TnFastArgs{(const h16_t*)A, (const h16_t*)B, C, colsum, lda, ldb, ldc, (int)Mc, (int)N, (int)K, (int)chunk,
-                     (int)((K + 127) / 128), (int)splits};
-    wgs = ((splits * ((N + 127) / 128) + 7) / 8) * 8 * ((K + 127) / 128);   // items padded to whole groups of 8 (tn_dma_body)
+                     (int)((K + 127) / 128), (int)splits, split_major ? 1 : 0};
+    if (split_major) wgs = ((splits + 7) / 8) * 8 * tiles;
+    else wgs = ((splits * ((N + 127) / 128) + 7) / 8) * 8 * ((K + 127) / 128);   // items padded to whole groups of 8 (tn_dma_body)
     return true;
 }
 
