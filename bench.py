@@ -353,6 +353,51 @@ def main():
     if trace:
         print('host_ms per step:', [round(x, 1) for x in host_ms], file=sys.stderr)
     ops.timer.disable()
+
+    def clock_block(probe):
+        """the shader clock the chip holds under this step: --steps more steps, UNTIMED, with a one-wave probe on
+        its own stream sampling shader-clock ticks against the constant wall counter in 200 us windows (csrc/clock_probe.hip).
+        Box-to-box spread of the headline on this pool is +-2 %, mostly this number."""
+        import ctypes
+        from svol_amd import _lib
+        if not probe:                # (the other ranks of a multi-GPU run: the same steps — they hold collectives —, no probe)
+            for _ in range(a.steps):
+                step()
+            torch.cuda.synchronize()
+            return None
+        cap = 8192
+        samples = torch.zeros(2 * cap, dtype=torch.int64, device=dev)
+        count = torch.zeros(1, dtype=torch.int32, device=dev)
+        stop = torch.zeros(1, dtype=torch.int32, device=dev)
+        khz = ctypes.c_int32(0)
+        ps = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        _lib.check(_lib.lib().svol_clock_probe(samples.data_ptr(), count.data_ptr(), cap, stop.data_ptr(), 200, 20000, ctypes.byref(khz),
+                                               ps.cuda_stream), 'svol_clock_probe')
+        try:
+            for _ in range(a.steps):
+                step()
+        finally:
+            stop.fill_(1)            # stream-ordered behind the steps: the probe leaves at its next window
+            torch.cuda.synchronize()
+        n = int(count.item())
+        if n < 8:
+            return None
+        w = samples[:2 * n].view(n, 2).cpu().double()
+        ghz = (w[:, 0] / w[:, 1] * (khz.value / 1e6)).sort().values
+        pick = lambda q: round(float(ghz[min(n - 1, int(q * n))]), 3)
+        return {'mean': round(float(ghz.mean()), 3), 'p10': pick(0.1), 'median': pick(0.5), 'p90': pick(0.9), 'windows': n, 'window_us': 200,
+                'how': 's_memtime / s_memrealtime in one probe wave beside an untimed block of --steps steps right after the timed blocks'}
+
+    sclk = None
+    if not use_graph and os.environ.get('SVOL_NO_CLOCK_PROBE') is None:
+        if rank == 0 and world == 1:
+            try:
+                sclk = clock_block(True)
+            except Exception as e:   # a measurement aid must not cost the bench line
+                sclk = {'error': str(e)[:200]}
+        else:                        # (multi-GPU: no swallowing — a rank that skipped steps would leave the others in a collective)
+            sclk = clock_block(rank == 0)
     # host time to ISSUE one step, measured on an EMPTY queue right after the timed region (3 free-running steps): inside the timed
     # region the host runs ahead until the HIP queue pushes back (a few steps), after which a step's host wall time is the GPU's
     free_ms = []
@@ -513,7 +558,7 @@ def main():
         res = {
             'metric': 'frames/sec (fwd+matcher+bwd), T=%d·P=%d·d=256' % (T, P),
             'value': fps, 'unit': 'frames/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': ms_per_step, 'ms_per_step_blocks': [round(b_[0] / a.steps * 1e3, 4) for b_ in timed],
+            'ms_per_step': ms_per_step, 'ms_per_step_blocks': [round(b_[0] / a.steps * 1e3, 4) for b_ in timed], 'sclk_ghz': sclk,
             'timed_blocks': ('%d blocks of exactly --steps steps, each between barrier + synchronize, max over ranks; value / ms_per_step = the '
                              'median block' % len(timed)),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,

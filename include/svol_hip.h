@@ -504,6 +504,14 @@ const char* svol_block_slot_names(int block);
  * calls; this synchronises the device, writes "program | call site  calls  avg_us  total_ms" lines for everything recorded since the
  * last dump into buf (NUL-terminated, truncated to cap) and forgets them.  Without the variable: writes "" and returns. */
 int svol_block_trace_dump(char* buf, int64_t cap);
+/* ---- measurement aid: the shader clock the chip holds while other streams work (bench.py `sclk_ghz`) ----
+ * One wave samples (shader-clock ticks, wall-counter ticks) pairs in windows of period_us until *stop != 0 (the caller sets it with a
+ * stream-ordered fill on another stream), max_samples windows, or max_ms (<= 60000) have passed; then writes *count.
+ * GHz of a window = samples[2i] / samples[2i+1] * wall_khz / 1e6 (*wall_khz: hipDeviceAttributeWallClockRate, returned at once).
+ * Not part of the hot path: the reference has no counterpart (it reads nvidia-smi by hand). */
+int svol_clock_probe(uint64_t* samples, int32_t* count, int32_t max_samples, const int32_t* stop, int64_t period_us,
+                     int64_t max_ms, int32_t* wall_khz, void* stream);
+
 
 /* video half (:122-143): gate -> LN1 ; q|k, v projections, self-attention, out-proj + residual -> LN2 ; fc1+GELU, fc2 + residual
  * -> LN3 (+pos).  M = B*L rows.

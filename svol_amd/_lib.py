@@ -84,6 +84,7 @@ SIGNATURES = {
     'svol_gate_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p],
     'svol_gate_bwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _int,
                       _p],
+    'svol_clock_probe': [_p, _p, _int, _p, _i64, _i64, _p, _p],
     'svol_gate_fwd_scored': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p],
     'svol_layernorm_gate_scores_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _int, _p],
     'svol_gate_vectors_fwd': [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p],

@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libsvol_hip.so')
-SOURCES = ['gemm.hip', 'gemm_bf16.hip', 'gemm_tn_bf16.hip', 'gemm_ws_bf16.hip', 'gemm_n256_bf16.hip', 'norm.hip', 'attention.hip', 'attention_bf16.hip', 'gate.hip', 'criterion.hip', 'posteval.hip', 'vit.hip', 'attn_weights.hip', 'resnet.hip', 'resnet_train.hip', 'blocks.hip', 'lsap_host.hip', 'heads.hip']
+SOURCES = ['gemm.hip', 'gemm_bf16.hip', 'gemm_tn_bf16.hip', 'gemm_ws_bf16.hip', 'gemm_n256_bf16.hip', 'norm.hip', 'attention.hip', 'attention_bf16.hip', 'gate.hip', 'criterion.hip', 'posteval.hip', 'vit.hip', 'attn_weights.hip', 'resnet.hip', 'resnet_train.hip', 'blocks.hip', 'lsap_host.hip', 'heads.hip', 'clock_probe.hip']
 # the MFMA-path files are written against h16_t (csrc/common.h) and compiled a second time with fp16 operands
 H16_SOURCES = ['gemm_bf16.hip', 'gemm_tn_bf16.hip', 'gemm_ws_bf16.hip', 'gemm_n256_bf16.hip', 'attention_bf16.hip']
 ARCH = 'gfx950'

@@ -261,3 +261,48 @@ print('LN', 'identical' if same else 'DIFFERENT', len(outs[0]))
     assert r.returncode == 0, r.stderr[-3000:]
     assert 'BAD {}' in r.stdout, r.stdout[-3000:]
     assert 'LN identical' in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_clock_probe_leaves_on_stop_and_on_its_own_time_limit():
+    """svol_clock_probe (bench.py `sclk_ghz`): one wave samples shader-clock ticks against the wall counter beside other streams' work.
+    It must leave (a) when the caller's stream-ordered stop flag arrives and (b) by itself at its time limit when nobody stops it —
+    a persistent kernel every path out of which is reached without help —, and the clock it reports must be a clock."""
+    import ctypes
+    import time
+    import torch
+    from svol_amd import _lib
+    dev = torch.device('cuda', 0)
+    L_ = _lib.lib()
+    x = torch.randn(4096, 4096, device=dev)
+
+    def probe(max_ms, stop_after_work):
+        cap = 4096
+        samples = torch.zeros(2 * cap, dtype=torch.int64, device=dev)
+        count = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        stop = torch.zeros(1, dtype=torch.int32, device=dev)
+        khz = ctypes.c_int32(0)
+        ps = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _lib.check(L_.svol_clock_probe(samples.data_ptr(), count.data_ptr(), cap, stop.data_ptr(), 100, max_ms, ctypes.byref(khz),
+                                       ps.cuda_stream), 'svol_clock_probe')
+        for _ in range(20):
+            (x @ x).sum()
+        if stop_after_work:
+            stop.fill_(1)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        n = int(count.item())
+        w = samples[:2 * n].view(n, 2).cpu().double()
+        return n, w[:, 0] / w[:, 1] * (khz.value / 1e6), khz.value, el
+
+    n, ghz, khz, el = probe(10000, True)
+    assert n >= 3 and khz > 0 and el < 5.0, (n, khz, el)
+    assert 0.3 < float(ghz.min()) and float(ghz.max()) < 3.5, ghz
+    n2, ghz2, _, el2 = probe(60, False)          # nobody stops it: the time limit does
+    assert n2 >= 3 and 0.05 <= el2 < 2.0, (n2, el2)
+    assert 0.3 < float(ghz2.min()) and float(ghz2.max()) < 3.5, ghz2
+    rc = L_.svol_clock_probe(None, None, 0, None, 0, 0, None, None)
+    assert rc == -1
+    print(f'clock probe: {n} windows, {float(ghz.mean()):.3f} GHz under fp32 GEMMs; wall counter {khz} kHz')
