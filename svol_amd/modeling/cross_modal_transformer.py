@@ -266,10 +266,11 @@ class CrossModalTransformer(nn.Module):
         self.d_model, self.nhead, self.num_layers = d_model, nhead, num_layers
         self._epoch_seen = -1
 
-    def forward(self, src_vid32, src_skch32, kbias, vid_pos, query_embed):
+    def forward(self, src_vid32, src_skch32, kbias, vid_pos, query_embed, us=None):
         """src_vid32 [B,L,d] fp32 (projected video tokens = start of the fp32 residual stream),
         src_skch32 [B,d] fp32, kbias [B,L] fp32 additive key mask, vid_pos [B,L,d] compute dtype,
-        query_embed [N,d] fp32 parameter.  Returns hs [num_layers,B,N,d] fp32."""
+        query_embed [N,d] fp32 parameter; us: every layer's gate vectors when the caller computed them (all_gate_vectors; SVANet does,
+        on the query stream beside the video projection).  Returns hs [num_layers,B,N,d] fp32."""
         # The compute-dtype weight copies are refreshed once per cache EPOCH; the heads that own this module (SVANet, the
         # svanet_variants) open one per forward.  Driven on its own (a training loop around the bare transformer), nobody does:
         # open it here, or an optimizer that rewrites parameters without bumping their version counters (torch's fused AdamW on ROCm)
@@ -292,7 +293,8 @@ class CrossModalTransformer(nn.Module):
         # waits for a CU beside the other streams' kernels (15 us each).  Their autograd nodes get the lowest sequence numbers of the
         # transformer, so the engine runs their backward (two tiny launches per layer, 65 us each in the middle of the backward)
         # after everything else: 6 x 14 us at the end.  (svol_amd.parallel.arrival_order puts these parameters last accordingly.)
-        us = all_gate_vectors(list(self.layers), src_skch32)
+        if us is None:
+            us = all_gate_vectors(list(self.layers), src_skch32)
         if not OVERLAP_QUERY_STREAM:
             out = initial_queries()
             for layer, u in zip(self.layers, us):

@@ -5,12 +5,18 @@ output dict; children are parameter containers, arithmetic is in ``svol_amd.ops`
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
 from .. import ops
+from . import cross_modal_transformer as cmt
 from .cross_modal_transformer import build_cross_modal_transformer
 from .position_encoding import build_position_encoding
+
+# the mask / sketch chain of the forward's head on the query stream beside the video projection (SVOL_NO_INPUT_OVERLAP=1: one chain)
+INPUT_OVERLAP = os.environ.get('SVOL_NO_INPUT_OVERLAP') is None
 
 _DTYPES = {'bf16': torch.bfloat16, 'fp32': torch.float32, 'fp16': torch.float16, torch.float16: torch.float16, torch.bfloat16: torch.bfloat16,
            torch.float32: torch.float32}
@@ -109,14 +115,36 @@ class SVANet(nn.Module):
         ops.weights.new_epoch()  # re-cast every fp32 master weight once per forward (see ops._WeightCache)
         if self.training:
             self._step += 1
-        vid = self._proj(self.input_video_proj, ops.cast_ag(src_video.float(), dt), 0)
-        mask_f = src_video_mask.to(torch.float32)
-        pos_video = self.video_position_embed(mask_f, d, dt)
-        skch = self._proj(self.input_sketch_proj, ops.cast_ag(src_sketch.float(), dt), 1)
-        # key_padding_mask (True on pads) as an additive bias for the cross-attention kernel
-        kbias = torch.zeros_like(mask_f).masked_fill_(mask_f == 0, float('-inf'))
-        hs = self.transformer(vid, skch.reshape(skch.shape[0], -1), kbias, pos_video,
-                              self.query_embed.weight)  # [NL,B,N,d] fp32
+        def mask_side(with_us):
+            """what depends on the masks and the sketch only: position encoding, key bias, sketch projection, every layer's gate
+            vectors (B*d-sized algebra; their backward is 2 launches per step that used to close the backward on the main stream)"""
+            mask_f = src_video_mask.to(torch.float32)
+            pos_video = self.video_position_embed(mask_f, d, dt)
+            skch = self._proj(self.input_sketch_proj, ops.cast_ag(src_sketch.float(), dt), 1)
+            skch = skch.reshape(skch.shape[0], -1)
+            # key_padding_mask (True on pads) as an additive bias for the cross-attention kernel
+            kbias = torch.zeros_like(mask_f).masked_fill_(mask_f == 0, float('-inf'))
+            us = cmt.all_gate_vectors(list(self.transformer.layers), skch) if with_us else None
+            return pos_video, skch, kbias, us
+
+        if INPUT_OVERLAP and cmt.OVERLAP_QUERY_STREAM and isinstance(self.transformer, cmt.CrossModalTransformer):
+            # Round 6: the step's head (and, replayed by autograd on the same streams, its tail) was one chain of ~25 dependent small
+            # launches on the main stream.  The mask / sketch chain is independent of the video projection: it runs on the query
+            # stream beside it (forward ~70 us, backward ~150 us of the 1.0 ms step boundary).
+            main = torch.cuda.current_stream()
+            side = cmt._side_stream(main.device)
+            side.wait_stream(main)   # the weight casts of new_epoch(), the caller's inputs
+            with torch.cuda.stream(side):
+                pos_video, skch, kbias, us = mask_side(True)
+            vid = self._proj(self.input_video_proj, ops.cast_ag(src_video.float(), dt), 0)
+            main.wait_stream(side)
+            for t in [pos_video, skch, kbias] + list(us or []):
+                t.record_stream(main)   # allocated on the query stream, read by the video half on this one
+        else:
+            vid = self._proj(self.input_video_proj, ops.cast_ag(src_video.float(), dt), 0)
+            pos_video, skch, kbias, us = mask_side(False)
+        hs = (self.transformer(vid, skch, kbias, pos_video, self.query_embed.weight, us) if us is not None else
+              self.transformer(vid, skch, kbias, pos_video, self.query_embed.weight))   # [NL,B,N,d] fp32
         # heads run in fp32 (tiny; keeps logits / box coordinates at full precision)
         if ops.heads_fusable(hs, self.class_embed, self.bbox_embed):   # both heads, all layers, one launch (csrc/heads.hip)
             outputs_class, outputs_coord = ops.heads(hs, self.class_embed, self.bbox_embed)
