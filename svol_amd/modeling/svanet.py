@@ -112,7 +112,9 @@ class SVANet(nn.Module):
                                'inputs to cuda (there is no CPU path — the CPU oracle lives under oracle/).')
         dt = self.compute_dtype
         d = self.transformer.d_model
-        ops.weights.new_epoch()  # re-cast every fp32 master weight once per forward (see ops._WeightCache)
+        overlap = INPUT_OVERLAP and cmt.OVERLAP_QUERY_STREAM and isinstance(self.transformer, cmt.CrossModalTransformer)
+        if not overlap:
+            ops.weights.new_epoch()  # re-cast every fp32 master weight once per forward (see ops._WeightCache)
         if self.training:
             self._step += 1
         def mask_side(with_us):
@@ -127,16 +129,22 @@ class SVANet(nn.Module):
             us = cmt.all_gate_vectors(list(self.transformer.layers), skch) if with_us else None
             return pos_video, skch, kbias, us
 
-        if INPUT_OVERLAP and cmt.OVERLAP_QUERY_STREAM and isinstance(self.transformer, cmt.CrossModalTransformer):
+        if overlap:
             # Round 6: the step's head (and, replayed by autograd on the same streams, its tail) was one chain of ~25 dependent small
             # launches on the main stream.  The mask / sketch chain is independent of the video projection: it runs on the query
-            # stream beside it (forward ~70 us, backward ~150 us of the 1.0 ms step boundary).
+            # stream beside it (forward ~70 us, backward ~150 us of the 1.0 ms step boundary) — and so do the weight casts, beside
+            # the cast of the video features (the first kernel that needs a cast weight is the first projection GEMM).
             main = torch.cuda.current_stream()
             side = cmt._side_stream(main.device)
-            side.wait_stream(main)   # the weight casts of new_epoch(), the caller's inputs
+            side.wait_stream(main)   # the optimizer's update, the last readers of the old copies, the caller's inputs
+            with torch.cuda.stream(side):
+                ops.weights.new_epoch()
+                casts_done = side.record_event()
+            xv = ops.cast_ag(src_video.float(), dt)
             with torch.cuda.stream(side):
                 pos_video, skch, kbias, us = mask_side(True)
-            vid = self._proj(self.input_video_proj, ops.cast_ag(src_video.float(), dt), 0)
+            main.wait_event(casts_done)
+            vid = self._proj(self.input_video_proj, xv, 0)
             main.wait_stream(side)
             for t in [pos_video, skch, kbias] + list(us or []):
                 t.record_stream(main)   # allocated on the query stream, read by the video half on this one
