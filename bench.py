@@ -498,7 +498,7 @@ def main():
                 tj = json.load(open(files[-1]))
                 meta = tj.pop('_meta', {})
                 pick = (['attn_bwd_dq_bf16_pre|', 'attn_bwd_dq_bf16_rot|', 'attn_bwd_dkdv_bf16_pre|', 'attn_bwd_dkdv_bf16_pre_dma|', 'attn_delta_bf16|',
-                         'attn_bwd_sp_prep_bf16|', 'attn_bwd_sp_bf16|', 'attn_dq_round_bf16|'] if bwd[1] >= fwd[1]
+                         'attn_bwd_sp_prep_bf16|', 'attn_bwd_sp_bf16|', 'attn_dq_round_bf16|', 'attn_sp_zero_image|'] if bwd[1] >= fwd[1]
                         else ['attn_fwd_bf16_pre|', 'attn_fwd_bf16_fast|'])
                 tot = sum((v['read_MB'] + v['write_MB']) * 1048576.0 for k_, v in tj.items() if any(k_.startswith(q_) for q_ in pick))
                 if tot > 0:

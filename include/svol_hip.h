@@ -218,6 +218,26 @@ int svol_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const 
                   int64_t Lq, int64_t Lk, int64_t dh, float scale, float q_premul, void* ws, int64_t ws_bytes,
                   int dtype, void* stream);
 
+/* Round 6 (ABI 7): the zero fill of the single pass's fp32 dQ image off the critical path.  The image (B*Lq*H*dh floats at the head
+ * of ws) must be zero when the key-stationary kernel starts; svol_attn_bwd zeroes it in its prologue kernel, 51 MB of stores per cfg2
+ * launch in front of an issue-bound kernel that leaves the memory side idle.  A caller that alternates between TWO workspaces can
+ * have the other one zeroed beside that kernel instead:
+ *   svol_attn_bwd_sp_image_bytes: bytes of the image if an unmasked, pre-multiplied launch of this shape with a workspace of ws_bytes
+ *     runs the single pass, else 0 (then the two entries below add nothing).
+ *   svol_attn_bwd_zero_ws: zeroes that image on `stream` (SVOL_E_UNSUPPORTED when the shape is not the single pass's).
+ *   svol_attn_bwd_ex = svol_attn_bwd plus  flags: SVOL_ATTN_DQ_PREZEROED = the image of ws is zero already (honoured by the single
+ *     pass only; every other path ignores it)  ·  ev_prep: optional hipEvent_t recorded on `stream` behind the prologue kernel (other
+ *     paths: behind the last launch) — the point after which work on the caller's OTHER workspace may start on another stream.
+ * Same values as svol_attn_bwd (the zero fill moves, nothing else); replaces the same reference lines. */
+#define SVOL_ATTN_DQ_PREZEROED 1
+int64_t svol_attn_bwd_sp_image_bytes(int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t dh, int64_t ws_bytes, int dtype);
+int svol_attn_bwd_zero_ws(void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t dh, int dtype, void* stream);
+int svol_attn_bwd_ex(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
+                     int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta, const float* kbias,
+                     void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int64_t B, int64_t H,
+                     int64_t Lq, int64_t Lk, int64_t dh, float scale, float q_premul, void* ws, int64_t ws_bytes,
+                     int dtype, int flags, void* ev_prep, void* stream);
+
 /* The same with attention-probability dropout (nn.MultiheadAttention(dropout = p) in training mode, transformer.py:158-160): the softmax
  * numerators that feed P V are multiplied by keep(seed, row = (b*H + h)*Lq + q, column = key) — svol_dropout over a ones tensor
  * [B,H,Lq,Lk] with row_len = Lk and the same seed IS the mask; lse2 stays the undropped softmax's.  dropout_p > 0 runs on the general kernels (no anchored fast path). */
@@ -529,7 +549,11 @@ int svol_clock_probe(uint64_t* samples, int32_t* count, int32_t max_samples, con
  *  bwd tmp: DS32_3 f32, DS3 dt [M,D] · DPRE dt [M,F] · DY2 dt · DS32_2 f32 · G2D dt · DO dt [M,D] · DQKV dt [M,3D] ·
  *           DELTA f32 [3,B,H,L] · DXQP, DXQ dt [M,D] · GATE_WS2 f32 [B*L + B*H]
  *  bwd out: DX32 f32 [M,D] · DU f32 [B,H,D] (caller zeroes)
- *  grads  : DG1,DBT1,DG2,DBT2,DG3,DBT3 · DW_IN [3D,D], DB_IN · DW_O, DB_O · DW_FC1, DB_FC1 · DW_FC2, DB_FC2 (f32, accumulated) */
+ *  grads  : DG1,DBT1,DG2,DBT2,DG3,DBT3 · DW_IN [3D,D], DB_IN · DW_O, DB_O · DW_FC1, DB_FC1 · DW_FC2, DB_FC2 (f32, accumulated)
+ *  backward, optional (all NULL = svol_attn_bwd as before): EV_CLEAN_IN hipEvent_t = ATTN_WS's dQ image was zeroed on another stream
+ *       (the program waits for it and passes SVOL_ATTN_DQ_PREZEROED) · EV_PREP hipEvent_t + ATTN_WS_NEXT + ZERO_STREAM hipStream_t +
+ *       EV_CLEAN_OUT hipEvent_t: behind the attention backward's prologue the program zeroes ATTN_WS_NEXT's image on ZERO_STREAM
+ *       (svol_attn_bwd_zero_ws) and records EV_CLEAN_OUT there — the caller hands that buffer / event to the next layer's backward */
 #define SVOL_VH_SLOTS(X) \
     X(X32) X(POS) X(U) X(G1) X(BT1) X(G2) X(BT2) X(G3) X(BT3) X(B_IN) X(B_O) X(B_FC1) X(B_FC2) X(QSCALE) \
     X(W_IN) X(WV_HILO) X(W_O) X(W_FC1) X(W_FC2) X(W_IN_T) X(W_O_T) X(W_FC1_T) X(W_FC2_T) \
@@ -539,7 +563,7 @@ int svol_clock_probe(uint64_t* samples, int32_t* count, int32_t max_samples, con
     X(DM32) X(DM) X(DMPOS) X(DS32_3) X(DS3) X(DPRE) X(DY2) X(DS32_2) X(G2D) X(DO) X(DQKV) X(DELTA) X(DXQP) X(DXQ) X(GATE_WS2) \
     X(DX32) X(DU) \
     X(DG1) X(DBT1) X(DG2) X(DBT2) X(DG3) X(DBT3) X(DW_IN) X(DB_IN) X(DW_O) X(DB_O) X(DW_FC1) X(DB_FC1) X(DW_FC2) X(DB_FC2) \
-    X(EV_A0) X(EV_A1)
+    X(EV_A0) X(EV_A1) X(EV_CLEAN_IN) X(EV_PREP) X(ATTN_WS_NEXT) X(ZERO_STREAM) X(EV_CLEAN_OUT)
 /* query self-attention (:145-147): packed q|k, v projections of the N queries, self-attention, out-proj + residual -> LN4 (+query_pos).
  * R = B*N rows, everything in qdt.
  *  in : O32 f32, O qdt, OPOS qdt [R,D] · QPOS qdt [N,D]

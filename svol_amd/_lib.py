@@ -75,6 +75,10 @@ SIGNATURES = {
                       _int, _p],
     'svol_attn_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64,
                       _i64, _i64, _i64, _i64, _i64, _f32, _f32, _p, _i64, _int, _p],
+    'svol_attn_bwd_ex': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64,
+                         _i64, _i64, _i64, _i64, _i64, _f32, _f32, _p, _i64, _int, _int, _p, _p],
+    'svol_attn_bwd_sp_image_bytes': [_i64, _i64, _i64, _i64, _i64, _i64, _int],
+    'svol_attn_bwd_zero_ws': [_p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _p],
     'svol_attn_fwd_dropout': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _p, _i64,
                               _f32, _u64, _int, _p],
     'svol_attn_bwd_dropout': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64,
@@ -140,6 +144,7 @@ def lib():
             f.restype = _int
             f.argtypes = at
         L.svol_attn_ws_bytes.restype = _i64
+        L.svol_attn_bwd_sp_image_bytes.restype = _i64
         L.svol_block_slot_names.restype = ctypes.c_char_p
         L.svol_block_slot_names.argtypes = [_int]
         _LIB = L

@@ -373,6 +373,68 @@ def _maybe_events(name, meta):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# the single-pass attention backward's fp32 dQ image, zeroed off the critical path
+# ----------------------------------------------------------------------------------------------------------------------
+# The key-stationary kernel adds into a zeroed [B, L, H, 32] fp32 image (51 MB at cfg2).  svol_attn_bwd zeroes it in its prologue
+# kernel — a third of that kernel's bytes, on the video stream, in front of an issue-bound launch that leaves the memory side idle
+# for 0.86 ms.  With TWO workspaces alternating between the layers, layer i's program zeroes the other one on a side stream BEHIND
+# its own prologue, i.e. beside its long kernel, and layer i-1 finds it clean (include/svol_hip.h: svol_attn_bwd_ex, the
+# EV_CLEAN_IN / EV_PREP / ATTN_WS_NEXT / ZERO_STREAM / EV_CLEAN_OUT slots).  The last layer of a step cleans the first one's of the
+# next step.  Same values either way: only the zero fill moves.
+# MEASURED (round 6, same box): the prologue 35.8 -> 13.6 us, the zero launch 12.8 us beside the long kernel; the launch group in the
+# step 915 -> 895 us with a 64-workgroup fill (2048 workgroups: +10 us — a wide grid takes dispatch slots from the long kernel's first
+# round) — and the STEP does not move: 17.04-17.11 ms with it against 17.02-17.05 without (four alternating pairs).  The video stream's
+# chain gets shorter, the step does not: outside the attention launches the three streams are bound by memory THROUGHPUT together, and
+# 0.3 GB of 46 GB per step moved under the attention kernel is below what the two extra event packets per layer on the video stream
+# cost.  Off by default; SVOL_DQ_PREZERO=1 turns it on.
+DQ_PREZERO = os.environ.get('SVOL_DQ_PREZERO') is not None and os.environ.get('SVOL_NO_DQ_PREZERO') is None
+_DQ_PREZERO = {}
+
+
+class _DqPrezero:
+    __slots__ = ('bufs', 'side', 'ev_prep', 'clean_ev', 'clean', 'nxt')
+
+    def __init__(self, dev, wsb):
+        self.bufs = [torch.empty((_align(wsb, 1 << 20),), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.side = torch.cuda.Stream(device=dev)
+        self.ev_prep = torch.cuda.Event()
+        self.clean_ev = [torch.cuda.Event(), torch.cuda.Event()]
+        for e_ in [self.ev_prep] + self.clean_ev:
+            e_.record()   # materialises the handle (torch creates the hipEvent at the first record)
+        self.clean = [False, False]
+        self.nxt = 0
+
+    def bind(self, tbl):
+        i = self.nxt
+        tbl.set('ATTN_WS', self.bufs[i].data_ptr())
+        tbl.set('EV_CLEAN_IN', self.clean_ev[i].cuda_event if self.clean[i] else None)
+        tbl.set('EV_PREP', self.ev_prep.cuda_event)
+        tbl.set('ATTN_WS_NEXT', self.bufs[1 - i].data_ptr())
+        tbl.set('ZERO_STREAM', self.side.cuda_stream)
+        tbl.set('EV_CLEAN_OUT', self.clean_ev[1 - i].cuda_event)
+        self.clean[i] = False   # whatever happens from here on, this image is no longer known to be zero
+
+    def advance(self, tbl):
+        i = self.nxt
+        self.clean[1 - i] = True
+        self.nxt = 1 - i
+        for n_ in ('EV_CLEAN_IN', 'EV_PREP', 'ATTN_WS_NEXT', 'ZERO_STREAM', 'EV_CLEAN_OUT'):
+            tbl.set(n_, None)
+
+
+def _dq_prezero(dev, B, H, L, dh, dt, wsb):
+    """the two-workspace state for this launch shape, or None (switch off, stream capture, a shape the single pass does not serve)."""
+    if not DQ_PREZERO or dt == torch.float32 or torch.cuda.is_current_stream_capturing():
+        return None
+    key = (dev, ops._stream(), B, H, L, dh, dt, wsb)
+    st = _DQ_PREZERO.get(key)
+    if st is None:
+        img = _lib.lib().svol_attn_bwd_sp_image_bytes(B, H, L, L, dh, wsb, ops._DT[dt])
+        st = _DQ_PREZERO[key] = _DqPrezero(dev, wsb) if img > 0 else False
+    return st or None
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # video half
 # ----------------------------------------------------------------------------------------------------------------------
 def _vh_fwd_layout(B, L, D, H, F, e):
@@ -498,7 +560,12 @@ class VideoHalfFn(torch.autograd.Function):
         if ev:
             tbl.set('EV_A0', ev[0].cuda_event)
             tbl.set('EV_A1', ev[1].cuda_event)
+        pz = _dq_prezero(dev, B, H, L, D // H, dt, dims[8]) if ctx.big else None
+        if pz is not None:
+            pz.bind(tbl)
         _lib.check(L_.svol_video_half_bwd(dims, tbl.arr, 2, s), 'svol_video_half_bwd')
+        if pz is not None:
+            pz.advance(tbl)
         tbl.set('EV_A0', None)
         tbl.set('EV_A1', None)
         if split:

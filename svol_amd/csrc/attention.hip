@@ -500,9 +500,13 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
                               const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta,
                               const float* kbias, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int B,
                               int H, int Lq, int Lk, int dh, float scale, float premul, float* ws, int64_t ws_bytes,
-                              float drop_p, uint64_t drop_seed, hipStream_t s);
+                              float drop_p, uint64_t drop_seed, int flags, void* ev_prep, hipStream_t s);
 
 int64_t svol_attn_ws_floats_bf16(int B, int H, int Lq, int Lk, int dh);
+int64_t svol_attn_sp_image_bytes_bf16(int B, int H, int Lq, int Lk, int dh, int64_t ws_bytes);
+int svol_attn_sp_zero_bf16_launch(float* ws, int64_t ws_bytes, int B, int H, int Lq, int Lk, int dh, hipStream_t s);
+int64_t svol_attn_sp_image_bytes_f16(int B, int H, int Lq, int Lk, int dh, int64_t ws_bytes);
+int svol_attn_sp_zero_f16_launch(float* ws, int64_t ws_bytes, int B, int H, int Lq, int Lk, int dh, hipStream_t s);
 // the same kernels compiled with fp16 operands (attention_bf16.hip with -DSVOL_H16_FP16)
 int svol_attn_fwd_f16_launch(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                              int64_t ldo, float* lse2, const float* kbias, int B, int H, int Lq, int Lk, int dh, float scale,
@@ -511,7 +515,7 @@ int svol_attn_bwd_f16_launch(const void* q, int64_t ldq, const void* k, int64_t 
                              const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta,
                              const float* kbias, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int B,
                              int H, int Lq, int Lk, int dh, float scale, float premul, float* ws, int64_t ws_bytes,
-                             float drop_p, uint64_t drop_seed, hipStream_t s);
+                             float drop_p, uint64_t drop_seed, int flags, void* ev_prep, hipStream_t s);
 
 extern "C" {
 
@@ -564,7 +568,7 @@ static int attn_bwd_impl(const void* q, int64_t ldq, const void* k, int64_t ldk,
                          int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta, const float* kbias, void* dq,
                          int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int64_t B, int64_t H, int64_t Lq, int64_t Lk,
                          int64_t dh, float scale, float q_premul, void* ws, int64_t ws_bytes, float drop_p, uint64_t drop_seed,
-                         int dtype, void* stream) {
+                         int dtype, void* stream, int flags = 0, void* ev_prep = nullptr) {
     if (!q || !k || !v || !o || !d_o || !lse2 || !delta || !dq || !dk || !dv) return SVOL_E_INVALID;
     if (!(drop_p >= 0.f && drop_p < 1.f)) return SVOL_E_INVALID;
     int rc = check_common(B, H, Lq, Lk, dh, dtype);
@@ -589,10 +593,11 @@ static int attn_bwd_impl(const void* q, int64_t ldq, const void* k, int64_t ldk,
     if (svol_is16(dtype))
         return (dtype == SVOL_BF16 ? svol_attn_bwd_bf16_launch : svol_attn_bwd_f16_launch)(
             q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse2, delta, kbias, dq, lddq, dk, lddk, dv, lddv, (int)B, (int)H, (int)Lq,
-            (int)Lk, (int)dh, scale, q_premul, aligned16(ws) ? (float*)ws : nullptr, ws_bytes, drop_p, drop_seed, s);
+            (int)Lk, (int)dh, scale, q_premul, aligned16(ws) ? (float*)ws : nullptr, ws_bytes, drop_p, drop_seed, flags, ev_prep, s);
     hipLaunchKernelGGL(attn_delta_kernel<float>, gd, dim3(256), 0, s, p);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, gq, dim3(256), 0, s, p);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<float>, gk, dim3(256), 0, s, p);
+    if (ev_prep) (void)hipEventRecord(static_cast<hipEvent_t>(ev_prep), s);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }
@@ -603,6 +608,28 @@ int svol_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const 
                   int64_t dh, float scale, float q_premul, void* ws, int64_t ws_bytes, int dtype, void* stream) {
     return attn_bwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse2, delta, kbias, dq, lddq, dk, lddk, dv, lddv, B, H, Lq, Lk, dh,
                          scale, q_premul, ws, ws_bytes, 0.f, 0, dtype, stream);
+}
+int svol_attn_bwd_ex(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
+                     int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta, const float* kbias, void* dq,
+                     int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int64_t B, int64_t H, int64_t Lq, int64_t Lk,
+                     int64_t dh, float scale, float q_premul, void* ws, int64_t ws_bytes, int dtype, int flags, void* ev_prep,
+                     void* stream) {
+    if (flags & ~SVOL_ATTN_DQ_PREZEROED) return SVOL_E_INVALID;
+    return attn_bwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse2, delta, kbias, dq, lddq, dk, lddk, dv, lddv, B, H, Lq, Lk, dh,
+                         scale, q_premul, ws, ws_bytes, 0.f, 0, dtype, stream, flags, ev_prep);
+}
+int64_t svol_attn_bwd_sp_image_bytes(int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t dh, int64_t ws_bytes, int dtype) {
+    if (!svol_is16(dtype) || check_common(B, H, Lq, Lk, dh, dtype)) return 0;
+    return (dtype == SVOL_BF16 ? svol_attn_sp_image_bytes_bf16 : svol_attn_sp_image_bytes_f16)((int)B, (int)H, (int)Lq, (int)Lk, (int)dh,
+                                                                                              ws_bytes);
+}
+int svol_attn_bwd_zero_ws(void* ws, int64_t ws_bytes, int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t dh, int dtype, void* stream) {
+    if (!ws || !aligned16(ws)) return SVOL_E_INVALID;
+    if (!svol_is16(dtype)) return SVOL_E_UNSUPPORTED;
+    const int rc = check_common(B, H, Lq, Lk, dh, dtype);
+    if (rc) return rc;
+    return (dtype == SVOL_BF16 ? svol_attn_sp_zero_bf16_launch : svol_attn_sp_zero_f16_launch)(
+        static_cast<float*>(ws), ws_bytes, (int)B, (int)H, (int)Lq, (int)Lk, (int)dh, reinterpret_cast<hipStream_t>(stream));
 }
 int svol_attn_bwd_dropout(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
                           int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta, const float* kbias, void* dq,

@@ -1817,6 +1817,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fq_bf16(Args p) {
 // before the single pass: delta = rowsum(dO * O); the row constants as plain fp32 vectors nl = -lse2, nd = -delta ([B,H,Lq], the
 // loop DMAs 64 of them per wave instruction); the fp32 dQ image zeroed.  One thread per (row, head), 32 rows x H heads per block;
 // the [B,H,Lq] side is read / written through LDS so that both sides of the transposition are coalesced.
+// ZERO = false: the caller has zeroed the image already (SVOL_ATTN_DQ_PREZEROED: on another stream, under the previous launch's
+// issue-bound single pass, where the 51 MB of stores cost nothing — here they are a third of this kernel's bytes on the critical path).
+template <bool ZERO>
 __global__ __launch_bounds__(256) void attn_bwd_sp_prep_bf16(Args p) {
     __shared__ float s_lse[8][33], s_dl[8][33];
     const int tid = threadIdx.x;
@@ -1838,9 +1841,11 @@ __global__ __launch_bounds__(256) void attn_bwd_sp_prep_bf16(Args p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) dl += (float)a[e] * (float)c[e];
         }
-        float* z = p.ws_dq + row * (p.H * 32) + hh * 32;
+        if constexpr (ZERO) {
+            float* z = p.ws_dq + row * (p.H * 32) + hh * 32;
 #pragma unroll
-        for (int i = 0; i < 32; i += 4) *reinterpret_cast<f32x4*>(z + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 32; i += 4) *reinterpret_cast<f32x4*>(z + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         s_dl[hh][rl] = dl;
     }
     __syncthreads();
@@ -1885,6 +1890,13 @@ __global__ __launch_bounds__(256) void attn_dq_round_bf16(Args p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] = (h16_t)(a[e] * p.scale); v[4 + e] = (h16_t)(b[e] * p.scale); }
     *reinterpret_cast<h16x8*>(reinterpret_cast<h16_t*>(p.dq) + row * p.lddq + c) = v;
+}
+
+// the fp32 dQ image zeroed by itself (svol_attn_bwd_zero_ws): few registers, no LDS — its waves fit beside a single-pass workgroup's
+__global__ __launch_bounds__(256) void attn_sp_zero_image(float* __restrict__ z, int64_t n4) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+        reinterpret_cast<f32x4*>(z)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 // Every MFMA of the single-pass kernel is inline asm: at one wave per SIMD (512 registers) hipcc selects the AGPR-destination form
@@ -2864,6 +2876,25 @@ static bool fewq_ok(const Args& p) {
     return !off && !attn_deterministic() && p.ksplit > 1 && p.Lq <= KT && p.dh == 32 && p.drop_p == 0.f && p.ws_dq != nullptr;
 }
 static int64_t sp_ws_floats(int B, int H, int Lq, int Lk) { return (int64_t)B * Lq * H * 32 + (int64_t)B * H * 4 * 2 * (Lk % SP_KEYS) * 32; }
+// an unmasked, pre-multiplied, dropout-free launch of this shape with this workspace runs the single pass
+static bool sp_taken(int B, int H, int Lq, int Lk, int dh, const void* ws, int64_t ws_bytes) {
+    static const bool no_head_xcd = getenv("SVOL_ATTN_NO_HEAD_XCD") != nullptr;
+    return !no_head_xcd && sp_shape_ok(B, H, Lq, Lk, dh) && ws && ws_bytes >= 4 * sp_ws_floats(B, H, Lq, Lk);
+}
+// bytes of the fp32 dQ image at the head of the workspace when the single pass serves the shape, else 0 (svol_attn_bwd_sp_image_bytes)
+int64_t svol_attn_sp_image_bytes_bf16(int B, int H, int Lq, int Lk, int dh, int64_t ws_bytes) {
+    return sp_taken(B, H, Lq, Lk, dh, reinterpret_cast<const void*>(16), ws_bytes) ? (int64_t)B * Lq * H * 32 * 4 : 0;
+}
+int svol_attn_sp_zero_bf16_launch(float* ws, int64_t ws_bytes, int B, int H, int Lq, int Lk, int dh, hipStream_t s) {
+    if (!sp_taken(B, H, Lq, Lk, dh, ws, ws_bytes)) return SVOL_E_UNSUPPORTED;
+    const int64_t n4 = (int64_t)B * Lq * H * 32 / 4;
+    // few workgroups: the launch runs BESIDE a single-pass kernel whose workgroups own their CUs' register files; a wide grid takes
+    // dispatch slots from that kernel's first round (measured: 2048 workgroups cost it 30 us, more than the fill saves)
+    static const int wgs = getenv("SVOL_SP_ZERO_WGS") ? atoi(getenv("SVOL_SP_ZERO_WGS")) : 64;
+    const int64_t want = (n4 + 255) / 256;
+    hipLaunchKernelGGL(attn_sp_zero_image, dim3((unsigned)(want < wgs ? want : (wgs > 0 ? wgs : 1))), dim3(256), 0, s, ws, n4);
+    return hipGetLastError() == hipSuccess ? SVOL_OK : SVOL_E_LAUNCH;
+}
 int64_t svol_attn_ws_floats_bf16(int B, int H, int Lq, int Lk, int dh) {
     int tps;
     const int ks = plan_ksplit(B, H, Lq, Lk, dh, INT64_MAX, &tps);
@@ -2941,7 +2972,14 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
                               const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse2, float* delta,
                               const float* kbias, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int B,
                               int H, int Lq, int Lk, int dh, float scale, float premul, float* ws, int64_t ws_bytes,
-                              float drop_p, uint64_t drop_seed, hipStream_t s) {
+                              float drop_p, uint64_t drop_seed, int flags, void* ev_prep, hipStream_t s) {
+    // ev_prep: recorded behind the launches that must precede work on the caller's OTHER workspace (single pass: behind the prep
+    // kernel, i.e. in front of the long key-stationary kernel; every other path: behind the last launch)
+    struct PrepEvent {
+        void* ev; hipStream_t s; bool done = false;
+        void fire() { if (ev && !done) (void)hipEventRecord(static_cast<hipEvent_t>(ev), s); done = true; }
+        ~PrepEvent() { fire(); }
+    } prep_ev{ev_prep, s};
     Args p{};
     p.drop_p = drop_p; p.drop_inv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; p.drop_seed = drop_seed;
     p.q = q; p.k = k; p.v = v; p.o = o; p.d_o = d_o; p.lse2 = const_cast<float*>(lse2); p.delta = delta; p.kbias = kbias;
@@ -2981,14 +3019,16 @@ int svol_attn_bwd_bf16_launch(const void* q, int64_t ldq, const void* k, int64_t
             hipLaunchKernelGGL(attn_bwd_dq_bf16_pre_masked, gq2, dim3(256), 0, s, pq);
             hipLaunchKernelGGL(attn_bwd_dkdv_bf16_pre_masked, gk2, dim3(256), 0, s, pk);
         } else {
-            if (pq.head_xcd && sp_shape_ok(B, H, Lq, Lk, dh) && ws && ws_bytes >= 4 * sp_ws_floats(B, H, Lq, Lk)) {
+            if (pq.head_xcd && sp_taken(B, H, Lq, Lk, dh, ws, ws_bytes)) {
                 // single pass: row constants + zeroed fp32 dQ image, the key-stationary kernel, rounding of dQ
                 Args ps = pq;
                 const int64_t n = (int64_t)B * H * Lq;
                 ps.ws_dq = ws;
                 ps.nl2 = reinterpret_cast<unsigned*>(delta + n);     // here: plain fp32 -lse2
                 ps.nd2 = reinterpret_cast<unsigned*>(delta + 2 * n);  //       plain fp32 -delta
-                hipLaunchKernelGGL(attn_bwd_sp_prep_bf16, dim3((unsigned)((int64_t)B * Lq / 32)), dim3(256), 0, s, ps);
+                if (flags & SVOL_ATTN_DQ_PREZEROED) hipLaunchKernelGGL(attn_bwd_sp_prep_bf16<false>, dim3((unsigned)((int64_t)B * Lq / 32)), dim3(256), 0, s, ps);
+                else hipLaunchKernelGGL(attn_bwd_sp_prep_bf16<true>, dim3((unsigned)((int64_t)B * Lq / 32)), dim3(256), 0, s, ps);
+                prep_ev.fire();
                 static const bool sp_v9 = getenv("SVOL_ATTN_SP_V9") != nullptr;   // round 4's placement of the full workgroups' stream (A/B)
                 if (sp_v9) hipLaunchKernelGGL(attn_bwd_sp_bf16_v9, dim3(sp_grid(B, H, Lk)), dim3(256), 0, s, ps);
                 else hipLaunchKernelGGL(attn_bwd_sp_bf16, dim3(sp_grid(B, H, Lk)), dim3(256), 0, s, ps);

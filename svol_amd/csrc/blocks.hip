@@ -240,11 +240,24 @@ int svol_video_half_bwd(const int64_t* dims, void* const* p, int phase, void* s)
         RUN(nt(P(G2D), D, P(W_O_T), D, P(DO), D, nullptr, nullptr, M, D, D, dt, s));
     }
     if (phase != 1) {
+        // the fp32 dQ image of the single pass: zeroed beside the PREVIOUS layer's launch when the caller alternates two workspaces
+        int aflags = 0;
+        if (P(EV_CLEAN_IN)) {
+            if (hipStreamWaitEvent(static_cast<hipStream_t>(s), static_cast<hipEvent_t>(P(EV_CLEAN_IN)), 0) != hipSuccess) return SVOL_E_LAUNCH;
+            aflags = SVOL_ATTN_DQ_PREZEROED;
+        }
         record(P(EV_A0), s);
-        RUN(svol_attn_bwd(P(QKV), 3 * D, at(P(QKV), D, dt), 3 * D, at(P(QKV), 2 * D, dt), 3 * D, P(O), D, P(DO), D, f32(P(LSE)),
-                          f32(P(DELTA)), nullptr, P(DQKV), 3 * D, at(P(DQKV), D, dt), 3 * D, at(P(DQKV), 2 * D, dt), 3 * D, d.B, d.H, d.L,
-                          d.L, dh, attn_scale(dh), attn_premul(dh, dt), P(ATTN_WS), d.ws_bytes, dt, s));
+        RUN(svol_attn_bwd_ex(P(QKV), 3 * D, at(P(QKV), D, dt), 3 * D, at(P(QKV), 2 * D, dt), 3 * D, P(O), D, P(DO), D, f32(P(LSE)),
+                             f32(P(DELTA)), nullptr, P(DQKV), 3 * D, at(P(DQKV), D, dt), 3 * D, at(P(DQKV), 2 * D, dt), 3 * D, d.B, d.H, d.L,
+                             d.L, dh, attn_scale(dh), attn_premul(dh, dt), P(ATTN_WS), d.ws_bytes, dt, aflags, P(EV_PREP), s));
         record(P(EV_A1), s);
+        if (P(ATTN_WS_NEXT) && P(ZERO_STREAM) && P(EV_PREP) && P(EV_CLEAN_OUT)) {   // ... and the next layer's beside this one
+            hipStream_t zs = static_cast<hipStream_t>(P(ZERO_STREAM));
+            if (hipStreamWaitEvent(zs, static_cast<hipEvent_t>(P(EV_PREP)), 0) != hipSuccess) return SVOL_E_LAUNCH;
+            const int zrc = svol_attn_bwd_zero_ws(P(ATTN_WS_NEXT), d.ws_bytes, d.B, d.H, d.L, d.L, dh, dt, zs);
+            if (zrc) return zrc;
+            record(P(EV_CLEAN_OUT), zs);
+        }
         // d(y + pos) = [dq dk] W_qk ; dy = dv W_v
         RUN(nt(P(DQKV), 3 * D, P(W_IN_T), 3 * D, P(DXQP), D, nullptr, nullptr, M, D, 2 * D, dt, s));
         RUN(nt(at(P(DQKV), 2 * D, dt), 3 * D, at(P(W_IN_T), 2 * D, dt), 3 * D, P(DXQ), D, nullptr, nullptr, M, D, D, dt, s));

@@ -44,6 +44,8 @@ typedef f16x2 h16x2;
 #define svol_attn_fwd_bf16_launch svol_attn_fwd_f16_launch
 #define svol_attn_bwd_bf16_launch svol_attn_bwd_f16_launch
 #define svol_attn_ws_floats_bf16 svol_attn_ws_floats_f16
+#define svol_attn_sp_image_bytes_bf16 svol_attn_sp_image_bytes_f16
+#define svol_attn_sp_zero_bf16_launch svol_attn_sp_zero_f16_launch
 #else
 typedef bf16_t h16_t;
 typedef bf16x8 h16x8;

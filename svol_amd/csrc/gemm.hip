@@ -648,7 +648,7 @@ static int tn_generic_plan(const void* A, int64_t lda, const void* B, int64_t ld
 
 extern "C" {
 
-int svol_abi_version(void) { return 6; }
+int svol_abi_version(void) { return 7; }
 
 const char* svol_strerror(int code) {
     switch (code) {

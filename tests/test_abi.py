@@ -30,7 +30,7 @@ def test_header_symbols_exported():
         assert getattr(L, fn)(0, 0, 0) == -1
     for blk, first in ((0, 'X32'), (1, 'O32'), (2, 'O32')):
         assert L.svol_block_slot_names(blk).decode().split(',')[0] == first
-    assert L.svol_abi_version() == 6
+    assert L.svol_abi_version() == 7
     assert b'invalid' in L.svol_strerror(-1)
 
 

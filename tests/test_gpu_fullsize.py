@@ -315,6 +315,86 @@ def test_single_pass_backward_stays_inside_its_scratch(B, L):
         assert bool(torch.isfinite(dqkv.float()).all())
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_single_pass_backward_with_a_prezeroed_image(dtype):
+    """svol_attn_bwd_ex / svol_attn_bwd_zero_ws (round 6, ABI 7): the fp32 dQ image zeroed by the caller on ANOTHER stream instead of
+    by the prologue kernel.  (a) same values: dK / dV bit-identical to svol_attn_bwd, dQ to fp32 summation order; the other-stream
+    hand-off is the block programs' (zero on a side stream -> event -> wait on the launch stream; ev_prep -> wait -> next zero).
+    (b) negative control: the flag over an image full of 1.0 must show in dQ — i.e. the prologue really skipped its zero fill.
+    (c) a shape the single pass does not serve: image bytes 0, zero_ws refuses, the flag is ignored (values as svol_attn_bwd)."""
+    import math
+    from svol_amd import _lib, ops
+    lib = _lib.lib()
+    B, H, L, dh = 1, 8, 1536, 32     # 3 key groups of 512, no tail
+    d = H * dh
+    pm = 1.4426950408889634 / math.sqrt(dh)
+    g = torch.Generator().manual_seed(21)
+    qkv = torch.cat([torch.randn((B * L, d), generator=g) * pm, torch.randn((B * L, d), generator=g), torch.randn((B * L, d), generator=g)],
+                    1).to(dtype).cuda()
+    do = torch.randn((B * L, d), generator=g).to(dtype).cuda()
+    qd, kd, vd = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    o, lse2 = ops.attn_fwd(qd, kd, vd, B, H, L, L, dh, None, pm)
+    P = ops._ptr
+    wsb = int(lib.svol_attn_ws_bytes(B, H, L, L, dh))
+    img = int(lib.svol_attn_bwd_sp_image_bytes(B, H, L, L, dh, wsb, ops._dt(qd)))
+    assert img == B * L * H * dh * 4 and wsb >= img
+    assert int(lib.svol_attn_bwd_sp_image_bytes(B, H, L, L, dh, img - 4, ops._dt(qd))) == 0   # a workspace too small for the image
+
+    def run(ws, flags, ev_prep=None, stream=None):
+        dqkv = torch.full_like(qkv, float('nan'))
+        delta = torch.empty((3, B, H, L), dtype=torch.float32, device='cuda')
+        rc = lib.svol_attn_bwd_ex(P(qd), qd.stride(0), P(kd), kd.stride(0), P(vd), vd.stride(0), P(o), o.stride(0), P(do), do.stride(0),
+                                  P(lse2), P(delta), None, P(dqkv[:, :d]), dqkv.stride(0), P(dqkv[:, d:2 * d]), dqkv.stride(0),
+                                  P(dqkv[:, 2 * d:]), dqkv.stride(0), B, H, L, L, dh, 1.0 / math.sqrt(dh), pm, P(ws), wsb, ops._dt(qd),
+                                  flags, ev_prep, stream if stream is not None else ops._stream())
+        _lib.check(rc, 'svol_attn_bwd_ex')
+        return dqkv
+
+    ws0 = torch.full((wsb // 4,), 7.0, dtype=torch.float32, device='cuda')
+    ref = run(ws0, 0)                                     # the prologue zeroes (== svol_attn_bwd)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ref.float()).all())
+    # (a) two workspaces, the block programs' hand-off: zero A on the side stream; launch on A; behind its prologue zero B; launch on B
+    side = torch.cuda.Stream()
+    cur = torch.cuda.current_stream()
+    wsA = torch.full((wsb // 4,), 3.0, dtype=torch.float32, device='cuda')
+    wsB = torch.full((wsb // 4,), 5.0, dtype=torch.float32, device='cuda')
+    ev_prep, clean = torch.cuda.Event(), torch.cuda.Event()
+    ev_prep.record()
+    clean.record()
+    torch.cuda.synchronize()
+    _lib.check(lib.svol_attn_bwd_zero_ws(P(wsA), wsb, B, H, L, L, dh, ops._dt(qd), side.cuda_stream), 'svol_attn_bwd_zero_ws')
+    clean.record(side)
+    cur.wait_event(clean)
+    gotA = run(wsA, 1, ev_prep.cuda_event)
+    side.wait_event(ev_prep)
+    _lib.check(lib.svol_attn_bwd_zero_ws(P(wsB), wsb, B, H, L, L, dh, ops._dt(qd), side.cuda_stream), 'svol_attn_bwd_zero_ws')
+    clean.record(side)
+    cur.wait_event(clean)
+    gotB = run(wsB, 1, ev_prep.cuda_event)
+    torch.cuda.synchronize()
+    dq_scale = float(ref[:, :d].float().abs().max())
+    for got in (gotA, gotB):
+        assert torch.equal(got[:, d:], ref[:, d:])
+        assert float((got[:, :d].float() - ref[:, :d].float()).abs().max()) <= 2.0 ** -6 * dq_scale
+    # (b) the flag over a dirty image: dQ = scale * (1.0 + the sum) — far outside the summation-order band
+    ws1 = torch.full((wsb // 4,), 1.0, dtype=torch.float32, device='cuda')
+    bad = run(ws1, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(bad[:, d:], ref[:, d:])
+    off = (bad[:, :d].float() - ref[:, :d].float())
+    assert abs(float(off.double().mean()) - 1.0 / math.sqrt(dh)) < 0.05 / math.sqrt(dh), 'the prologue zeroed an image it was told is clean'
+    # (c) 256 keys: the two-pass kernels; no image, zero_ws refuses, the flag changes nothing
+    L2 = 256
+    assert int(lib.svol_attn_bwd_sp_image_bytes(B, H, L2, L2, dh, 1 << 30, ops._dt(qd))) == 0
+    assert lib.svol_attn_bwd_zero_ws(P(ws1), wsb, B, H, L2, L2, dh, ops._dt(qd), ops._stream()) == -2   # SVOL_E_UNSUPPORTED
+    assert lib.svol_attn_bwd_ex(P(qd), qd.stride(0), P(kd), kd.stride(0), P(vd), vd.stride(0), P(o), o.stride(0), P(do), do.stride(0),
+                                P(lse2), P(ws1), None, P(bad[:, :d]), bad.stride(0), P(bad[:, d:2 * d]), bad.stride(0),
+                                P(bad[:, 2 * d:]), bad.stride(0), B, H, L, L, dh, 1.0 / math.sqrt(dh), pm, P(ws1), wsb, ops._dt(qd),
+                                2, None, ops._stream()) == -1   # unknown flag bits: SVOL_E_INVALID, nothing launched
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize('dtype,qv,kv', [(torch.bfloat16, 16.0, 4.0), (torch.float16, 16.0, 4.0), (torch.float16, 2.0, 1.5)],
                          ids=['bf16', 'fp16', 'fp16-2^24'])
 def test_fast_forward_flags_overflow_and_the_safe_kernel_repairs_it(dtype, qv, kv):

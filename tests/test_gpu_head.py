@@ -203,6 +203,65 @@ def test_forward_does_not_depend_on_which_stream_lags(lag):
             assert torch.equal(out['pred_logits'], ref['pred_logits']) and torch.equal(out['pred_boxes'], ref['pred_boxes'])
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_dq_image_zeroed_beside_the_previous_layers_attention_backward_changes_nothing(dtype):
+    """Round 6: the video half's backward can alternate between TWO attention workspaces and zero the next layer's fp32 dQ image on a
+    side stream beside its own single-pass kernel (blocks.DQ_PREZERO / SVOL_DQ_PREZERO=1, svol_attn_bwd_ex + svol_attn_bwd_zero_ws
+    through the EV_CLEAN_IN / EV_PREP / ATTN_WS_NEXT / ZERO_STREAM / EV_CLEAN_OUT slots; off by default: +-0 in the step, see
+    svol_amd/blocks.py).  At the benchmarked depth and length (cfg2, B = 1: six layers, L = 6272 — the launch the single pass serves):
+    forward outputs and losses bit-identical with the switch on and off; gradients to 2e-2 of each parameter's largest entry (float
+    atomics land in run-to-run order, 16-bit rounding behind them) over TWO backward passes, so that the second one starts from an
+    image the first pass's last layer cleaned; the state must really have alternated and ended clean."""
+    from svol_amd import blocks
+    from svol_amd.modeling.loss import build_loss
+    from svol_amd.modeling.svanet import build_svanet
+    from tests.helpers import head_case
+    assert blocks.ENABLED
+    default = blocks.DQ_PREZERO
+    z, meta, args, sd, inp, tg = head_case('cfg2_b1_video')
+    args.compute_dtype = {torch.bfloat16: 'bf16', torch.float16: 'fp16'}[dtype]
+    dev = torch.device('cuda', 0)
+    model = build_svanet(args)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    crit = build_loss(args).to(dev).eval()
+    x = [inp[k].to(dev) for k in ('src_sketch', 'src_sketch_mask', 'src_video', 'src_video_mask')]
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        out = model(*x)
+        ld = crit(out, tg)
+        tot = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+        tot.backward()
+        torch.cuda.synchronize()
+        return out, float(tot), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    try:
+        blocks.DQ_PREZERO = False
+        off, tot_off, g_off = run()
+        blocks.DQ_PREZERO = True
+        blocks._DQ_PREZERO.clear()
+        on1, tot_on1, g_on1 = run()
+        states = [st for st in blocks._DQ_PREZERO.values() if st]
+        assert len(states) == 1, 'the single pass did not serve the launch: nothing was tested'
+        st = states[0]
+        n = args.num_layers
+        assert st.nxt == n % 2 and st.clean[st.nxt] and not st.clean[1 - st.nxt]   # n launches alternated; the next one's image is clean
+        on2, tot_on2, g_on2 = run()                                                  # ... and this pass starts from it
+        assert st.nxt == (2 * n) % 2 and st.clean[st.nxt]
+    finally:
+        blocks.DQ_PREZERO = default
+        blocks._DQ_PREZERO.clear()
+    for on, tot_on, g_on in ((on1, tot_on1, g_on1), (on2, tot_on2, g_on2)):
+        for a, b in zip(list(on.get('aux_outputs', [])) + [on], list(off.get('aux_outputs', [])) + [off]):
+            assert torch.equal(a['pred_logits'], b['pred_logits']) and torch.equal(a['pred_boxes'], b['pred_boxes'])
+        assert tot_on == tot_off
+        assert g_on.keys() == g_off.keys()
+        for k in g_on:
+            scale = float(g_off[k].abs().max())
+            assert float((g_on[k] - g_off[k]).abs().max()) <= 2e-2 * scale + 1e-12, k
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16], ids=['fp32', 'bf16', 'fp16'])
 def test_gate_scores_from_the_previous_layers_layernorm_change_nothing(dtype):
     """Round 6: layer i's last LayerNorm can also write layer i + 1's gate scores (blocks.GATE_SCORES_FUSE / SVOL_GATE_SCORES_FUSE=1,

@@ -22,7 +22,7 @@ def G():
 
 def test_native_library_loaded():
     from svol_amd import _lib
-    assert _lib.lib().svol_abi_version() == 6
+    assert _lib.lib().svol_abi_version() == 7
 
 
 def test_gemm_nt(G):
