@@ -273,11 +273,116 @@ __device__ __forceinline__ bool lsap_reg(const float* __restrict__ Cs, int nr, i
     return true;
 }
 
+// Round 6: the same solver with a shorter step.  One search step of lsap_reg is ~150 instructions of ONE wave (~900 cycles: the 48
+// problems of a training step run one wave each on 48 CUs, and the launch — 0.2 ms — sits on the forward -> backward dependency
+// chain with the rest of the chip idle).  What the step needs per column pair is the smallest UPPER word of the two keys; the lower
+// word, the tie preference and the per-lane pre-selection only matter when two candidates share an upper word (sign, exponent, 20
+// mantissa bits) — then the full procedure of lsap_reg runs (`slow`), bit for bit.  Otherwise the one candidate IS the arg-min:
+// its value, list position and row are four v_readlane.  Scanned-column flags are the removed positions (pos < 0), scanned rows a
+// scalar bit mask, the row index a scalar (v_readfirstlane: the cost row's address is SALU), the second column's cost an immediate
+// offset from the first (the staged block is padded: the value of a column >= nc is discarded).  Same arithmetic in the same
+// order, same visiting order, same tie rule: assignments bit-identical to lsap_reg's (tests: scipy blocks incl. ties, goldens).
+__device__ __forceinline__ unsigned mono_hi32(unsigned hi) { return hi ^ ((unsigned)((int)hi >> 31) | 0x80000000u); }
+__device__ __forceinline__ bool lsap_reg2(const float* __restrict__ Cs, int nr, int nc, int lane, int (&col4row_out)) {
+    const int j0 = lane, j1 = lane + 64;
+    const bool ok0 = j0 < nc, ok1 = j1 < nc;
+    double v0 = 0.0, v1 = 0.0, u = 0.0;
+    int path0 = -1, path1 = -1, r4c0 = -1, r4c1 = -1, c4r = -1;
+    const unsigned long long K_INF = 0xFFF0000000000000ull;  // mono_f64(+inf)
+    for (int cur = 0; cur < nr; ++cur) {
+        int pos0 = ok0 ? nc - 1 - j0 : -1;  // remaining[it] = nc - it - 1; < 0: not in the list (scanned, or no such column)
+        int pos1 = ok1 ? nc - 1 - j1 : -1;
+        double spc0 = INFINITY, spc1 = INFINITY;
+        unsigned long long sr = 0;           // scanned rows
+        int num_remaining = nc, i = cur, sink = -1;
+        double min_val = 0.0;
+        while (sink == -1) {
+            i = __builtin_amdgcn_readfirstlane(i);
+            sr |= 1ull << i;
+            const double ui = readlane_f64(u, i);
+            const float* crow = Cs + i * nc + lane;
+            const double r0 = min_val + (double)crow[0] - ui - v0;
+            const double r1 = min_val + (double)crow[64] - ui - v1;
+            const bool up0 = pos0 >= 0 && r0 < spc0, up1 = pos1 >= 0 && r1 < spc1;
+            spc0 = up0 ? r0 : spc0;
+            path0 = up0 ? i : path0;
+            spc1 = up1 ? r1 : spc1;
+            path1 = up1 ? i : path1;
+            const double f0 = spc0 + 0.0, f1 = spc1 + 0.0;   // -0.0 folded onto +0.0 (equal doubles, equal keys)
+            const unsigned h0 = mono_hi32((unsigned)(__builtin_bit_cast(unsigned long long, f0) >> 32)) | (unsigned)(pos0 >> 31);
+            const unsigned h1 = mono_hi32((unsigned)(__builtin_bit_cast(unsigned long long, f1) >> 32)) | (unsigned)(pos1 >> 31);
+            const unsigned mh = wave_min_u32(min(h0, h1));
+            if (mh >= (unsigned)(K_INF >> 32)) return false;  // infeasible: the cheapest remaining column costs +inf (or none remains)
+            const unsigned long long c0 = __ballot(h0 == mh), c1 = __ballot(h1 == mh);
+            int lj, slot, index, r4;
+            if (__builtin_popcountll(c0) + __builtin_popcountll(c1) == 1) {
+                if (c0) {
+                    lj = __builtin_ctzll(c0); slot = 0;
+                    min_val = readlane_f64(f0, lj);
+                    index = __builtin_amdgcn_readlane(pos0, lj);
+                    r4 = __builtin_amdgcn_readlane(r4c0, lj);
+                } else {
+                    lj = __builtin_ctzll(c1); slot = 1;
+                    min_val = readlane_f64(f1, lj);
+                    index = __builtin_amdgcn_readlane(pos1, lj);
+                    r4 = __builtin_amdgcn_readlane(r4c1, lj);
+                }
+            } else {   // `slow`: several candidates share the upper word — lsap_reg's full (cost, preference) arg-min
+                const bool a0 = pos0 >= 0, a1 = pos1 >= 0;
+                const unsigned long long k0 = a0 ? mono_f64(spc0) : ~0ull, k1 = a1 ? mono_f64(spc1) : ~0ull;
+                const unsigned t0 = a0 ? (0x100000u | ((r4c0 == -1 ? 0x80u | (unsigned)pos0 : 127u - (unsigned)pos0) << 8) | (unsigned)lane) : 0u;
+                const unsigned t1 = a1 ? (0x100000u | ((r4c1 == -1 ? 0x80u | (unsigned)pos1 : 127u - (unsigned)pos1) << 8) | 0x40u | (unsigned)lane) : 0u;
+                const bool second = k1 < k0 || (k1 == k0 && t1 > t0);
+                const unsigned long long k = second ? k1 : k0;
+                const unsigned t = second ? t1 : t0;
+                const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+                const unsigned ml = wave_min_u32(hi == mh ? lo : 0xffffffffu);
+                const unsigned mt = wave_max_u32((hi == mh && lo == ml) ? t : 0u);
+                min_val = unmono_f64(((unsigned long long)mh << 32) | ml);
+                const unsigned pf = (mt >> 8) & 0xffu;
+                index = (pf & 0x80u) ? (int)(pf & 0x7fu) : 127 - (int)pf;
+                lj = (int)(mt & 0x3fu);
+                slot = (int)((mt >> 6) & 1u);
+                r4 = __builtin_amdgcn_readlane(slot ? r4c1 : r4c0, lj);
+            }
+            if (r4 == -1) sink = lj + 64 * slot; else i = r4;
+            const int last = num_remaining - 1;
+            // SC[j] = true; remaining[index] = remaining[last]; --num_remaining
+            const bool me = lane == lj;
+            pos0 = (me && slot == 0) ? -1 : (pos0 == last ? index : pos0);
+            pos1 = (me && slot == 1) ? -1 : (pos1 == last ? index : pos1);
+            num_remaining = last;
+        }
+        // dual update
+        if (lane == cur) u += min_val;
+        {
+            const int c = c4r < 0 ? 0 : c4r;
+            const double s0 = __shfl(spc0, c & 63, 64), s1 = __shfl(spc1, c & 63, 64);
+            if (((sr >> lane) & 1ull) && lane != cur && lane < nr) u += min_val - ((c >> 6) ? s1 : s0);
+        }
+        if (ok0 && pos0 < 0) v0 -= min_val - spc0;
+        if (ok1 && pos1 < 0) v1 -= min_val - spc1;
+        // augment along the path
+        int j = sink;
+        for (;;) {
+            const int lj = j & 63, slot = j >> 6;
+            const int ii = slot ? __builtin_amdgcn_readlane(path1, lj) : __builtin_amdgcn_readlane(path0, lj);
+            if (lane == lj) { if (slot) r4c1 = ii; else r4c0 = ii; }
+            const int t = __builtin_amdgcn_readlane(c4r, ii);
+            if (lane == ii) c4r = j;
+            j = t;
+            if (ii == cur) break;
+        }
+    }
+    col4row_out = c4r;
+    return true;
+}
+
 __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost, const int64_t* __restrict__ cost_off,
                                                   const int32_t* __restrict__ pred_off, const int32_t* __restrict__ pred_cnt,
                                                   const int32_t* __restrict__ tgt_off, const int32_t* __restrict__ tgt_cnt,
                                                   int32_t* __restrict__ match, int32_t* __restrict__ status, int max_dim,
-                                                  int stage_floats) {
+                                                  int stage_floats, int v1) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     double* u = reinterpret_cast<double*>(lds);
     double* v = u + max_dim;
@@ -324,7 +429,7 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost
     if (staged && nr <= 64 && nc <= 128) {  // register-resident path (see lsap_reg)
         __syncthreads();
         int c4 = -1;
-        if (!lsap_reg(Cs, nr, nc, lane, c4)) {
+        if (!(v1 ? lsap_reg(Cs, nr, nc, lane, c4) : lsap_reg2(Cs, nr, nc, lane, c4))) {
             if (lane == 0) status[p] = 2;
             return;
         }
@@ -583,11 +688,13 @@ int svol_lsap_batched(const float* cost, const int64_t* cost_off, const int32_t*
     if (md < 16) md = 16;
     const size_t base = (size_t)md * (3 * 8 + 4 * 4 + 2);  // multiple of 16 bytes (md % 16 == 0)
     size_t stage = (size_t)max_dim * max_dim * 4;             // room for a max_dim x max_dim block, capped by 64 KiB of LDS
-    if (base + stage > 65536) stage = base < 65536 ? (65536 - base) / 16 * 16 : 0;
-    const size_t lds = base + stage;
+    const size_t pad = 512;   // lsap_reg2 reads column lane + 64 of a cost row unconditionally (discarded when >= nc)
+    if (base + stage + pad > 65536) stage = base + pad < 65536 ? (65536 - base - pad) / 16 * 16 : 0;
+    const size_t lds = base + stage + pad;
+    static const int v1 = getenv("SVOL_LSAP_V1") != nullptr;   // round 2's search step (A/B)
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(lsap_kernel, dim3((unsigned)n_problems), dim3(64), lds, s, cost, cost_off, pred_off, pred_cnt, tgt_off,
-                       tgt_cnt, match, status, md, (int)(stage / 4));
+                       tgt_cnt, match, status, md, (int)(stage / 4), v1);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }

@@ -777,6 +777,19 @@ def check_lsap_vs_scipy(n_cases=60):
             costs.append(rng.random_sample((nr, nc)).astype(np.float32))
         else:
             costs.append(np.zeros((nr, nc), np.float32))
+    # round 6 (lsap_reg2: arg-min on the keys' upper words first): values that SHARE the upper word of their fp64 key but differ
+    # below it (1 + k * 2^-23: the search's candidates then go through the full (cost, preference) procedure), the same mixed with
+    # exact ties, signed zeros, and sums of a few distinct magnitudes (duals that cancel to +-0)
+    for i in range(24):
+        nr, nc = rng.randint(2, 120), rng.randint(2, 70)
+        k = rng.randint(0, 6 if i % 2 else 200, size=(nr, nc)).astype(np.float32)
+        c = np.float32(1.0) + k * np.float32(2.0 ** -23)
+        if i % 4 == 2:
+            c = (rng.randint(-2, 3, size=(nr, nc)) * np.float32(0.25)).astype(np.float32)
+            c[rng.random_sample((nr, nc)) < 0.2] = np.float32(-0.0)
+        if i % 4 == 3:
+            c = (rng.choice([0.5, 1.0, 1.5, 1e-3, 3.0], size=(nr, nc)) + k * np.float32(2.0 ** -24)).astype(np.float32)
+        costs.append(np.ascontiguousarray(c, dtype=np.float32))
     P = len(costs)
     pred_cnt = np.array([c.shape[0] for c in costs], np.int32)
     tgt_cnt = np.array([c.shape[1] for c in costs], np.int32)
