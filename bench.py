@@ -116,6 +116,8 @@ def main():
                     help='N=1 only: replay the whole step as one captured hipGraph (removes the ~15 ms/step of host issue time, '
                          'but a captured graph serialises the query-stream / video-stream overlap: measured slower)')
     ap.add_argument('--no-graph', action='store_true', help='accepted for compatibility (eager is the default)')
+    ap.add_argument('--opt-in-backward', action='store_true',
+                    help='lab: FlatAdamW(zero_grads=True, step_in_backward=True) — bucket updates issued during backward, buckets zeroed by the update kernel')
     ap.add_argument('--batch', type=int, default=None, help='videos per GPU (default: 8, cfg5: 1)')
     ap.add_argument('--dropout', type=float, default=None,
                     help="--workload encdec: the Transformer's dropout (reference default 0.1; the bench default stays 0 = round 3's line)")
@@ -241,7 +243,13 @@ def main():
     if use_graph:  # (the captured step keeps torch's capturable optimizer: its step counter lives on the device)
         opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, fused=True, capturable=True)  # train.py:98-99
     else:  # the same update as one streaming kernel per gradient bucket (svol_amd.parallel.FlatAdamW)
-        opt = parallel.FlatAdamW(reducer, lr=1e-4, weight_decay=1e-4, params=params)
+        # --opt-in-backward (lab, off by default): zero_grads = optimizer.zero_grad() of the next iteration (train.py:222) folded
+        # into the update kernel; step_in_backward = a bucket's update right behind its gradients (and its all-reduce) instead of
+        # all six behind the whole backward — same arithmetic (bit-identical parameters in the deterministic mode), the step
+        # boundary 0.95 -> 0.85 ms on one clock and the STEP +-0: the updates then run beside memory-bound kernels of the
+        # backward, whose time grows by what the boundary lost
+        opt = parallel.FlatAdamW(reducer, lr=1e-4, weight_decay=1e-4, params=params, zero_grads=a.opt_in_backward,
+                                 step_in_backward=a.opt_in_backward)
     # weak scaling: every rank gets its own B videos (different seeds = a properly sharded global batch)
     inp = {k: v.to(dev) for k, v in syn.synth_inputs(args, B, T, P, seed=1 + rank).items()}
     tg = syn.synth_targets(B, T, seed=1 + rank)
@@ -274,6 +282,8 @@ def main():
 
     fence = parallel.StepFence(a.max_inflight) if a.max_inflight > 0 else None
 
+    turn_sleep_cycles = int(float(os.environ.get('SVOL_BENCH_TURN_SLEEP_US', '0')) * 2309.0)   # (torch.cuda._sleep spins on the shader clock: 1e6 cycles = 433 us measured, tools/lab_power_bound.sh)
+
     def step():
         reducer.zero_grad()
         if backbone is not None:
@@ -282,6 +292,8 @@ def main():
         out = model(inp['src_sketch'], inp['src_sketch_mask'], inp['src_video'], inp['src_video_mask'])
         ld = crit(out, tg)
         loss = crit.weighted_total()  # = sum(ld[k] * wd[k] for k in ld if k in wd) (train.py:227-228), one multiply + one reduction
+        if turn_sleep_cycles:   # (lab: an idle gap of known length on the forward -> backward dependency chain)
+            torch.cuda._sleep(turn_sleep_cycles)
         (scaler.scale(loss) if scaler is not None else (loss * loss_scale if loss_scale != 1.0 else loss)).backward()
         reducer.finish(mean=use_graph)   # the 1 / world of the gradient mean rides FlatAdamW's update kernel
         opt.step()

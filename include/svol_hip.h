@@ -77,6 +77,11 @@ int svol_cast_split(const float* src, int64_t ld_src, void* dst_hilo, int64_t R,
  *   p -= lr/(1 - b1^step) * m / (sqrt(v)/sqrt(1 - b2^step) + eps).          step counts from 1. */
 int svol_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int64_t step, float grad_scale, void* stream);
+/* The same update; the gradient range is ZEROED behind its read (round 6, ABI 7): optimizer.zero_grad() of the next iteration
+ * (train.py:222) folded into the step, so that the step boundary — a chain of small dependent launches with the chip idle — loses
+ * one fill launch per gradient bucket.  For a caller whose loop reads no gradient between step() and zero_grad(). */
+int svol_adamw_flat_zero(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int64_t step, float grad_scale, void* stream);
 /* Dynamic loss scaling for fp16 operands (the reference's fp16 mode is apex amp: dynamic scale, overflowed steps skipped,
  * configs.py:52-61, train.py:111-114,231-232), without a host synchronisation.  scaler_state: four floats on the DEVICE —
  * [0] the loss scale (the caller multiplies the loss by it ON THE DEVICE), [1] overflow flag of the current step, [2] clean steps since

@@ -49,6 +49,7 @@ SIGNATURES = {
     'svol_patchify': [_p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p],
     'svol_vit_embed': [_p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p],
     'svol_adamw_flat': [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _p],
+    'svol_adamw_flat_zero': [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _p],
     'svol_grad_finite': [_p, _i64, _p, _p],
     'svol_adamw_flat_scaled': [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _p, _p],
     'svol_loss_scaler_update': [_p, _f32, _f32, _i64, _f32, _f32, _p],

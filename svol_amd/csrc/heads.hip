@@ -14,6 +14,7 @@
 // every compute mode.  A workgroup = 32 rows of the [R, D] query-state matrix (R = layers * B * N); the tile and
 // the hidden activations live in LDS, a wave owns 32-column chunks of a layer's output and streams the weight rows from L2.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "../../include/svol_hip.h"
 #include "common.h"
@@ -130,7 +131,7 @@ __device__ inline void small_out(const float* __restrict__ Xs, int ldx, const fl
 
 __device__ inline void load_tile(float* __restrict__ Xs, int ldx, const float* __restrict__ X, int row0, int R, int D, int tid) {
     const int q = D >> 2;   // float4 per row
-    for (int i = tid; i < HT * q; i += 256) {
+    for (int i = tid; i < HT * q; i += (int)blockDim.x) {
         const int row = i / q, c = (i - row * q) * 4;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (row0 + row < R) v = *reinterpret_cast<const f32x4*>(X + (int64_t)(row0 + row) * D + c);
@@ -138,16 +139,20 @@ __device__ inline void load_tile(float* __restrict__ Xs, int ldx, const float* _
     }
 }
 
-__global__ __launch_bounds__(256) void heads_fwd_kernel(HeadsArgs p) {
+// 256 or 512 threads (round 6, second half): a 32-column chunk is 128 dependent MFMAs (~4 us) behind weight rows that arrive as 64
+// scattered 16-byte pieces per load instruction; with 8 waves a wave owns ONE chunk per layer at D = 256 instead of two and a SIMD's
+// two waves cover each other's load latency.  The row-per-8-threads sections run on the first 256 threads.
+__global__ __launch_bounds__(512) void heads_fwd_kernel(HeadsArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int D = p.D, ld = D + HPAD;
     float* Xs = lds;             // hs tile, later h2
     float* Hs = lds + HT * ld;   // h1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int row0 = blockIdx.x * HT;
+    const int cstride = ((int)blockDim.x >> 6) * 32;   // columns the workgroup's waves cover per round
     load_tile(Xs, ld, p.hs, row0, p.R, D, tid);
     __syncthreads();
-    {   // class logits: Linear(d, 2) (svanet.py:44,125)
+    if (tid < 256) {   // class logits: Linear(d, 2) (svanet.py:44,125)
         float lg[2];
         small_out<2>(Xs, ld, p.Wc, p.bc, D, tid, lg);
         const int row = tid >> 3;
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(HeadsArgs p) {
         const float* bias = layer == 0 ? p.b0 : p.b1;
         float* out = layer == 0 ? p.h1 : p.h2;
         // (layer 1 overwrites the hs tile with h2: every wave has passed the barrier behind layer 0, i.e. has read the tile for the last time)
-        for (int n0 = wave * 32; n0 < D; n0 += 128) {
+        for (int n0 = wave * 32; n0 < D; n0 += cstride) {
             const f32x16 acc = tile_nt(src, ld, W, D, n0, D, r, h);
             const float bn = bias[n0 + r];
 #pragma unroll
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(HeadsArgs p) {
         if (layer == 0) __syncthreads();   // h1 complete before layer 1 reads it
     }
     __syncthreads();
-    {   // layer 2: Linear(d, 4) -> sigmoid (svanet.py:126-127)
+    if (tid < 256) {   // layer 2: Linear(d, 4) -> sigmoid (svanet.py:126-127)
         float bx[4];
         small_out<4>(Xs, ld, p.W2, p.b2, D, tid, bx);
         const int row = tid >> 3;
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(HeadsArgs p) {
     }
 }
 
-__global__ __launch_bounds__(256) void heads_bwd_kernel(HeadsBwdArgs p) {
+__global__ __launch_bounds__(512) void heads_bwd_kernel(HeadsBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int D = p.D, ld = D + HPAD;
     float* As = lds;                 // g_pre1, later the hs tile (for dWc)
@@ -214,12 +219,13 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadsBwdArgs p) {
         sm[tid * 8 + 4] = gl[0];
         sm[tid * 8 + 5] = gl[1];
     }
+    const int nthr = (int)blockDim.x, cstride = (nthr >> 6) * 32;
     load_tile(Bs, ld, p.h2, row0, p.R, D, tid);
     __syncthreads();
     {   // dh2 = g_pre2 W2 (K = 4), g_pre1 = dh2 * [h2 > 0]  ->  As, and the 4-row weight gradient dW2 += g_pre2^T h2, db2 += colsum(g_pre2)
-        const int row = tid >> 3, part = tid & 7;
+        const int row = (tid & 255) >> 3, part = tid & 7;
         const float g0 = sm[row * 8], g1 = sm[row * 8 + 1], g2 = sm[row * 8 + 2], g3 = sm[row * 8 + 3];
-        for (int c = part * 4; c < D; c += 32) {
+        for (int c = part * 4; c < (tid < 256 ? D : 0); c += 32) {
             const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.W2 + c), w1 = *reinterpret_cast<const f32x4*>(p.W2 + D + c);
             const f32x4 w2 = *reinterpret_cast<const f32x4*>(p.W2 + 2 * D + c), w3 = *reinterpret_cast<const f32x4*>(p.W2 + 3 * D + c);
             const f32x4 hv = *reinterpret_cast<const f32x4*>(Bs + row * ld + c);
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadsBwdArgs p) {
             *reinterpret_cast<f32x4*>(As + row * ld + c) = v;
             if (row0 + row < p.R) *reinterpret_cast<f32x4*>(p.gp1 + (int64_t)(row0 + row) * D + c) = v;
         }
-        for (int c = tid; c < D; c += 256) {   // column c of dW2's four rows: sum over the tile's rows
+        for (int c = tid; c < D; c += nthr) {   // column c of dW2's four rows: sum over the tile's rows
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
             for (int m = 0; m < HT; ++m) {
                 const float x = Bs[m * ld + c];
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadsBwdArgs p) {
     }
     __syncthreads();
     // dh1 = g_pre1 W1, g_pre0 = dh1 * [h1 > 0]  ->  Bs
-    for (int n0 = wave * 32; n0 < D; n0 += 128) {
+    for (int n0 = wave * 32; n0 < D; n0 += cstride) {
         const f32x16 acc = tile_nn(As, ld, p.W1, D, n0, D, r, h);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadsBwdArgs p) {
     }
     __syncthreads();
     // dhs = g_pre0 W0 + dlogits Wc; then the hs tile for the 2-row weight gradient dWc += dlogits^T hs
-    for (int n0 = wave * 32; n0 < D; n0 += 128) {
+    for (int n0 = wave * 32; n0 < D; n0 += cstride) {
         const f32x16 acc = tile_nn(Bs, ld, p.W0, D, n0, D, r, h);
         const float wc0 = p.Wc[n0 + r], wc1 = p.Wc[D + n0 + r];
 #pragma unroll
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadsBwdArgs p) {
     }
     load_tile(As, ld, p.hs, row0, p.R, D, tid);   // (As = g_pre1 was last read by the dh1 products, two barriers ago)
     __syncthreads();
-    for (int c = tid; c < D; c += 256) {
+    for (int c = tid; c < D; c += nthr) {
         float a0 = 0.f, a1 = 0.f;
         for (int m = 0; m < HT; ++m) {
             const float x = As[m * ld + c];
@@ -318,6 +324,12 @@ __global__ void weighted_total_bwd_kernel(const float* __restrict__ w, const flo
     if (i < n) dx[i] = w[i] * dout[0];
 }
 
+// 8 waves when the layer has at least 8 chunks of 32 columns (D >= 256); SVOL_HEADS_WAVES=4: round 6's first form (A/B)
+inline unsigned heads_threads(int64_t D) {
+    static const int w = getenv("SVOL_HEADS_WAVES") ? atoi(getenv("SVOL_HEADS_WAVES")) : 8;
+    return (w >= 8 && D >= 256) ? 512u : 256u;
+}
+
 }  // namespace
 
 extern "C" {
@@ -334,7 +346,7 @@ int svol_heads_fwd(const float* hs, const float* Wc, const float* bc, const floa
     const size_t lds = (size_t)2 * HT * (D + HPAD) * sizeof(float);
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(heads_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return SVOL_E_LAUNCH;
-    hipLaunchKernelGGL(heads_fwd_kernel, dim3((unsigned)((R + HT - 1) / HT)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(heads_fwd_kernel, dim3((unsigned)((R + HT - 1) / HT)), dim3(heads_threads(D)), lds, reinterpret_cast<hipStream_t>(stream), p);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }
@@ -354,7 +366,7 @@ int svol_heads_bwd(const float* dlogits, const float* dboxes, const float* hs, c
     const size_t lds = ((size_t)2 * HT * (D + HPAD) + HT * 8) * sizeof(float);
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(heads_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return SVOL_E_LAUNCH;
-    hipLaunchKernelGGL(heads_bwd_kernel, dim3((unsigned)((R + HT - 1) / HT)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(heads_bwd_kernel, dim3((unsigned)((R + HT - 1) / HT)), dim3(heads_threads(D)), lds, reinterpret_cast<hipStream_t>(stream), p);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
 }

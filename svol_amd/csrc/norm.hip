@@ -427,7 +427,9 @@ int svol_posenc_sine(const float* mask, void* pos, int64_t B, int64_t L, int64_t
 // ---- AdamW over a flat fp32 range (torch.optim.AdamW semantics; reference train.py:98-99) ---------------------------------
 // One streaming pass: p, g, m, v read once, p, m, v written once (28 bytes per parameter); 4 parameters per thread.
 namespace {
-__global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+// ZERO: the gradient range is zeroed behind its read (svol_adamw_flat_zero: the step boundary loses the caller's fill launches)
+template <bool ZERO>
+__global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, int64_t n4, int64_t n, float decay, float b1, float b2,
                                                          float step_size, float inv_bc2_sqrt, float eps, float gscale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -445,6 +447,7 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
         *reinterpret_cast<f32x4*>(p + 4 * i) = pp;
         *reinterpret_cast<f32x4*>(m + 4 * i) = mm;
         *reinterpret_cast<f32x4*>(v + 4 * i) = vv;
+        if constexpr (ZERO) *reinterpret_cast<f32x4*>(g + 4 * i) = f32x4{0.f, 0.f, 0.f, 0.f};
     } else if (i == n4) {  // scalar tail (n % 4 elements)
         for (int64_t j = 4 * n4; j < n; ++j) {
             const float gr = g[j] * gscale;
@@ -453,6 +456,7 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
             const float vj = v[j] * b2 + (1.f - b2) * gr * gr;
             pj -= step_size * (mj / (sqrtf(vj) * inv_bc2_sqrt + eps));
             p[j] = pj; m[j] = mj; v[j] = vj;
+            if constexpr (ZERO) g[j] = 0.f;
         }
     }
 }
@@ -554,8 +558,8 @@ extern "C" int svol_loss_scaler_update(float* scaler_state, float growth_factor,
     return SVOL_OK;
 }
 
-extern "C" int svol_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                               float weight_decay, int64_t step, float grad_scale, void* stream) {
+static int adamw_flat_launch(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int64_t step, float grad_scale, bool zero, void* stream) {
     if (!p || !g || !m || !v || n < 0 || step <= 0) return SVOL_E_INVALID;
     if (n == 0) return SVOL_OK;
     if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return SVOL_E_UNSUPPORTED;
@@ -563,9 +567,21 @@ extern "C" int svol_adamw_flat(float* p, const float* g, float* m, float* v, int
     const int64_t n4 = n / 4;
     const int64_t blocks = (n4 + 1 + 255) / 256;
     if (blocks >= (1ll << 31)) return SVOL_E_UNSUPPORTED;
-    hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n4, n,
-                       1.f - lr * weight_decay, beta1, beta2, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), eps, grad_scale);
+    if (zero)
+        hipLaunchKernelGGL(adamw_flat_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n4, n,
+                           1.f - lr * weight_decay, beta1, beta2, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), eps, grad_scale);
+    else
+        hipLaunchKernelGGL(adamw_flat_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n4, n,
+                           1.f - lr * weight_decay, beta1, beta2, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), eps, grad_scale);
     SVOL_CHECK_LAUNCH();
     return SVOL_OK;
+}
+extern "C" int svol_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int64_t step, float grad_scale, void* stream) {
+    return adamw_flat_launch(p, const_cast<float*>(g), m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, false, stream);
+}
+extern "C" int svol_adamw_flat_zero(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                                    float weight_decay, int64_t step, float grad_scale, void* stream) {
+    return adamw_flat_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, true, stream);
 }
 

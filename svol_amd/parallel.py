@@ -114,6 +114,8 @@ class BucketedGradAllReduce:
             raise ValueError('SVOL_ALLREDUCE_SPIN must be ring or direct')
         self._spin_cycles_per_ms = None
         self.pending_scale = 1.0   # see finish(mean=False)
+        self.on_bucket_reduced = None   # FlatAdamW(step_in_backward=True): callable(bucket index, stream handle), see _launch
+        self._early_any = False
         self.fire_order: List[int] = []   # diagnostics: bucket index of every hook of the current step, in firing order
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         # the stream the caller computes on (the video half of the model, the criterion, the optimizer); re-read
@@ -179,7 +181,11 @@ class BucketedGradAllReduce:
         return out
 
     def _launch(self, b):
-        if self.world == 1 and not self.force:
+        collective = not (self.world == 1 and not self.force)
+        early = self.on_bucket_reduced is not None and self.on_gpu
+        if not collective:
+            if early:
+                self._early_step_local(b)
             return
         if self.on_gpu:
             # The hook runs on the autograd thread under the stream guard of the LAST-arriving parameter's node.  That
@@ -204,9 +210,33 @@ class BucketedGradAllReduce:
                     h.wait()       # (stream-side wait: orders the communication stream behind the collective, does not block the host)
                     e1.record(self.comm_stream)
                     self.spans.append((next(i for i, x in enumerate(self.buckets) if x is b), e0, e1))
+                if early:          # the bucket's optimizer update right behind its exchange, on the communication stream
+                    h.wait()
+                    self._early_any = True
+                    self.on_bucket_reduced(next(i for i, x in enumerate(self.buckets) if x is b), self.comm_stream.cuda_stream)
         else:
             h = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._handles.append((h, b))
+
+    def _early_step_local(self, b):
+        """world size 1, FlatAdamW(step_in_backward=True): the bucket's update as soon as its gradients are final, on the communication
+        stream behind every producer stream's work so far.  Weight-gradient launches still QUEUED on the host (ops: deferred to
+        the next large attention backward) belong in front of it: the update joins that queue behind them, so the deferral keeps its
+        schedule and the update lands beside the attention backward — an issue-bound launch that leaves the memory side idle."""
+        from . import ops
+        bi = next(i for i, x in enumerate(self.buckets) if x is b)
+
+        def issue():
+            for s in self._producer_streams():
+                self.comm_stream.wait_stream(s)
+            self._early_any = True
+            self.on_bucket_reduced(bi, self.comm_stream.cuda_stream)
+
+        if ops._WGRAD_PENDING:
+            ops._WGRAD_PENDING.append(issue)
+            ops.arm_wgrad_flush()
+        else:
+            issue()
 
     def modelled_exchange_ms(self, nbytes: int, ranks: int = 8, link_gbs: float = 153.0) -> float:
         """duration of one bucket's all-reduce over xGMI in the SVOL_ALLREDUCE_SPIN model (see __init__)."""
@@ -236,8 +266,12 @@ class BucketedGradAllReduce:
             ops.drop_pending_wgrad()   # weight-gradient launches a failed backward left queued must not land in the zeroed buckets
         self.fire_order = []
         self.spans = []
+        self._early_any = False
         for b in self.buckets:
-            b['flat'].zero_()
+            if b.pop('clean', False):
+                pass   # FlatAdamW(zero_grads=True) zeroed the range behind its read of it (svol_adamw_flat_zero)
+            else:
+                b['flat'].zero_()
             b['pending'] = b['n']
             for p in b['params']:
                 if p.grad is None or p.grad.data_ptr() < b['flat'].data_ptr() or \
@@ -268,6 +302,8 @@ class BucketedGradAllReduce:
                 self._launch(b)
         for h, b in self._handles:
             h.wait()
+        if self.on_gpu and self._early_any and not collective:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)   # bucket updates issued during backward (FlatAdamW(step_in_backward=True))
         if self.on_gpu and collective:
             cur = torch.cuda.current_stream()
             if self.record_spans:   # what the caller's stream waits here is the exchange that backward did not cover
@@ -362,7 +398,15 @@ class FlatAdamW(torch.optim.Optimizer):
     to the reducer's own parameters in bucket order."""
 
     def __init__(self, reducer: 'BucketedGradAllReduce', lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
-                 params: Optional[Iterable[torch.nn.Parameter]] = None):
+                 params: Optional[Iterable[torch.nn.Parameter]] = None, zero_grads: bool = False, step_in_backward: bool = False):
+        """zero_grads: the update kernel zeroes each gradient bucket behind its read (``svol_adamw_flat_zero``) and the reducer's next
+        ``zero_grad()`` skips its fill — the reference loop's ``optimizer.zero_grad()`` (train.py:222) folded into ``step()``; for a
+        loop that reads no ``param.grad`` between ``step()`` and ``zero_grad()``.
+        step_in_backward: a bucket's update is issued as soon as its gradients are final (behind its all-reduce at world size > 1),
+        on the reducer's communication stream, instead of all of them in ``step()`` behind the whole backward; ``step()`` then only
+        updates what is left (the last bucket) and closes the step.  Same arithmetic on the same values: the reference has no
+        gradient clipping or any other cross-bucket dependency between backward and the update (train.py:229-234).  NOT for a loop
+        that may skip ``step()`` after ``backward()``; ignored while a loss scaler is attached (its overflow check spans all buckets)."""
         owned = [p for b in reducer.buckets for p in b['params']]
         plist = list(params) if params is not None else owned
         self._params_given = params is not None
@@ -391,6 +435,11 @@ class FlatAdamW(torch.optim.Optimizer):
                 p.data = flat_p[off:off + n].view_as(p)  # same layout as the gradient views of the bucket
                 self._slot[id(p)] = (bi, off, n)
             self.flat.append({'p': flat_p, 'm': torch.zeros_like(flat_p), 'v': torch.zeros_like(flat_p)})
+        self.zero_grads = bool(zero_grads)
+        self.step_in_backward = bool(step_in_backward)
+        self._stepped = [False] * len(self.flat)
+        if self.step_in_backward:
+            reducer.on_bucket_reduced = self._step_bucket_early
 
     # With a scaler attached the bias-correction step count is the DEVICE count of updates really taken (scaler.state[3]: an
     # overflow-skipped step does not advance it, as apex + torch AdamW do not advance 'step').  It is what checkpoints carry
@@ -448,12 +497,34 @@ class FlatAdamW(torch.optim.Optimizer):
         self.t += 1
         gscale = float(self.reducer.pending_scale) / float(self.loss_scale)
         self.reducer.pending_scale = 1.0
-        for b, st in zip(self.reducer.buckets, self.flat):
-            rc = _lib.lib().svol_adamw_flat(_ptr(st['p']), _ptr(b['flat']), _ptr(st['m']), _ptr(st['v']), st['p'].numel(),
-                                            float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
-                                            float(g['weight_decay']), self.t, gscale, _stream())
-            _lib.check(rc, 'svol_adamw_flat')
+        for bi, (b, st) in enumerate(zip(self.reducer.buckets, self.flat)):
+            if self._stepped[bi]:      # updated during backward (_step_bucket_early), with this step's count
+                self._stepped[bi] = False
+                continue
+            self._launch_bucket(b, st, g, self.t, gscale, _stream())
         return loss
+
+    def _launch_bucket(self, b, st, g, t, gscale, stream):
+        from . import _lib
+        from .ops import _ptr
+        fn = _lib.lib().svol_adamw_flat_zero if self.zero_grads else _lib.lib().svol_adamw_flat
+        rc = fn(_ptr(st['p']), _ptr(b['flat']), _ptr(st['m']), _ptr(st['v']), st['p'].numel(), float(g['lr']), float(g['betas'][0]),
+                float(g['betas'][1]), float(g['eps']), float(g['weight_decay']), t, gscale, stream)
+        _lib.check(rc, 'svol_adamw_flat_zero' if self.zero_grads else 'svol_adamw_flat')
+        if self.zero_grads:
+            b['clean'] = True
+
+    @torch.no_grad()
+    def _step_bucket_early(self, bi, stream):
+        """reducer callback (step_in_backward): bucket ``bi``'s gradients are final and ``stream`` is ordered behind every kernel
+        that wrote them or read its parameters in this step."""
+        if self._scaler is not None or self._stepped[bi]:
+            return
+        g = self.param_groups[0]
+        world = self.reducer.world
+        gscale = (1.0 / world if world > 1 else 1.0) / float(self.loss_scale)
+        self._launch_bucket(self.reducer.buckets[bi], self.flat[bi], g, self.t + 1, gscale, stream)
+        self._stepped[bi] = True
 
     def zero_grad(self, set_to_none=False):
         self.reducer.zero_grad()

@@ -297,3 +297,84 @@ print('RUNS', a[0], b[0], a[1], b[1])
     assert res[True][2] == res[True][2] and abs(res[True][2]) < 1e4
     # the mode changes summation orders, not the algorithm: same loss as the default mode to rounding
     assert abs(res[True][2] - res[False][2]) <= 2e-2 * max(1.0, abs(res[False][2]))
+
+
+@pytest.mark.gpu
+def test_optimizer_updates_issued_during_backward_change_nothing():
+    """Round 6: FlatAdamW(zero_grads=True, step_in_backward=True) — a bucket's update is issued as soon as its gradients are final, on the
+    reducer's communication stream (behind the deferred weight-gradient launches of the bucket), and zeroes the bucket behind its
+    read; step() only updates what is left.  The same kernels on the same values in another ORDER: under SVOL_DETERMINISTIC=1 (one
+    adder per output element everywhere) four optimisation steps must leave parameters, both moment buffers and losses BIT-identical
+    to the plain optimizer's — a bucket updated before its last gradient landed, a reader of a parameter overtaken by its update, or a
+    gradient range zeroed too early / not at all would all show.  Also asserted: every bucket but the last really went early, the
+    reducer's zero_grad() skipped its fills, and (second half, SVOL_FORCE_ALLREDUCE=1) the same with a one-rank RCCL all-reduce per
+    bucket in front of each update.  The library reads SVOL_DETERMINISTIC once: child processes."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import hashlib, os, torch
+import torch.distributed as dist
+from svol_amd import parallel
+from svol_amd import synthetic as syn
+from svol_amd.modeling.loss import build_loss
+from svol_amd.modeling.svanet import build_svanet
+if os.environ.get('SVOL_FORCE_ALLREDUCE') == '1':
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29671')
+    dist.init_process_group('nccl', rank=0, world_size=1)
+args = syn.head_args(hidden_dim=256, nheads=8, num_layers=3, num_queries=100, num_frames=8, input_vid_dim=512, input_skch_dim=512,
+                     input_dropout=0.1, matcher='video_matcher')
+args.compute_dtype = 'bf16'
+B, T, P = 2, 8, 192
+def run(early):
+    torch.manual_seed(1)
+    model = build_svanet(args).cuda().train()
+    crit = build_loss(args).cuda().train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    red = parallel.BucketedGradAllReduce(parallel.arrival_order(model), skip=parallel.unused_parameters(model), bucket_bytes=2 << 20)
+    opt = parallel.FlatAdamW(red, lr=1e-3, weight_decay=1e-4, params=params, zero_grads=early, step_in_backward=early)
+    inp = {k: v.cuda() for k, v in syn.synth_inputs(args, B, T, P, seed=3).items()}
+    tg = syn.synth_targets(B, T, seed=3)
+    h = hashlib.sha256()
+    went_early, fills_skipped = [], []
+    for _ in range(4):
+        fills_skipped.append(sum(1 for b in red.buckets if b.get('clean')))
+        red.zero_grad()
+        out = model(inp['src_sketch'], inp['src_sketch_mask'], inp['src_video'], inp['src_video_mask'])
+        crit(out, tg)
+        loss = crit.weighted_total()
+        loss.backward()
+        red.finish(mean=False)
+        went_early.append(sum(opt._stepped))
+        opt.step()
+        h.update(loss.detach().cpu().numpy().tobytes())
+    torch.cuda.synchronize()
+    for p in params:
+        h.update(p.detach().cpu().numpy().tobytes())
+    for st in opt.flat:
+        h.update(st['m'].cpu().numpy().tobytes()); h.update(st['v'].cpu().numpy().tobytes())
+    return h.hexdigest(), float(loss), len(red.buckets), went_early, fills_skipped
+a = run(False)
+b = run(True)
+print('RUNS', a[0], b[0], a[1], b[1], a[2], '|', b[3], '|', b[4], '|', a[3], '|', a[4])
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for force in (False, True):
+        env = dict(os.environ, PYTHONPATH=root, SVOL_DETERMINISTIC='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+        env.pop('SVOL_FORCE_ALLREDUCE', None)
+        if force:
+            env['SVOL_FORCE_ALLREDUCE'] = '1'
+        r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('RUNS')][0]
+        head, early_s, skipped_s, plain_early_s, plain_skipped_s = [x.strip() for x in line.split('|')]
+        f = head.split()
+        nb = int(f[5])
+        print('force' if force else 'local', line)
+        assert nb >= 3, 'one bucket only: nothing can go early'
+        assert f[1] == f[2], 'updates issued during backward changed the parameters / moments / losses'
+        assert float(f[3]) == float(f[4]) and abs(float(f[3])) < 1e4
+        early, skipped = eval(early_s), eval(skipped_s)
+        assert all(e >= nb - 1 for e in early), (early, nb)          # every bucket but (at most) the last one went early, every step
+        assert skipped[0] == 0 and all(k == nb for k in skipped[1:]), skipped   # from the second step on zero_grad() had nothing to fill
+        assert eval(plain_early_s) == [0] * 4 and eval(plain_skipped_s) == [0] * 4

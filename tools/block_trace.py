@@ -26,7 +26,8 @@ def main():
     crit = build_loss(args).to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
     reducer = parallel.BucketedGradAllReduce(parallel.arrival_order(model), skip=parallel.unused_parameters(model), ordered=True)
-    opt = parallel.FlatAdamW(reducer, lr=1e-4, weight_decay=1e-4, params=params)
+    plain = os.environ.get('SVOL_TRACE_OPT_IN_BACKWARD') is None   # (bench.py --opt-in-backward)
+    opt = parallel.FlatAdamW(reducer, lr=1e-4, weight_decay=1e-4, params=params, zero_grads=not plain, step_in_backward=not plain)
     inp = {k: v.to(dev) for k, v in syn.synth_inputs(args, B, T, P, seed=1).items()}
     tg = syn.synth_targets(B, T, seed=1)
     fence = parallel.StepFence(2)
@@ -66,6 +67,12 @@ def main():
             print(f'# video-stream block programs: span {span:.3f} ms, busy {busy:.3f} ms, idle {span - busy:.3f} ms in {len(gaps)} gaps; largest:')
             for g in gaps[:5]:
                 print(f'#   {g[0]:.3f} ms at {g[1]:.3f}: after {g[2][:44]} before {g[3][:44]}')
+            turns = [g[0] for g in gaps if 'svol_layernorm' in g[2] and 'svol_layernorm_bwd' in g[3]]
+            bounds = [g[0] for g in gaps if 'svol_gate_bwd' in g[2] and 'svol_gate_fwd' in g[3]]
+            if turns and bounds:
+                med = lambda v: sorted(v)[len(v) // 2]
+                print(f'# forward -> backward turn (LN3 end to LN3\' start): median {med(turns):.3f} ms over {len(turns)}; '
+                      f'step boundary (gate\' end to gate start): median {med(bounds):.3f} ms over {len(bounds)}')
         return
     tot = 0.0
     print(f'# {steps} steps, {ms:.2f} ms/step with the trace events; per step:')
