@@ -257,9 +257,17 @@ def test_dq_image_zeroed_beside_the_previous_layers_attention_backward_changes_n
             assert torch.equal(a['pred_logits'], b['pred_logits']) and torch.equal(a['pred_boxes'], b['pred_boxes'])
         assert tot_on == tot_off
         assert g_on.keys() == g_off.keys()
+        # per parameter against its own largest entry — plus a floor of 1e-4 of the largest gradient entry of the model: at this depth
+        # some parameters (layer 0's query self-attention in_proj: the object queries enter as zeros) have gradients of 1e-9 that are
+        # rounding noise of two identical runs already; and norm-wise over the whole gradient
+        gmax = max(float(g_off[k].abs().max()) for k in g_off)
+        num = den = 0.0
         for k in g_on:
             scale = float(g_off[k].abs().max())
-            assert float((g_on[k] - g_off[k]).abs().max()) <= 2e-2 * scale + 1e-12, k
+            assert float((g_on[k] - g_off[k]).abs().max()) <= 2e-2 * scale + 1e-4 * gmax, k
+            num += float((g_on[k].double() - g_off[k].double()).pow(2).sum())
+            den += float(g_off[k].double().pow(2).sum())
+        assert (num / den) ** 0.5 <= 1e-2, (num / den) ** 0.5
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16], ids=['fp32', 'bf16', 'fp16'])
