@@ -1,10 +1,11 @@
+# kernel statistics of the attention backward launch group with (on) / without (off) SVOL_DQ_PREZERO=1:  bash tools/kt_prezero.sh  -> gpurun_out/kt_{on,off}/
 set -e
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
 for V in on off; do
   O=$R/gpurun_out/kt_$V; rm -rf $O; mkdir -p $O
-  if [ $V = off ]; then export SVOL_NO_DQ_PREZERO=1; fi
+  if [ $V = off ]; then unset SVOL_DQ_PREZERO; else export SVOL_DQ_PREZERO=1; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o r -- python3 bench.py --steps 6 --warmup 3 --blocks 1 --no-cpu-baseline > $O/bench.json 2> $O/bench.err
   F=$(find $O/kt -name "*kernel_stats.csv" | head -1)
   grep -E "sp_prep|sp_zero|attn_bwd_sp_bf16|dq_round" $F > $O/stats.txt || true
